@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of volume_render forward + backward on synthetic
+800x800 renders of the depth-8 SH9 shell tree (BASELINE.json configs[2]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one ray batch: VolumeRenderer.forward
+on Q = 800*800 rays followed by backward() of a fixed upstream gradient, i.e.
+volume_render + volume_render_backward through the autograd.Function surface.
+Inputs (tree topology, feature table, rays, upstream gradient) are resident in
+HBM before the timed region.  With N > 1 every rank holds a replica of the tree
+and renders its own camera (weak scaling: per-GPU work fixed); each step ends
+with the exchange a data-parallel caller needs: RCCL all-reduce(sum) of the
+feature gradient and all-gather of the rendered pixels.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+`roofline` (algorithmic bytes of the dominant kernel / its mean duration,
+against the 8 TB/s HBM peak) and `cpu_baseline` (the CPU oracle on the same
+workload, host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+WORKLOADS = {
+    # name: (depth, K, data_format, width, height)
+    "d8_sh9_800": (8, 28, "SH9", 800, 800),          # BASELINE configs[1]/[2] -- the metric's config
+    "d5_rgba_64": (5, 4, "RGBA", 64, 64),            # configs[0]
+    "d9_rgba32_1024": (9, 32, "RGBA", 1024, 1024),   # configs[3]
+}
+
+
+def algorithmic_bytes(cnt, Q, M, K, C):
+    """SURVEY.md 8(d).  cnt = (rays_hit, steps S, levels sum L, valid, active)."""
+    _, S, L, V, A = cnt
+    march = 4 * L + 4 * S + 4 * V + 4 * (K - 1) * A
+    fwd = Q * (36 + 4 * (C + 1)) + march
+    bwd = 4 * M * K + Q * (36 + 4 * (C + 1)) + 2 * march + A * (8 * (K - 1) + 8)
+    return fwd, bwd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="d8_sh9_800", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forward-only", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+
+    import svox_t_amd as svox
+    import svox_t_amd.csrc as _C
+    from svox_t_amd import synth
+    from svox_t_amd.renderer import _rays_spec_from_rays
+
+    depth, K, fmt, W, H = WORKLOADS[args.workload]
+    Q = W * H
+    st = synth.shell_tree(depth)
+    feats = synth.shell_features(st.n_features, K)
+    tree = svox.N3Tree.from_arrays(st.child, st.data, st.parent_depth, feats, data_format=fmt, device=dev)
+    renderer = svox.VolumeRenderer(tree)
+    # rank r renders camera r (azimuth 30 + 45 r degrees), SURVEY.md 8(d)
+    pose = synth.camera_pose(azimuth_deg=30.0 + 45.0 * rank)
+    o, d, v = synth.pinhole_rays(W, H, c2w=pose)
+    rays = svox.Rays(o.to(dev), d.to(dev), v.to(dev))
+    features = tree.features
+    M = features.shape[0]
+    opt = renderer._get_options()
+    C = _C.get_out_data_dim(opt, K) - 1
+    gout = synth.grad_output(Q, C + 1).to(dev)
+
+    cnt = _C.count_forward(tree._spec(features), _rays_spec_from_rays(rays), opt).cpu().tolist()
+    bytes_fwd, bytes_bwd = algorithmic_bytes(cnt, Q, M, K, C)
+
+    gathered = None
+    if dist is not None:
+        gathered = torch.empty((world * Q, C + 1), dtype=torch.float32, device=dev)
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(i=None):
+        features.grad = None
+        e = ev[i] if i is not None else None
+        if e: e[0].record()
+        out = renderer(features, rays)
+        if e: e[1].record()
+        if not args.forward_only:
+            out.backward(gout)
+        if e: e[2].record()
+        if dist is not None:
+            dist.all_gather_into_tensor(gathered, out.detach())
+            if not args.forward_only:
+                dist.all_reduce(features.grad)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    bwd_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = world * Q / (elapsed / args.steps) / 1e6
+        if args.forward_only or fwd_ms >= bwd_ms:
+            dom, dom_ms, dom_bytes = "render_fwd_kernel", fwd_ms, bytes_fwd
+        else:
+            dom, dom_ms, dom_bytes = "render_bwd_kernel (+ grad memset)", bwd_ms, bytes_bwd
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        res = {
+            "metric": "Mrays/s fwd+bwd, 800×800 render, depth-8 SH9 N3Tree, 1→8 MI355X"
+                      if args.workload == "d8_sh9_800" and not args.forward_only
+                      else f"Mrays/s {'fwd' if args.forward_only else 'fwd+bwd'}, {args.workload}",
+            "value": round(value, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"depth-{depth} shell N3Tree (n_internal {st.n_internal}, M {M}), "
+                            f"{fmt} data_dim {K}, {W}x{H} pinhole rays per GPU, "
+                            f"{'forward' if args.forward_only else 'forward+backward'}, "
+                            f"step_size 1e-3, thresholds 0",
+                "rays_per_gpu": Q,
+                "partitioning": "replicated tree, one camera (ray batch) per GPU"
+                                + ("; all-gather of pixels + all-reduce of grad per step" if world > 1 else ""),
+            },
+            "kernel_ms": {"forward": round(fwd_ms, 4), "backward": round(bwd_ms, 4)},
+            "counters": dict(zip(("rays_hit", "steps", "levels", "valid", "active"), cnt)),
+            "algorithmic_bytes": {"forward": bytes_fwd, "backward": bytes_bwd},
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom,
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+            },
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(st, feats, o, d, v, fmt, K, gout.cpu(), args.forward_only)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(st, feats, o, d, v, fmt, K, gout, forward_only):
+    """The CPU oracle (oracle/, a restatement -- the reference's own CPU renderer
+    asserts) on the same workload, all host cores (OpenMP)."""
+    from oracle import oracle as O
+    from svox_t_amd.helpers import DataFormat
+    df = DataFormat(fmt)
+    ot = O.Tree(feats.numpy(), st.data, st.child)
+    opt = O.make_options(format=df.format, basis_dim=df.basis_dim)
+    Q = o.shape[0]
+    rays = (o.numpy(), d.numpy(), v.numpy())
+    t0 = time.perf_counter()
+    O.volume_render(ot, *rays, opt)
+    if not forward_only:
+        O.volume_render_backward(ot, *rays, opt, gout.numpy())
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(Q / dt / 1e6, 4),
+        "unit": "Mrays/s",
+        "cores": O.num_threads(),
+        "kind": "port",
+        "sample": f"the full workload once ({Q} rays, {'forward' if forward_only else 'forward+backward'}), "
+                  f"{dt:.1f} s wall, OpenMP over rays",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+/* svoxt.h -- C ABI of libsvoxt_hip.so, the MI355X (gfx950) implementation of
+ * svox_t's differentiable volume-render hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / pybind
+ * types.  Each entry point replaces one function of the reference's pybind11
+ * module `svox_t.csrc` (reference paths are relative to the svox_t checkout):
+ *
+ *   svoxt_volume_render_fwd   <- volume_render            svox_t/csrc/svox.cpp:55,128   (rt_kernel.cu:1362-1379)
+ *   svoxt_volume_render_bwd   <- volume_render_backward   svox_t/csrc/svox.cpp:57,130   (rt_kernel.cu:1402-1426)
+ *   svoxt_opacity_render_fwd  <- opacity_render           svox_t/csrc/svox.cpp:68,138   (rt_kernel.cu:1574-1591)
+ *   svoxt_opacity_render_bwd  <- opacity_render_backward  svox_t/csrc/svox.cpp:69,139   (rt_kernel.cu:1593-1616)
+ *   svoxt_render_depth        <- render_depth             svox_t/csrc/svox.cpp:63,134   (rt_kernel.cu:1506-1523)
+ *   svoxt_query_fwd           <- query_vertical           svox_t/csrc/svox.cpp:45,119   (svox_kernel.cu:274-324)
+ *   svoxt_query_bwd           <- query_vertical_backward  svox_t/csrc/svox.cpp:46,120   (svox_kernel.cu:380-402)
+ *   svoxt_tree / svoxt_rays / svoxt_options
+ *                             <- TreeSpec / RaysSpec / RenderOptions
+ *                                                         svox_t/csrc/include/data_spec.hpp:52-145
+ *
+ * Conventions
+ *   - Every pointer marked "device" is HBM memory of the current HIP device;
+ *     the caller owns all buffers (inputs are borrowed, outputs are written in
+ *     place, nothing is allocated or freed by the library).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *     calls are asynchronous with respect to the host: they enqueue work and
+ *     return; no call synchronises.
+ *   - Return value 0 = success; otherwise one of SVOXT_ERR_* and
+ *     svoxt_last_error() describes the failure (thread-local string).
+ *     Unlike the reference (which only printf's launch errors,
+ *     svox_t/csrc/include/common.cuh:108-111) launch failures are returned.
+ *   - fp32 only (the reference dispatches fp64 nominally, but every Python
+ *     path builds fp32 tensors).
+ */
+#ifndef SVOXT_H_
+#define SVOXT_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVOXT_ABI_VERSION 1
+
+enum {
+    SVOXT_OK = 0,
+    SVOXT_ERR_INVALID = 1,      /* null pointer, bad extent, inconsistent options */
+    SVOXT_ERR_UNSUPPORTED = 2,  /* valid for the reference, not implemented here  */
+    SVOXT_ERR_HIP = 3           /* HIP runtime / launch failure                   */
+};
+
+/* enum DataFormat, svox_t/csrc/include/data_spec.hpp:45-50 */
+enum {
+    SVOXT_FORMAT_RGBA = 0,
+    SVOXT_FORMAT_SH = 1,
+    SVOXT_FORMAT_SG = 2,
+    SVOXT_FORMAT_ASG = 3
+};
+
+/* TreeSpec (data_spec.hpp:67-111) as the kernels need it.  `data` is NOT the
+ * feature storage: it holds, per leaf slot, the row index into `features`; a
+ * slot is empty iff its index >= M (rt_kernel.cu:269). */
+typedef struct svoxt_tree {
+    const float*   features;     /* device [M, K] row-major; row = colour/SH coeffs..., sigma last */
+    int64_t        M;
+    int32_t        K;            /* data_dim */
+    int32_t        N;            /* branching factor per axis (2 = octree) */
+    const int32_t* data;         /* device [capacity, N, N, N, 1] feature-row index per slot */
+    const int32_t* child;        /* device [capacity, N, N, N] relative child offset, 0 = leaf */
+    int64_t        n_internal;   /* rows of child/data in use (TreeSpec.n_internal) */
+    const float*   offset;       /* device [3]  world -> tree: p' = offset + scaling * p */
+    const float*   scaling;      /* device [3] */
+    const float*   extra_data;   /* device [extra_rows, extra_cols] SG/ASG lobes, or NULL */
+    int32_t        extra_rows;
+    int32_t        extra_cols;
+    float*         weight_accum; /* device [capacity * N^3] or NULL (TreeSpec._weight_accum) */
+    const float*   xform;        /* TreeSpec.transformation_matrices [M,3,3]; must be NULL (unsupported) */
+} svoxt_tree;
+
+/* RaysSpec (data_spec.hpp:52-65) */
+typedef struct svoxt_rays {
+    const float* origins;        /* device [Q, 3] */
+    const float* dirs;           /* device [Q, 3] */
+    const float* vdirs;          /* device [Q, 3] */
+    int64_t      Q;
+} svoxt_rays;
+
+/* RenderOptions (data_spec.hpp:129-145), same fields in the same order. */
+typedef struct svoxt_options {
+    float   step_size;
+    float   background_brightness;
+    int32_t format;
+    int32_t basis_dim;
+    int32_t ndc_width;
+    int32_t ndc_height;
+    float   ndc_focal;
+    int32_t min_comp;
+    int32_t max_comp;
+    float   sigma_thresh;
+    float   stop_thresh;
+} svoxt_options;
+
+int         svoxt_abi_version(void);
+const char* svoxt_last_error(void);
+
+/* get_out_data_dim (rt_kernel.cu:1352-1358): number of output columns C+1 of
+ * volume_render for a feature width K. Returns -1 for invalid options. */
+int svoxt_out_data_dim(const svoxt_options* opt, int32_t K);
+
+/* out: device [Q, C+1], fully written (no pre-zeroing needed). */
+int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
+                            const svoxt_options* opt, float* out, void* stream);
+
+/* grad_out: device [Q, grad_cols] with grad_cols = C+1.
+ * fwd_out : device [Q, C+1] = the matching forward output, or NULL.  When given
+ *           (and sigma_thresh == stop_thresh == 0) the backward needs one march
+ *           instead of the reference's two.
+ * grad_features: device [M, K]; zeroed by this call on `stream`, then
+ *           accumulated with float atomics (as the reference: zeros_like +
+ *           atomicAdd, rt_kernel.cu:1415,413,486). */
+int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
+                            const svoxt_options* opt, const float* grad_out,
+                            int32_t grad_cols, const float* fwd_out,
+                            float* grad_features, void* stream);
+
+/* out: device [Q, 1] = accumulated opacity (alpha). */
+int svoxt_opacity_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
+                             const svoxt_options* opt, float* out, void* stream);
+
+/* grad_out: device [Q, 1].  Same kernel family as volume_render_bwd with zero
+ * colour channels (the reference launches render_ray_backward_kernel,
+ * rt_kernel.cu:1607): only the sigma column of grad_features is non-zero. */
+int svoxt_opacity_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
+                             const svoxt_options* opt, const float* grad_out,
+                             float* grad_features, void* stream);
+
+/* depth: device [Q, 1] = delta_scale * t of the first sample with
+ * sigma > sigma_thresh, 0 if none. */
+int svoxt_render_depth(const svoxt_tree* tree, const svoxt_rays* rays,
+                       const svoxt_options* opt, float* depth, void* stream);
+
+/* Nearest-leaf point query.
+ * points  : device [Q, 3] (world coordinates; pass offset=0, scaling=1 for local)
+ * values  : device [Q, K]   feature row of the leaf; zeros for an empty leaf
+ *           (the reference leaves such rows uninitialised, svox_kernel.cu:282)
+ * node_ids: device [Q] int64 packed leaf id node*N^3 + u*N^2 + v*N + w
+ * data_ids: device [Q] int64 feature row index, -1 for an empty leaf
+ * hit_mask: device [n_internal * N^3] uint8 or NULL; set to 1 for every leaf
+ *           slot hit (caller pre-zeroes).  The unique-leaf list the reference
+ *           returns as leaf_node is the sorted set of non-zero entries. */
+int svoxt_query_fwd(const svoxt_tree* tree, const float* points, int64_t Q,
+                    float* values, int64_t* node_ids, int64_t* data_ids,
+                    uint8_t* hit_mask, void* stream);
+
+/* grad_out: device [Q, K]; grad_features: device [M, K], zeroed by this call. */
+int svoxt_query_bwd(const svoxt_tree* tree, const float* points, int64_t Q,
+                    const float* grad_out, float* grad_features, void* stream);
+
+/* Roofline counters: marches every ray exactly as
+ * volume_render_fwd does and adds to counters[5] (device int64, caller
+ * pre-zeroes): rays that enter the cube, leaf crossings S, child words read
+ * sum(L), crossings with a valid feature index, composited samples. */
+int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
+                    const svoxt_options* opt, int64_t* counters, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVOXT_H_ */

@@ -1,0 +1,244 @@
+"""ctypes front end of the CPU oracle (oracle/svoxt_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+the cpu_baseline leg of bench.py -- never by svox_t_amd/.  All arrays are
+numpy, C-contiguous; nothing here touches a GPU or /root/reference.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import NamedTuple, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsvoxt_oracle.so")
+
+FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
+
+
+class RenderOptions(ctypes.Structure):
+    """svox_t/csrc/include/data_spec.hpp:129-145, same field order."""
+    _fields_ = [
+        ("step_size", ctypes.c_float),
+        ("background_brightness", ctypes.c_float),
+        ("format", ctypes.c_int),
+        ("basis_dim", ctypes.c_int),
+        ("ndc_width", ctypes.c_int),
+        ("ndc_height", ctypes.c_int),
+        ("ndc_focal", ctypes.c_float),
+        ("min_comp", ctypes.c_int),
+        ("max_comp", ctypes.c_int),
+        ("sigma_thresh", ctypes.c_float),
+        ("stop_thresh", ctypes.c_float),
+    ]
+
+
+def make_options(step_size=1e-3, background_brightness=1.0, format=FORMAT_RGBA,
+                 basis_dim=-1, min_comp=0, max_comp=None, sigma_thresh=0.0,
+                 stop_thresh=0.0) -> RenderOptions:
+    if max_comp is None:
+        max_comp = basis_dim - 1
+    return RenderOptions(step_size, background_brightness, format, basis_dim,
+                         -1, -1, 0.0, min_comp, max_comp, sigma_thresh, stop_thresh)
+
+
+class Counters(NamedTuple):
+    rays_hit: int
+    steps: int
+    levels: int
+    valid: int
+    active: int
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with oracle/Makefile (g++)."""
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "svoxt_oracle.cpp")):
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        assert _lib.svoxt_oracle_sizeof_options() == ctypes.sizeof(RenderOptions)
+    return _lib
+
+
+def num_threads() -> int:
+    return lib().svoxt_oracle_num_threads()
+
+
+def set_num_threads(n: int) -> None:
+    lib().svoxt_oracle_set_num_threads(int(n))
+
+
+def use_libm_exp(on: bool) -> None:
+    """Switch the oracle's expf between the portable fixed-sequence one (default;
+    bit-identical to the HIP kernels' pexpf) and glibc's expf."""
+    lib().svoxt_oracle_use_libm_exp(int(bool(on)))
+
+
+def expf(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    lib().svoxt_oracle_expf(x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(x.size),
+                            y.ctypes.data_as(ctypes.c_void_p))
+    return y
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(np.asarray(a), dtype=dtype)
+
+
+class Tree:
+    """Host copy of the tree tensors the kernels read."""
+
+    def __init__(self, features, data, child, offset=(0, 0, 0), scaling=(1, 1, 1),
+                 extra=None, dtype=np.float32):
+        self.dtype = dtype
+        self.features = _c(features, dtype)
+        self.data = _c(data, np.int32)
+        self.child = _c(child, np.int32)
+        assert self.child.ndim == 4 and self.data.size == self.child.size
+        self.N = int(self.child.shape[1])
+        self.M, self.K = (int(v) for v in self.features.shape)
+        self.offset = _c(offset, dtype)
+        self.scaling = _c(scaling, dtype)
+        self.extra = None if extra is None else _c(extra, dtype)
+
+    def astype(self, dtype):
+        return Tree(self.features, self.data, self.child, self.offset, self.scaling,
+                    self.extra, dtype=dtype)
+
+    def _args(self, with_extra=True):
+        a = [_p(self.features), ctypes.c_int64(self.M), ctypes.c_int(self.K),
+             _p(self.data), _p(self.child), ctypes.c_int(self.N),
+             _p(self.offset), _p(self.scaling)]
+        if with_extra:
+            if self.extra is None:
+                a += [None, ctypes.c_int(0), ctypes.c_int(0)]
+            else:
+                a += [_p(self.extra), ctypes.c_int(self.extra.shape[0]),
+                      ctypes.c_int(self.extra.shape[1])]
+        return a
+
+
+def out_data_dim(opt: RenderOptions, K: int) -> int:
+    """get_out_data_dim (rt_kernel.cu:1352-1358) = C + 1."""
+    if opt.format != FORMAT_RGBA:
+        return (K - 1) // opt.basis_dim + 1
+    return K
+
+
+def _rays(tree: Tree, origins, dirs, vdirs):
+    o, d, v = (_c(x, tree.dtype) for x in (origins, dirs, vdirs))
+    assert o.shape == d.shape == v.shape and o.shape[1] == 3
+    return o, d, v
+
+
+def volume_render(tree: Tree, origins, dirs, vdirs, opt: RenderOptions, count=False):
+    o, d, v = _rays(tree, origins, dirs, vdirs)
+    Q = o.shape[0]
+    out = np.zeros((Q, out_data_dim(opt, tree.K)), dtype=tree.dtype)
+    cnt = np.zeros(5, dtype=np.int64)
+    fn = lib().svoxt_oracle_volume_render_f32 if tree.dtype == np.float32 \
+        else lib().svoxt_oracle_volume_render_f64
+    fn(*tree._args(), _p(o), _p(d), _p(v), ctypes.c_int64(Q), ctypes.byref(opt),
+       _p(out), _p(cnt) if count else None)
+    return (out, Counters(*cnt.tolist())) if count else out
+
+
+def volume_render_backward(tree: Tree, origins, dirs, vdirs, opt: RenderOptions,
+                           grad_output, want_abs=False):
+    """Returns grad [M, K] float64 (and sum |contribution| if want_abs)."""
+    o, d, v = _rays(tree, origins, dirs, vdirs)
+    g = _c(grad_output, tree.dtype)
+    Q = o.shape[0]
+    assert g.shape[0] == Q
+    grad = np.zeros((tree.M, tree.K), dtype=np.float64)
+    absum = np.zeros((tree.M, tree.K), dtype=np.float64) if want_abs else None
+    fn = lib().svoxt_oracle_volume_render_backward_f32 if tree.dtype == np.float32 \
+        else lib().svoxt_oracle_volume_render_backward_f64
+    fn(*tree._args(), _p(o), _p(d), _p(v), ctypes.c_int64(Q), ctypes.byref(opt),
+       _p(g), ctypes.c_int(g.shape[1]), _p(grad), _p(absum))
+    return (grad, absum) if want_abs else grad
+
+
+def opacity_render(tree: Tree, origins, dirs, vdirs, opt: RenderOptions):
+    o, d, v = _rays(tree, origins, dirs, vdirs)
+    Q = o.shape[0]
+    out = np.zeros((Q, 1), dtype=np.float32)
+    lib().svoxt_oracle_opacity_render_f32(*tree._args(False), _p(o), _p(d), _p(v),
+                                          ctypes.c_int64(Q), ctypes.byref(opt), _p(out))
+    return out
+
+
+def render_depth(tree: Tree, origins, dirs, vdirs, opt: RenderOptions, count=False):
+    o, d, v = _rays(tree, origins, dirs, vdirs)
+    Q = o.shape[0]
+    out = np.zeros((Q, 1), dtype=np.float32)
+    cnt = np.zeros(5, dtype=np.int64)
+    lib().svoxt_oracle_render_depth_f32(*tree._args(False), _p(o), _p(d), _p(v),
+                                        ctypes.c_int64(Q), ctypes.byref(opt), _p(out),
+                                        _p(cnt) if count else None)
+    return (out, Counters(*cnt.tolist())) if count else out
+
+
+def query(tree: Tree, points):
+    p = _c(points, np.float32)
+    Q = p.shape[0]
+    values = np.zeros((Q, tree.K), dtype=np.float32)
+    node_ids = np.zeros(Q, dtype=np.int64)
+    data_ids = np.zeros(Q, dtype=np.int64)
+    lib().svoxt_oracle_query_f32(*tree._args(False), _p(p), ctypes.c_int64(Q),
+                                 _p(values), _p(node_ids), _p(data_ids))
+    return values, node_ids, data_ids
+
+
+def query_backward(tree: Tree, points, grad_output):
+    p = _c(points, np.float32)
+    g = _c(grad_output, np.float32)
+    grad = np.zeros((tree.M, tree.K), dtype=np.float64)
+    lib().svoxt_oracle_query_backward_f32(ctypes.c_int64(tree.M), ctypes.c_int(tree.K),
+                                          _p(tree.data), _p(tree.child), ctypes.c_int(tree.N),
+                                          _p(tree.offset), _p(tree.scaling), _p(p),
+                                          ctypes.c_int64(p.shape[0]), _p(g), _p(grad))
+    return grad
+
+
+def basis(format: int, basis_dim: int, dirs, extra=None):
+    d = _c(dirs, np.float32)
+    out = np.zeros((d.shape[0], basis_dim), dtype=np.float32)
+    e = None if extra is None else _c(extra, np.float32)
+    lib().svoxt_oracle_basis_f32(ctypes.c_int(format), ctypes.c_int(basis_dim), _p(e),
+                                 ctypes.c_int(0 if e is None else e.shape[0]),
+                                 ctypes.c_int(0 if e is None else e.shape[1]),
+                                 _p(d), ctypes.c_int64(d.shape[0]), _p(out))
+    return out
+
+
+def algorithmic_bytes_forward(cnt: Counters, Q: int, K: int, C: int) -> int:
+    """B_f = sum_r [36 + 4(C+1)] + sum_steps (4L + 4 + 4v + 4(K-1)a)."""
+    return Q * (36 + 4 * (C + 1)) + 4 * cnt.levels + 4 * cnt.steps + 4 * cnt.valid \
+        + 4 * (K - 1) * cnt.active
+
+
+def algorithmic_bytes_backward(cnt: Counters, Q: int, M: int, K: int, C: int) -> int:
+    """B_b (two re-marches, K-1 colour atomics + 1 sigma atomic
+    per active sample, an atomic counted as 4 B read + 4 B write, zero-init)."""
+    per_march = 4 * cnt.levels + 4 * cnt.steps + 4 * cnt.valid + 4 * (K - 1) * cnt.active
+    return 4 * M * K + Q * (36 + 4 * (C + 1)) + 2 * per_march + cnt.active * (8 * (K - 1) + 8)

@@ -1,0 +1,55 @@
+"""Build libsvoxt_hip.so (the HIP kernels + C ABI) in-tree with hipcc.
+
+Cross-compiles for gfx950 without a GPU.  Usage: ``python -m svox_t_amd.build``
+or ``svox_t_amd.build.build()``.  The library lands next to its sources in
+``svox_t_amd/csrc/`` (git-ignored, but shipped to the GPU box by gpurun).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_NAME = "libsvoxt_hip.so"
+LIB_PATH = os.path.join(CSRC, LIB_NAME)
+SOURCES = ["svoxt_kernels.hip"]
+HEADERS = ["svoxt_device.h", os.path.join("..", "..", "include", "svoxt.h")]
+
+# -ffp-contract=off is part of the numerical contract (svoxt_device.h): the
+# stepping arithmetic must not be fused into FMAs.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; cannot build " + LIB_NAME)
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH + ".tmp"] + \
+        [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

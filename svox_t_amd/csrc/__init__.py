@@ -1,0 +1,437 @@
+"""`svox_t_amd.csrc` -- the operator boundary, shaped like the reference's
+pybind11 module `svox_t.csrc` (svox_t/csrc/svox.cpp:73-145) so that the
+`autograd.Function`s and `N3Tree._spec` that sit on top of it read the same.
+
+Same class names (`RaysSpec`, `TreeSpec`, `CameraSpec`, `RenderOptions`), same
+attribute names, same function names and argument order for the hot path:
+
+    volume_render(tree, rays, opt)                    -> Tensor [Q, C+1]
+    volume_render_backward(tree, rays, opt, grad)     -> Tensor [M, K]
+    render_depth(tree, rays, opt)                     -> Tensor [Q, 1]
+    opacity_render(tree, rays, opt)                   -> Tensor [Q, 1]
+    opacity_render_backward(tree, rays, opt, grad)    -> Tensor [M, K]
+    query_vertical(tree, indices)                     -> (values, node_ids, data_ids, leaf_node)
+    query_vertical_backward(tree, indices, grad)      -> Tensor [M, K]
+
+Underneath there is no pybind: tensors are marshalled to raw device pointers
+and handed to the C ABI of libsvoxt_hip.so (include/svoxt.h) through ctypes,
+on torch's *current* stream (the reference launches on the legacy default
+stream, rt_kernel.cu:1373).  Outputs are allocated by torch's caching
+allocator.  Precondition failures raise RuntimeError like the reference's
+TORCH_CHECKs (data_spec.hpp:38-43); unlike the reference, launch errors are
+raised too.
+
+There is NO CPU fallback here: if the shared library is missing the import
+fails, and non-GPU tensors are rejected.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvoxt_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: the HIP extension is not built. "
+        "Run `python -m svox_t_amd.build` (needs hipcc; cross-compiles for gfx950).")
+
+_lib = ctypes.CDLL(LIB_PATH)
+
+ABI_VERSION = 1
+FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
+
+
+class _CTree(ctypes.Structure):          # struct svoxt_tree
+    _fields_ = [
+        ("features", ctypes.c_void_p), ("M", ctypes.c_int64),
+        ("K", ctypes.c_int32), ("N", ctypes.c_int32),
+        ("data", ctypes.c_void_p), ("child", ctypes.c_void_p),
+        ("n_internal", ctypes.c_int64),
+        ("offset", ctypes.c_void_p), ("scaling", ctypes.c_void_p),
+        ("extra_data", ctypes.c_void_p),
+        ("extra_rows", ctypes.c_int32), ("extra_cols", ctypes.c_int32),
+        ("weight_accum", ctypes.c_void_p), ("xform", ctypes.c_void_p),
+    ]
+
+
+class _CRays(ctypes.Structure):          # struct svoxt_rays
+    _fields_ = [("origins", ctypes.c_void_p), ("dirs", ctypes.c_void_p),
+                ("vdirs", ctypes.c_void_p), ("Q", ctypes.c_int64)]
+
+
+class _COptions(ctypes.Structure):       # struct svoxt_options
+    _fields_ = [
+        ("step_size", ctypes.c_float), ("background_brightness", ctypes.c_float),
+        ("format", ctypes.c_int32), ("basis_dim", ctypes.c_int32),
+        ("ndc_width", ctypes.c_int32), ("ndc_height", ctypes.c_int32),
+        ("ndc_focal", ctypes.c_float),
+        ("min_comp", ctypes.c_int32), ("max_comp", ctypes.c_int32),
+        ("sigma_thresh", ctypes.c_float), ("stop_thresh", ctypes.c_float),
+    ]
+
+
+_P = ctypes.POINTER
+_vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+
+# Every symbol include/svoxt.h declares, with its signature.
+EXPORTS = {
+    "svoxt_abi_version": (ctypes.c_int, []),
+    "svoxt_last_error": (ctypes.c_char_p, []),
+    "svoxt_out_data_dim": (ctypes.c_int, [_P(_COptions), _i32]),
+    "svoxt_volume_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
+    "svoxt_volume_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _vp, _vp]),
+    "svoxt_opacity_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
+    "svoxt_opacity_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp]),
+    "svoxt_render_depth": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
+    "svoxt_query_fwd": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "svoxt_query_bwd": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp, _vp, _vp]),
+    "svoxt_count_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
+}
+for _name, (_res, _args) in EXPORTS.items():
+    _fn = getattr(_lib, _name)       # AttributeError here = library/header mismatch
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if _lib.svoxt_abi_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH}: ABI version {_lib.svoxt_abi_version()} != {ABI_VERSION}; rebuild")
+
+
+# ---------------------------------------------------------------------------
+# Spec classes (svox.cpp:74-117): default-constructed, read/write attributes.
+# ---------------------------------------------------------------------------
+
+class RaysSpec:
+    def __init__(self):
+        self.origins = None
+        self.dirs = None
+        self.vdirs = None
+
+
+class TreeSpec:
+    def __init__(self):
+        self.features = None
+        self.data = None
+        self.child = None
+        self.parent_depth = None
+        self.extra_data = None
+        self.offset = None
+        self.scaling = None
+        self._weight_accum = None
+        self.joint_features = None
+        self.skinning_weights = None
+        self.joint_index = None
+        self.n_internal = 0
+        self.transformation_matrices = None
+
+
+class CameraSpec:
+    def __init__(self):
+        self.c2w = None
+        self.fx = 0.0
+        self.fy = 0.0
+        self.width = 0
+        self.height = 0
+
+
+class RenderOptions:
+    def __init__(self):
+        self.step_size = 0.0
+        self.background_brightness = 0.0
+        self.format = 0
+        self.basis_dim = 0
+        self.ndc_width = 0
+        self.ndc_height = 0
+        self.ndc_focal = 0.0
+        self.min_comp = 0
+        self.max_comp = 0
+        self.sigma_thresh = 0.0
+        self.stop_thresh = 0.0
+
+
+# ---------------------------------------------------------------------------
+# Marshalling
+# ---------------------------------------------------------------------------
+
+def _check_input(x, name):
+    """CHECK_INPUT (data_spec.hpp:38-43)."""
+    if not isinstance(x, torch.Tensor):
+        raise RuntimeError(f"{name} must be a tensor")
+    if not x.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _numel(x):
+    return 0 if x is None else x.numel()
+
+
+def _ptr(x):
+    return None if (x is None or x.numel() == 0) else x.data_ptr()
+
+
+def _pack_tree(tree: TreeSpec) -> _CTree:
+    """TreeSpec.check() (data_spec.hpp:85-110) + pointer extraction."""
+    _check_input(tree.features, "features")
+    _check_input(tree.data, "data")
+    _check_input(tree.child, "child")
+    if tree.parent_depth is not None:
+        _check_input(tree.parent_depth, "parent_depth")
+    _check_input(tree.offset, "offset")
+    _check_input(tree.scaling, "scaling")
+    for nm in ("extra_data", "_weight_accum", "joint_features", "skinning_weights",
+               "joint_index", "transformation_matrices"):
+        t = getattr(tree, nm)
+        if _numel(t):
+            _check_input(t, nm)
+    if tree.features.dtype != torch.float32 or tree.features.dim() != 2:
+        raise RuntimeError("features must be a float32 [M, K] tensor")
+    if tree.child.dtype != torch.int32 or tree.child.dim() != 4:
+        raise RuntimeError("child must be an int32 [n, N, N, N] tensor")
+    if tree.data.dtype != torch.int32 or tree.data.numel() != tree.child.numel():
+        raise RuntimeError("data must be an int32 [n, N, N, N, 1] tensor matching child")
+    if tree.offset.dtype != torch.float32 or tree.scaling.dtype != torch.float32 \
+            or tree.offset.numel() != 3 or tree.scaling.numel() != 3:
+        raise RuntimeError("offset / scaling must be float32 tensors of 3 elements")
+    dev = tree.features.device
+    for nm in ("data", "child", "offset", "scaling"):
+        if getattr(tree, nm).device != dev:
+            raise RuntimeError(f"{nm} must be on the same device as features")
+    n_internal = int(tree.n_internal) if tree.n_internal else tree.child.shape[0]
+    if n_internal > tree.child.shape[0]:
+        raise RuntimeError("n_internal exceeds the capacity of child")
+    c = _CTree()
+    c.features = _ptr(tree.features)
+    c.M, c.K = tree.features.shape
+    c.N = tree.child.shape[1]
+    c.data = tree.data.data_ptr()
+    c.child = tree.child.data_ptr()
+    c.n_internal = n_internal
+    c.offset = tree.offset.data_ptr()
+    c.scaling = tree.scaling.data_ptr()
+    if _numel(tree.extra_data):
+        if tree.extra_data.dtype != torch.float32 or tree.extra_data.dim() != 2:
+            raise RuntimeError("extra_data must be a float32 2-D tensor")
+        c.extra_data = tree.extra_data.data_ptr()
+        c.extra_rows, c.extra_cols = tree.extra_data.shape
+    if _numel(tree._weight_accum):
+        if tree._weight_accum.dtype != torch.float32 or \
+                tree._weight_accum.numel() != tree.child.numel():
+            raise RuntimeError("_weight_accum must be float32 with one entry per leaf slot")
+        c.weight_accum = tree._weight_accum.data_ptr()
+    if _numel(tree.transformation_matrices):
+        c.xform = tree.transformation_matrices.data_ptr()   # rejected by the library (unsupported)
+    return c
+
+
+def _pack_rays(rays: RaysSpec) -> _CRays:
+    """RaysSpec.check() (data_spec.hpp:57-64)."""
+    for nm in ("origins", "dirs", "vdirs"):
+        t = getattr(rays, nm)
+        _check_input(t, nm)
+        if not t.is_floating_point():
+            raise RuntimeError(f"{nm} must be floating point")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"{nm} must be float32 (the HIP path is fp32 only)")
+        if t.dim() != 2 or t.shape[1] != 3:
+            raise RuntimeError(f"{nm} must have shape [Q, 3]")
+    Q = rays.origins.shape[0]
+    if rays.dirs.shape[0] != Q or rays.vdirs.shape[0] != Q:
+        raise RuntimeError("origins, dirs and vdirs must have the same number of rays")
+    c = _CRays()
+    c.origins, c.dirs, c.vdirs = _ptr(rays.origins), _ptr(rays.dirs), _ptr(rays.vdirs)
+    c.Q = Q
+    return c
+
+
+def _pack_opts(opt: RenderOptions) -> _COptions:
+    return _COptions(float(opt.step_size), float(opt.background_brightness),
+                     int(opt.format), int(opt.basis_dim),
+                     int(opt.ndc_width), int(opt.ndc_height), float(opt.ndc_focal),
+                     int(opt.min_comp), int(opt.max_comp),
+                     float(opt.sigma_thresh), float(opt.stop_thresh))
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _call(name, *args):
+    rc = getattr(_lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {_lib.svoxt_last_error().decode()}")
+
+
+def get_out_data_dim(opt: RenderOptions, K: int) -> int:
+    """get_out_data_dim (rt_kernel.cu:1352-1358)."""
+    n = _lib.svoxt_out_data_dim(ctypes.byref(_pack_opts(opt)), K)
+    if n < 0:
+        raise RuntimeError("invalid RenderOptions for get_out_data_dim")
+    return n
+
+
+# ---------------------------------------------------------------------------
+# Hot-path operators
+# ---------------------------------------------------------------------------
+
+def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
+    """rt_kernel.cu:1362-1379."""
+    ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
+    dev = tree.features.device
+    with torch.cuda.device(dev):
+        out = torch.empty((cr.Q, get_out_data_dim(opt, ct.K)), dtype=torch.float32, device=dev)
+        _call("svoxt_volume_render_fwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+              _ptr(out), _stream(dev))
+    return out
+
+
+def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
+                           grad_output: torch.Tensor, fwd_output: torch.Tensor = None) -> torch.Tensor:
+    """rt_kernel.cu:1402-1426.  `fwd_output` (optional, not in the reference
+    signature) lets the library skip one of the two backward marches."""
+    ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
+    _check_input(grad_output, "grad_output")
+    if grad_output.dtype != torch.float32 or grad_output.dim() != 2 or grad_output.shape[0] != cr.Q:
+        raise RuntimeError("grad_output must be float32 [Q, C+1]")
+    if fwd_output is not None:
+        _check_input(fwd_output, "fwd_output")
+        if fwd_output.shape != grad_output.shape or fwd_output.dtype != torch.float32:
+            raise RuntimeError("fwd_output must match grad_output")
+    dev = tree.features.device
+    with torch.cuda.device(dev):
+        grad = torch.empty_like(tree.features)
+        _call("svoxt_volume_render_bwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+              _ptr(grad_output), grad_output.shape[1], _ptr(fwd_output), _ptr(grad), _stream(dev))
+    return grad
+
+
+def render_depth(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
+    """rt_kernel.cu:1506-1523."""
+    ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
+    dev = tree.features.device
+    with torch.cuda.device(dev):
+        depth = torch.empty((cr.Q, 1), dtype=torch.float32, device=dev)
+        _call("svoxt_render_depth", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+              _ptr(depth), _stream(dev))
+    return depth
+
+
+def opacity_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
+    """rt_kernel.cu:1574-1591."""
+    ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
+    dev = tree.features.device
+    with torch.cuda.device(dev):
+        out = torch.empty((cr.Q, 1), dtype=torch.float32, device=dev)
+        _call("svoxt_opacity_render_fwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+              _ptr(out), _stream(dev))
+    return out
+
+
+def opacity_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
+                            grad_output: torch.Tensor) -> torch.Tensor:
+    """rt_kernel.cu:1593-1616."""
+    ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
+    _check_input(grad_output, "grad_output")
+    if grad_output.dtype != torch.float32 or grad_output.numel() != cr.Q:
+        raise RuntimeError("grad_output must be float32 [Q, 1]")
+    dev = tree.features.device
+    with torch.cuda.device(dev):
+        grad = torch.empty_like(tree.features)
+        _call("svoxt_opacity_render_bwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+              _ptr(grad_output), _ptr(grad), _stream(dev))
+    return grad
+
+
+def _check_indices(indices):
+    """check_indices (svox_kernel.cu:36-40)."""
+    _check_input(indices, "indices")
+    if indices.dim() != 2:
+        raise RuntimeError("indices must be 2-D")
+    if not indices.is_floating_point():
+        raise RuntimeError("indices must be floating point")
+    if indices.dtype != torch.float32 or indices.shape[1] != 3:
+        raise RuntimeError("indices must be float32 [Q, 3]")
+
+
+def query_vertical(tree: TreeSpec, indices: torch.Tensor):
+    """svox_kernel.cu:274-324.  Returns (values [Q,K], node_ids [Q] int64,
+    data_ids [Q] int64, leaf_node [U,4] int64).
+
+    Differences from the reference, all where its result is undefined:
+    rows of `values` for empty leaves are zeros (reference: uninitialised,
+    :282), `data_ids` is -1 there, and `leaf_node` is sorted by packed leaf id
+    (reference: order set by a float atomic counter, :260-269)."""
+    ct = _pack_tree(tree)
+    _check_indices(indices)
+    dev = indices.device
+    Q = indices.shape[0]
+    N = ct.N
+    with torch.cuda.device(dev):
+        values = torch.empty((Q, ct.K), dtype=torch.float32, device=dev)
+        node_ids = torch.empty((Q,), dtype=torch.int64, device=dev)
+        data_ids = torch.empty((Q,), dtype=torch.int64, device=dev)
+        mask = torch.zeros((ct.n_internal * N * N * N,), dtype=torch.uint8, device=dev)
+        _call("svoxt_query_fwd", ctypes.byref(ct), _ptr(indices), Q, _ptr(values), _ptr(node_ids),
+              _ptr(data_ids), _ptr(mask), _stream(dev))
+        packed = torch.nonzero(mask).squeeze(1)          # host sync, like the reference's .item() (:312)
+        w = packed % N
+        v = (packed // N) % N
+        u = (packed // (N * N)) % N
+        node = packed // (N * N * N)
+        leaf_node = torch.stack((node, u, v, w), dim=-1)
+    return values, node_ids, data_ids, leaf_node
+
+
+def query_vertical_backward(tree: TreeSpec, indices: torch.Tensor,
+                            grad_output: torch.Tensor) -> torch.Tensor:
+    """svox_kernel.cu:380-402."""
+    ct = _pack_tree(tree)
+    _check_indices(indices)
+    _check_input(grad_output, "grad_output")
+    if grad_output.dtype != torch.float32 or tuple(grad_output.shape) != (indices.shape[0], ct.K):
+        raise RuntimeError("grad_output must be float32 [Q, K]")
+    dev = indices.device
+    with torch.cuda.device(dev):
+        grad = torch.empty((ct.M, ct.K), dtype=torch.float32, device=dev)
+        _call("svoxt_query_bwd", ctypes.byref(ct), _ptr(indices), indices.shape[0],
+              _ptr(grad_output), _ptr(grad), _stream(dev))
+    return grad
+
+
+def count_forward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
+    """Roofline counters (not in the reference): int64 [5] on the device =
+    (rays hitting the cube, leaf crossings, child words read, valid leaves,
+    composited samples).  See SURVEY.md 8(d)."""
+    ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
+    dev = tree.features.device
+    with torch.cuda.device(dev):
+        counters = torch.zeros((5,), dtype=torch.int64, device=dev)
+        _call("svoxt_count_fwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+              _ptr(counters), _stream(dev))
+    return counters
+
+
+# ---------------------------------------------------------------------------
+# Entry points of svox_t.csrc that are outside this project's hot path
+# (SURVEY.md section 2).  They exist so a caller gets a clear error, not an
+# AttributeError.
+# ---------------------------------------------------------------------------
+
+def _out_of_scope(name):
+    def fn(*_a, **_k):
+        raise NotImplementedError(
+            f"svox_t_amd.csrc.{name}: outside the accelerated hot path "
+            "(volume_render / opacity / depth / query); see SURVEY.md section 2")
+    fn.__name__ = name
+    return fn
+
+
+for _n in ("assign_vertical", "construct_tree", "warp_vertices", "warp_vertices_backward",
+           "p2v", "p2v_backward", "volume_render_image", "volume_render_image_backward",
+           "motion_render", "motion_feature_render", "motion_feature_render_backward",
+           "calc_corners", "grid_weight_render", "quantize_median_cut"):
+    globals()[_n] = _out_of_scope(_n)

@@ -1,0 +1,364 @@
+// svoxt_device.h -- device-side building blocks shared by the render, depth,
+// opacity, query and counting kernels (gfx950 / CDNA4 only).
+//
+// Numerical contract.  The *stepping* arithmetic of a ray (world->tree
+// transform, direction normalisation, slab tests, leaf lookup, step length)
+// decides which leaves a ray visits, so it is kept bit-identical to the
+// source semantics of the reference (and therefore to oracle/):
+//   - the translation unit is compiled with -ffp-contract=off and carries
+//     `#pragma clang fp contract(off)`: no multiply-add is ever fused here;
+//   - sqrt and divide are the correctly rounded forms;
+//   - the reference's mixed float/double expressions are evaluated in double
+//     where the reference evaluates them in double.
+// For N == 2 the root->leaf descent is done on integer cell coordinates.  This
+// is exact: for p in [0,1) every `p*2; floor; subtract` of the reference
+// (svox_t/csrc/include/common.cuh:78-86) is an exact floating-point operation,
+// so the slot path is the bit string of floor(p * 2^k) and the leaf-local
+// coordinate is frac(p * 2^k), both computed here without rounding.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace svoxt {
+
+struct TreeDev {
+    const float* __restrict__ features;
+    int64_t M;
+    int K;
+    int N;
+    const int32_t* __restrict__ data;
+    const int32_t* __restrict__ child;
+    const float* __restrict__ offset;
+    const float* __restrict__ scaling;
+    const float* __restrict__ extra;
+    int extra_rows;
+    int extra_cols;
+    float* weight_accum;
+};
+
+struct RaysDev {
+    const float* __restrict__ origins;
+    const float* __restrict__ dirs;
+    const float* __restrict__ vdirs;
+    int64_t Q;
+};
+
+// svox_t/csrc/include/data_spec.hpp:129-145
+struct Opts {
+    float step_size;
+    float background_brightness;
+    int format;
+    int basis_dim;
+    int ndc_width;
+    int ndc_height;
+    float ndc_focal;
+    int min_comp;
+    int max_comp;
+    float sigma_thresh;
+    float stop_thresh;
+};
+
+enum { FMT_RGBA = 0, FMT_SH = 1, FMT_SG = 2, FMT_ASG = 3 };
+
+// (float)(1.0 - 1e-6): the reference clamps with `min(scalar_t(1.0) - 1e-6, q)`
+// evaluated in double and rounds the result to float
+// (svox_t/csrc/include/common.cuh:40); for a float q that equals
+// fminf(q, (float)(1.0 - 1e-6)).
+constexpr float kClampHi = (float)(1.0 - 1e-6);
+
+struct Ray {
+    float ox, oy, oz;      // origin in tree space
+    float dx, dy, dz;      // unit direction in tree space
+    float ix, iy, iz;      // 1 / (d + 1e-9)
+    float delta_scale;
+    float tmin, tmax;
+};
+
+// One slab test of a ray against the unit cube (rt_kernel.cu:202-218).
+__device__ __forceinline__ void dda_unit(float cx, float cy, float cz,
+                                         float ix, float iy, float iz,
+                                         float& tmin, float& tmax) {
+    float t1, t2;
+    tmin = 0.0f;
+    tmax = 1e9f;
+    t1 = -cx * ix; t2 = t1 + ix;
+    tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+    t1 = -cy * iy; t2 = t1 + iy;
+    tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+    t1 = -cz * iz; t2 = t1 + iz;
+    tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+}
+
+// Ray preamble: render_ray_kernel's transform (rt_kernel.cu:663-665,
+// common.cuh:45-51), _get_delta_scale (:188-199), invdir (:237, double) and
+// the cube slab test (:239-241).  Returns false when the ray misses the cube.
+__device__ __forceinline__ bool setup_ray(const TreeDev& tr, const RaysDev& rays,
+                                          int64_t q, Ray& r) {
+    const float s0 = tr.scaling[0], s1 = tr.scaling[1], s2 = tr.scaling[2];
+    const float f0 = tr.offset[0], f1 = tr.offset[1], f2 = tr.offset[2];
+    const float* o = rays.origins + 3 * q;
+    const float* d = rays.dirs + 3 * q;
+    r.ox = f0 + s0 * o[0];
+    r.oy = f1 + s1 * o[1];
+    r.oz = f2 + s2 * o[2];
+    float dx = d[0] * s0, dy = d[1] * s1, dz = d[2] * s2;
+    // sqrtf and `/` are the correctly rounded forms under hipcc's default
+    // -fhip-fp32-correctly-rounded-divide-sqrt (__fsqrt_rn is NOT: it maps to
+    // the native approximation unless OCML_BASIC_ROUNDED_OPERATIONS is set).
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float ds = 1.f / nrm;
+    dx *= ds; dy *= ds; dz *= ds;
+    r.dx = dx; r.dy = dy; r.dz = dz;
+    r.delta_scale = ds;
+    r.ix = (float)(1.0 / ((double)dx + 1e-9));
+    r.iy = (float)(1.0 / ((double)dy + 1e-9));
+    r.iz = (float)(1.0 / ((double)dz + 1e-9));
+    dda_unit(r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, r.tmin, r.tmax);
+    return !(r.tmax < 0 || r.tmin > r.tmax);
+}
+
+struct Leaf {
+    uint32_t slot;      // flat index into child / data: ((node*N+u)*N+v)*N+w
+    float lx, ly, lz;   // leaf-local coordinates in [0,1)
+    float cube_sz;      // N^levels
+    int levels;         // child words read
+};
+
+// Generic-N continuation of the descent (common.cuh:74-99), starting at
+// `node` with node-local coordinates p in [0,1).
+__device__ __forceinline__ void descend_generic(const TreeDev& tr, int32_t node,
+                                                float px, float py, float pz,
+                                                float cube_sz, int levels, Leaf& lf) {
+    const int Ni = tr.N;
+    const float N = (float)Ni;
+    while (true) {
+        px *= N; py *= N; pz *= N;
+        const float fu = floorf(px), fv = floorf(py), fw = floorf(pz);
+        px -= fu; py -= fv; pz -= fw;
+        int u = (int)fu, v = (int)fv, w = (int)fw;
+        u = min(max(u, 0), Ni - 1);
+        v = min(max(v, 0), Ni - 1);
+        w = min(max(w, 0), Ni - 1);
+        const uint32_t slot = (((uint32_t)node * Ni + u) * Ni + v) * Ni + w;
+        const int32_t skip = tr.child[slot];
+        ++levels;
+        if (skip == 0) {
+            lf.slot = slot; lf.lx = px; lf.ly = py; lf.lz = pz;
+            lf.cube_sz = cube_sz; lf.levels = levels;
+            return;
+        }
+        cube_sz *= N;
+        node += skip;
+    }
+}
+
+constexpr int kFixBits = 22;   // integer descent handles up to 22 levels
+
+// query_single_from_root (common.cuh:63-100) for a tree-space point.
+template <bool N2>
+__device__ __forceinline__ void locate(const TreeDev& tr, float px, float py, float pz, Leaf& lf) {
+    px = fmaxf(0.f, fminf(kClampHi, px));
+    py = fmaxf(0.f, fminf(kClampHi, py));
+    pz = fmaxf(0.f, fminf(kClampHi, pz));
+    if constexpr (!N2) {
+        descend_generic(tr, 0, px, py, pz, (float)tr.N, 0, lf);
+    } else {
+        const float S = (float)(1 << kFixBits);
+        const uint32_t ux = (uint32_t)(px * S);   // exact: px*2^22 then truncation
+        const uint32_t uy = (uint32_t)(py * S);
+        const uint32_t uz = (uint32_t)(pz * S);
+        int32_t node = 0;
+        int k = 1;
+        uint32_t slot;
+        int32_t skip;
+#pragma unroll 1
+        for (;; ++k) {
+            const int sh = kFixBits - k;
+            const uint32_t cell = (((ux >> sh) & 1u) << 2) | (((uy >> sh) & 1u) << 1) | ((uz >> sh) & 1u);
+            slot = ((uint32_t)node << 3) + cell;
+            skip = tr.child[slot];
+            if (skip == 0 || k == kFixBits) break;
+            node += skip;
+        }
+        const float sc = __int_as_float((127 + k) << 23);   // 2^k
+        const float fx = px * sc, fy = py * sc, fz = pz * sc;
+        const float lx = fx - floorf(fx), ly = fy - floorf(fy), lz = fz - floorf(fz);
+        if (skip == 0) {
+            lf.slot = slot; lf.lx = lx; lf.ly = ly; lf.lz = lz;
+            lf.cube_sz = sc; lf.levels = k;
+        } else {
+            // deeper than the fixed-point path resolves: finish in float
+            descend_generic(tr, node + skip, lx, ly, lz, sc * 2.f, k, lf);
+        }
+    }
+}
+
+struct Sample {
+    Leaf leaf;
+    int32_t idx;       // feature row, valid iff (int64)idx < M (negative = empty too? no: see below)
+    float delta_t;
+    bool valid;
+};
+
+// One leaf crossing: rt_kernel.cu:261-277.
+template <bool N2>
+__device__ __forceinline__ void march_step(const TreeDev& tr, const Ray& r, float step_size,
+                                           float t, Sample& s) {
+    const float px = r.ox + t * r.dx;
+    const float py = r.oy + t * r.dy;
+    const float pz = r.oz + t * r.dz;
+    locate<N2>(tr, px, py, pz, s.leaf);
+    s.idx = tr.data[s.leaf.slot];
+    // `*data_idx_ptr >= features.size(0)` compares int32 with int64 (:269); a
+    // negative index is therefore "valid" for the reference (and reads out of
+    // bounds).  Treat it as empty instead of faulting.
+    s.valid = s.idx >= 0 && (int64_t)s.idx < tr.M;
+    float sub_tmin, sub_tmax;
+    dda_unit(s.leaf.lx, s.leaf.ly, s.leaf.lz, r.ix, r.iy, r.iz, sub_tmin, sub_tmax);
+    float t_subcube;
+    if constexpr (N2) {
+        // cube_sz is a power of two: multiplying by its reciprocal is the
+        // same correctly rounded result as the reference's division (:275).
+        t_subcube = (sub_tmax - sub_tmin) * __int_as_float((254 << 23) - __float_as_int(s.leaf.cube_sz));
+    } else {
+        t_subcube = (sub_tmax - sub_tmin) / s.leaf.cube_sz;
+    }
+    s.delta_t = t_subcube + step_size;
+}
+
+// expf with a fixed operation sequence (Cephes-style: n = rint(x*log2e), two-
+// step Cody-Waite reduction, degree-5 polynomial, exact power-of-two scaling).
+// Every step is a correctly rounded IEEE operation (mul, add, fma, rint), so
+// the result is reproducible bit for bit on any IEEE machine -- oracle/ carries
+// the same sequence, which makes the whole forward pass comparable exactly
+// rather than to within "some ulps of some libm".  Accuracy ~1 ulp (the
+// reference's CUDA expf is specified to 2 ulp).  Results below 2^-126
+// (x < -87) are returned as 0, above FLT_MAX as +inf.
+__device__ __forceinline__ float pexpf(float x) {
+    if (x != x) return x;
+    if (x > 88.72283905206835f) return __int_as_float(0x7f800000);
+    if (x < -87.0f) return 0.0f;
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float y = __builtin_fmaf(p, r * r, r);
+    y = y + 1.0f;
+    const int ni = (int)n;
+    const int n1 = ni >> 1, n2 = ni - n1;
+    y = y * __int_as_float((n1 + 127) << 23);
+    return y * __int_as_float((n2 + 127) << 23);
+}
+
+// SH constants, `const float` in the reference (rt_kernel.cu:54-84).
+__device__ __constant__ const float kC0 = 0.28209479177387814;
+__device__ __constant__ const float kC1 = 0.4886025119029199;
+__device__ __constant__ const float kC2[5] = {1.0925484305920792, -1.0925484305920792,
+                                              0.31539156525252005, -1.0925484305920792,
+                                              0.5462742152960396};
+__device__ __constant__ const float kC3[7] = {-0.5900435899266435, 2.890611442640554,
+                                              -0.4570457994644658, 0.3731763325901154,
+                                              -0.4570457994644658, 1.445305721320277,
+                                              -0.5900435899266435};
+__device__ __constant__ const float kC4[9] = {2.5033429417967046,  -1.7701307697799304,
+                                              0.9461746957575601,  -0.6690465435572892,
+                                              0.10578554691520431, -0.6690465435572892,
+                                              0.47308734787878004, -1.7701307697799304,
+                                              0.6258357354491761};
+
+__device__ __forceinline__ float dot3(const float* u, const float* v) {
+    return u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
+}
+
+// maybe_precalc_basis (rt_kernel.cu:110-185).  BD is the number of basis
+// functions; `out` must hold at least BD (<= 25) floats.
+template <int BD_STATIC>
+__device__ __forceinline__ void precalc_basis(int format, int basis_dim_rt, const TreeDev& tr,
+                                              float x, float y, float z, float* out) {
+    const int bd = BD_STATIC > 0 ? BD_STATIC : basis_dim_rt;
+    if (format == FMT_SH) {
+        out[0] = kC0;
+        const float xx = x * x, yy = y * y, zz = z * z;
+        const float xy = x * y, yz = y * z, xz = x * z;
+        if (bd == 25) {
+            out[16] = kC4[0] * xy * (xx - yy);
+            out[17] = kC4[1] * yz * (3 * xx - yy);
+            out[18] = kC4[2] * xy * (7 * zz - 1.f);
+            out[19] = kC4[3] * yz * (7 * zz - 3.f);
+            out[20] = kC4[4] * (zz * (35 * zz - 30) + 3);
+            out[21] = kC4[5] * xz * (7 * zz - 3);
+            out[22] = kC4[6] * (xx - yy) * (7 * zz - 1.f);
+            out[23] = kC4[7] * xz * (xx - 3 * yy);
+            out[24] = kC4[8] * (xx * (xx - 3 * yy) - yy * (3 * xx - yy));
+        }
+        if (bd == 25 || bd == 16) {
+            out[9] = kC3[0] * y * (3 * xx - yy);
+            out[10] = kC3[1] * xy * z;
+            out[11] = kC3[2] * y * (4 * zz - xx - yy);
+            out[12] = kC3[3] * z * (2 * zz - 3 * xx - 3 * yy);
+            out[13] = kC3[4] * x * (4 * zz - xx - yy);
+            out[14] = kC3[5] * z * (xx - yy);
+            out[15] = kC3[6] * x * (xx - 3 * yy);
+        }
+        if (bd == 25 || bd == 16 || bd == 9) {
+            out[4] = kC2[0] * xy;
+            out[5] = kC2[1] * yz;
+            out[6] = (float)((double)kC2[2] * (2.0 * (double)zz - (double)xx - (double)yy));  // :169
+            out[7] = kC2[3] * xz;
+            out[8] = kC2[4] * (xx - yy);
+        }
+        if (bd == 25 || bd == 16 || bd == 9 || bd == 4) {
+            out[1] = -kC1 * y;
+            out[2] = kC1 * z;
+            out[3] = -kC1 * x;
+        }
+    } else if (format == FMT_SG) {
+        const float dir[3] = {x, y, z};
+        for (int i = 0; i < bd; ++i) {
+            const float* lobe = tr.extra + (int64_t)i * tr.extra_cols;
+            out[i] = pexpf(lobe[0] * (dot3(dir, lobe + 1) - 1.f)) / (float)bd;
+        }
+    } else if (format == FMT_ASG) {
+        const float dir[3] = {x, y, z};
+        for (int i = 0; i < bd; ++i) {
+            const float* lobe = tr.extra + (int64_t)i * tr.extra_cols;
+            const float S = dot3(dir, lobe + 8);
+            const float dot_x = dot3(dir, lobe + 2);
+            const float dot_y = dot3(dir, lobe + 5);
+            out[i] = S * pexpf(-lobe[0] * dot_x * dot_x - lobe[1] * dot_y * dot_y) / (float)bd;
+        }
+    }
+}
+
+// The reference's `w / (1.0 + expf(-x))` family is evaluated in double
+// (rt_kernel.cu:300,304,408,420,472,476).
+__device__ __forceinline__ double sigmoid_d(float x) {
+    return 1.0 / (1.0 + (double)pexpf(-x));
+}
+
+// Feature row -> registers.  16-byte loads when the row stride allows it
+// (K % 4 == 0 and torch allocations are >= 16-byte aligned).
+template <int K>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&row)[K]) {
+    if constexpr (K % 4 == 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+        for (int i = 0; i < K / 4; ++i) {
+            const float4 v = p4[i];
+            row[4 * i] = v.x; row[4 * i + 1] = v.y; row[4 * i + 2] = v.z; row[4 * i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i) row[i] = p[i];
+    }
+}
+
+}  // namespace svoxt

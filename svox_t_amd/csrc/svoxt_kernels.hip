@@ -1,0 +1,852 @@
+// svoxt_kernels.hip -- hand-written CDNA4 (gfx950) kernels for svox_t's
+// volume-render hot path and the C ABI declared in include/svoxt.h.
+//
+// Mapping: one ray per wavefront lane, 256-thread workgroups (4 waves).  The
+// per-ray output accumulators live in registers for the specialised payloads
+// (RGBA C=3 / C=31, SH with 1/4/9/16/25 basis functions x 3 channels) and in
+// global memory only for the generic fallback (any K / SG / ASG / component
+// sub-ranges), which mirrors the reference's read-modify-write of `out`
+// (svox_t/csrc/rt_kernel.cu:300,304).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/svoxt.h"
+#include "svoxt_device.h"
+
+#pragma clang fp contract(off)
+
+namespace svoxt {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------
+// Forward: trace_ray (rt_kernel.cu:222-328) + render_ray_kernel (:655-671)
+// ---------------------------------------------------------------------------
+
+// FMT: FMT_RGBA or FMT_SH (specialised);  C: colour channels;  BD: basis dim.
+template <int FMT, int C, int BD, bool N2>
+__global__ void __launch_bounds__(kBlock)
+render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) {
+    constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= rays.Q) return;
+    float* o = out + q * (C + 1);
+
+    Ray r;
+    if (!setup_ray(tr, rays, q, r)) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) o[j] = opt.background_brightness;
+        o[C] = 0.f;
+        return;
+    }
+    float basis[BD > 0 ? BD : 1];
+    if constexpr (FMT == FMT_SH) {
+        const float* vd = rays.vdirs + 3 * q;
+        precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
+    }
+    float acc[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) acc[j] = 0.f;
+
+    float light = 1.f;
+    float t = r.tmin;
+    bool stopped = false;
+    while (t < r.tmax) {
+        Sample s;
+        march_step<N2>(tr, r, opt.step_size, t, s);
+        if (s.valid) {
+            const float* rowp = tr.features + (int64_t)s.idx * K;
+            const float sigma = rowp[K - 1];
+            if (sigma > opt.sigma_thresh) {
+                float row[K];
+                load_row<K>(rowp, row);
+                const float att = pexpf(-s.delta_t * r.delta_scale * sigma);
+                const float weight = light * (1.f - att);
+                if constexpr (FMT == FMT_SH) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        float tmp = 0.f;
+#pragma unroll
+                        for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
+                        acc[c] = (float)((double)acc[c] + (double)weight / (1.0 + (double)pexpf(-tmp)));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < C; ++j)
+                        acc[j] = (float)((double)acc[j] + (double)weight / (1.0 + (double)pexpf(-row[j])));
+                }
+                light *= att;
+                if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + s.leaf.slot, weight);
+                if (light <= opt.stop_thresh) { stopped = true; break; }
+            }
+        }
+        t += s.delta_t;
+    }
+    if (stopped) {
+        const float scale = (float)(1.0 / (1.0 - (double)light));
+#pragma unroll
+        for (int j = 0; j < C; ++j) o[j] = acc[j] * scale;
+    } else {
+        const float bg = light * opt.background_brightness;
+#pragma unroll
+        for (int j = 0; j < C; ++j) o[j] = acc[j] + bg;
+    }
+    o[C] = 1.f - light;
+}
+
+// Generic fallback: any K, any format, component sub-range; accumulators in
+// global memory exactly as the reference keeps them.
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= rays.Q) return;
+    float* o = out + q * (C + 1);
+    const int K = tr.K;
+
+    Ray r;
+    if (!setup_ray(tr, rays, q, r)) {
+        for (int j = 0; j < C; ++j) o[j] = opt.background_brightness;
+        o[C] = 0.f;
+        return;
+    }
+    for (int j = 0; j < C; ++j) o[j] = 0.f;
+    float basis[25];
+    {
+        const float* vd = rays.vdirs + 3 * q;
+        precalc_basis<0>(opt.format, opt.basis_dim, tr, vd[0], vd[1], vd[2], basis);
+    }
+    float light = 1.f;
+    float t = r.tmin;
+    while (t < r.tmax) {
+        Sample s;
+        march_step<N2>(tr, r, opt.step_size, t, s);
+        if (s.valid) {
+            const float* row = tr.features + (int64_t)s.idx * K;
+            const float sigma = row[K - 1];
+            if (sigma > opt.sigma_thresh) {
+                const float att = pexpf(-s.delta_t * r.delta_scale * sigma);
+                const float weight = light * (1.f - att);
+                if (opt.format != FMT_RGBA) {
+                    for (int c = 0; c < C; ++c) {
+                        const int off = c * opt.basis_dim;
+                        float tmp = 0.f;
+                        for (int i = opt.min_comp; i <= opt.max_comp; ++i) tmp += basis[i] * row[off + i];
+                        o[c] = (float)((double)o[c] + (double)weight / (1.0 + (double)pexpf(-tmp)));
+                    }
+                } else {
+                    for (int j = 0; j < C; ++j)
+                        o[j] = (float)((double)o[j] + (double)weight / (1.0 + (double)pexpf(-row[j])));
+                }
+                light *= att;
+                if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + s.leaf.slot, weight);
+                if (light <= opt.stop_thresh) {
+                    const float scale = (float)(1.0 / (1.0 - (double)light));
+                    for (int j = 0; j < C; ++j) o[j] *= scale;
+                    o[C] = 1.f - light;
+                    return;
+                }
+            }
+        }
+        t += s.delta_t;
+    }
+    for (int j = 0; j < C; ++j) o[j] += light * opt.background_brightness;
+    o[C] = 1.f - light;
+}
+
+// ---------------------------------------------------------------------------
+// Backward: trace_ray_backward (rt_kernel.cu:331-496) + kernel (:675-694)
+// ---------------------------------------------------------------------------
+
+// Two marches, as the reference: pass 1 scatters the colour gradients and
+// builds `accum`, pass 2 scatters the sigma gradients.
+template <int FMT, int C, int BD, bool N2>
+__global__ void __launch_bounds__(kBlock)
+render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
+                  float* __restrict__ grad) {
+    constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= rays.Q) return;
+    Ray r;
+    if (!setup_ray(tr, rays, q, r)) return;
+
+    float basis[BD > 0 ? BD : 1];
+    if constexpr (FMT == FMT_SH) {
+        const float* vd = rays.vdirs + 3 * q;
+        precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
+    }
+    float g[C + 1];
+#pragma unroll
+    for (int j = 0; j <= C; ++j) g[j] = grad_out[q * (C + 1) + j];
+
+    float accum = 0.f;
+    float light_ray;
+    {   // pass 1
+        float light = 1.f, t = r.tmin;
+        while (t < r.tmax) {
+            Sample s;
+            march_step<N2>(tr, r, opt.step_size, t, s);
+            if (s.valid) {
+                const float* rowp = tr.features + (int64_t)s.idx * K;
+                const float sigma = rowp[K - 1];
+                if (sigma > 0.f) {
+                    float row[K];
+                    load_row<K>(rowp, row);
+                    float* grow = grad + (int64_t)s.idx * K;
+                    const float att = pexpf(-s.delta_t * sigma * r.delta_scale);
+                    const float weight = light * (1.f - att);
+                    float total_color = 0.f;
+                    if constexpr (FMT == FMT_SH) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            float tmp = 0.f;
+#pragma unroll
+                            for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
+                            const float sig = (float)sigmoid_d(tmp);
+                            const float gsig = (float)((double)sig * (1.0 - (double)sig));
+#pragma unroll
+                            for (int i = 0; i < BD; ++i)
+                                atomicAdd(grow + c * BD + i, weight * basis[i] * gsig * g[c]);
+                            total_color += sig * g[c];
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < C; ++j) {
+                            const float sig = (float)sigmoid_d(row[j]);
+                            atomicAdd(grow + j, weight * sig * (1.f - sig) * g[j]);
+                            total_color += sig * g[j];
+                        }
+                    }
+                    light *= att;
+                    accum += weight * total_color;
+                }
+            }
+            t += s.delta_t;
+        }
+        float total_grad = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) total_grad += g[j];
+        accum += light * opt.background_brightness * total_grad;
+        light_ray = light;
+    }
+    {   // pass 2
+        float light = 1.f, t = r.tmin;
+        while (t < r.tmax) {
+            Sample s;
+            march_step<N2>(tr, r, opt.step_size, t, s);
+            if (s.valid) {
+                const float* rowp = tr.features + (int64_t)s.idx * K;
+                const float sigma = rowp[K - 1];
+                if (sigma > 0.f) {
+                    float total_color = 0.f;
+                    if constexpr (C > 0) {
+                        float row[K];
+                        load_row<K>(rowp, row);
+                        if constexpr (FMT == FMT_SH) {
+#pragma unroll
+                            for (int c = 0; c < C; ++c) {
+                                float tmp = 0.f;
+#pragma unroll
+                                for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
+                                total_color = (float)((double)total_color + sigmoid_d(tmp) * (double)g[c]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < C; ++j)
+                                total_color = (float)((double)total_color + sigmoid_d(row[j]) * (double)g[j]);
+                        }
+                    }
+                    const float att = pexpf(-s.delta_t * sigma * r.delta_scale);
+                    const float weight = light * (1.f - att);
+                    light *= att;
+                    accum -= weight * total_color;
+                    const float toadd = s.delta_t * r.delta_scale * (total_color * light - accum)
+                                      + s.delta_t * r.delta_scale * g[C] * light_ray;
+                    atomicAdd(grad + (int64_t)s.idx * K + (K - 1), toadd);
+                }
+            }
+            t += s.delta_t;
+        }
+    }
+}
+
+// Generic backward: any K / format / component range / channel count
+// (C == 0 is opacity_render_backward, rt_kernel.cu:1593-1616).
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+render_bwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
+                          const float* __restrict__ grad_out, float* __restrict__ grad) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= rays.Q) return;
+    Ray r;
+    if (!setup_ray(tr, rays, q, r)) return;
+    const int K = tr.K;
+    const float* g = grad_out + q * (C + 1);
+    float basis[25];
+    {
+        const float* vd = rays.vdirs + 3 * q;
+        precalc_basis<0>(opt.format, opt.basis_dim, tr, vd[0], vd[1], vd[2], basis);
+    }
+    float accum = 0.f;
+    float light_ray;
+    {   // pass 1
+        float light = 1.f, t = r.tmin;
+        while (t < r.tmax) {
+            Sample s;
+            march_step<N2>(tr, r, opt.step_size, t, s);
+            if (s.valid) {
+                const float* row = tr.features + (int64_t)s.idx * K;
+                const float sigma = row[K - 1];
+                if (sigma > 0.f) {
+                    float* grow = grad + (int64_t)s.idx * K;
+                    const float att = pexpf(-s.delta_t * sigma * r.delta_scale);
+                    const float weight = light * (1.f - att);
+                    float total_color = 0.f;
+                    if (opt.format != FMT_RGBA) {
+                        for (int c = 0; c < C; ++c) {
+                            const int off = c * opt.basis_dim;
+                            float tmp = 0.f;
+                            for (int i = opt.min_comp; i <= opt.max_comp; ++i) tmp += basis[i] * row[off + i];
+                            const float sig = (float)(1.0 / (1.0 + (double)pexpf(-tmp)));
+                            const float gsig = (float)((double)sig * (1.0 - (double)sig));
+                            for (int i = opt.min_comp; i <= opt.max_comp; ++i)
+                                atomicAdd(grow + off + i, weight * basis[i] * gsig * g[c]);
+                            total_color += sig * g[c];
+                        }
+                    } else {
+                        for (int j = 0; j < C; ++j) {
+                            const float sig = (float)(1.0 / (1.0 + (double)pexpf(-row[j])));
+                            atomicAdd(grow + j, weight * sig * (1.f - sig) * g[j]);
+                            total_color += sig * g[j];
+                        }
+                    }
+                    light *= att;
+                    accum += weight * total_color;
+                }
+            }
+            t += s.delta_t;
+        }
+        float total_grad = 0.f;
+        for (int j = 0; j < C; ++j) total_grad += g[j];
+        accum += light * opt.background_brightness * total_grad;
+        light_ray = light;
+    }
+    {   // pass 2
+        float light = 1.f, t = r.tmin;
+        while (t < r.tmax) {
+            Sample s;
+            march_step<N2>(tr, r, opt.step_size, t, s);
+            if (s.valid) {
+                const float* row = tr.features + (int64_t)s.idx * K;
+                const float sigma = row[K - 1];
+                if (sigma > 0.f) {
+                    float total_color = 0.f;
+                    if (opt.format != FMT_RGBA) {
+                        for (int c = 0; c < C; ++c) {
+                            const int off = c * opt.basis_dim;
+                            float tmp = 0.f;
+                            for (int i = opt.min_comp; i <= opt.max_comp; ++i) tmp += basis[i] * row[off + i];
+                            total_color = (float)((double)total_color + 1.0 / (1.0 + (double)pexpf(-tmp)) * (double)g[c]);
+                        }
+                    } else {
+                        for (int j = 0; j < C; ++j)
+                            total_color = (float)((double)total_color + 1.0 / (1.0 + (double)pexpf(-row[j])) * (double)g[j]);
+                    }
+                    const float att = pexpf(-s.delta_t * sigma * r.delta_scale);
+                    const float weight = light * (1.f - att);
+                    light *= att;
+                    accum -= weight * total_color;
+                    const float toadd = s.delta_t * r.delta_scale * (total_color * light - accum)
+                                      + s.delta_t * r.delta_scale * g[C] * light_ray;
+                    atomicAdd(grad + (int64_t)s.idx * K + (K - 1), toadd);
+                }
+            }
+            t += s.delta_t;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Opacity (rt_kernel.cu:500-560, :1110-1126) and depth (:782-834, :866-882)
+// ---------------------------------------------------------------------------
+
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= rays.Q) return;
+    Ray r;
+    if (!setup_ray(tr, rays, q, r)) { out[q] = 0.f; return; }
+    const int K = tr.K;
+    float light = 1.f, t = r.tmin;
+    while (t < r.tmax) {
+        Sample s;
+        march_step<N2>(tr, r, opt.step_size, t, s);
+        if (s.valid) {
+            const float sigma = tr.features[(int64_t)s.idx * K + (K - 1)];
+            if (sigma > opt.sigma_thresh) {
+                light *= pexpf(-s.delta_t * r.delta_scale * sigma);
+                if (light <= opt.stop_thresh) break;
+            }
+        }
+        t += s.delta_t;
+    }
+    out[q] = 1.f - light;
+}
+
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+depth_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ depth) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= rays.Q) return;
+    Ray r;
+    float d = 0.f;
+    if (setup_ray(tr, rays, q, r)) {
+        const int K = tr.K;
+        float t = r.tmin;
+        while (t < r.tmax) {
+            Sample s;
+            march_step<N2>(tr, r, opt.step_size, t, s);
+            if (s.valid) {
+                const float sigma = tr.features[(int64_t)s.idx * K + (K - 1)];
+                if (sigma > opt.sigma_thresh) { d = r.delta_scale * t; break; }
+            }
+            t += s.delta_t;
+        }
+    }
+    depth[q] = d;
+}
+
+// ---------------------------------------------------------------------------
+// Roofline counters
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+count_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, unsigned long long* __restrict__ counters) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    unsigned long long hit = 0, steps = 0, levels = 0, valid = 0, active = 0;
+    Ray r;
+    if (q < rays.Q && setup_ray(tr, rays, q, r)) {
+        hit = 1;
+        const int K = tr.K;
+        float light = 1.f, t = r.tmin;
+        while (t < r.tmax) {
+            Sample s;
+            march_step<N2>(tr, r, opt.step_size, t, s);
+            ++steps;
+            levels += s.leaf.levels;
+            if (s.valid) {
+                ++valid;
+                const float sigma = tr.features[(int64_t)s.idx * K + (K - 1)];
+                if (sigma > opt.sigma_thresh) {
+                    ++active;
+                    light *= pexpf(-s.delta_t * r.delta_scale * sigma);
+                    if (light <= opt.stop_thresh) break;
+                }
+            }
+            t += s.delta_t;
+        }
+    }
+    hit = wave_sum(hit); steps = wave_sum(steps); levels = wave_sum(levels);
+    valid = wave_sum(valid); active = wave_sum(active);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(counters + 0, hit);
+        atomicAdd(counters + 1, steps);
+        atomicAdd(counters + 2, levels);
+        atomicAdd(counters + 3, valid);
+        atomicAdd(counters + 4, active);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Point query (svox_kernel.cu:45-94)
+// ---------------------------------------------------------------------------
+
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+query_fwd_kernel(TreeDev tr, const float* __restrict__ points, int64_t Q,
+                 float* __restrict__ values, int64_t* __restrict__ node_ids,
+                 int64_t* __restrict__ data_ids, uint8_t* __restrict__ hit_mask) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= Q) return;
+    const float* p = points + 3 * q;
+    const float px = tr.offset[0] + tr.scaling[0] * p[0];
+    const float py = tr.offset[1] + tr.scaling[1] * p[1];
+    const float pz = tr.offset[2] + tr.scaling[2] * p[2];
+    Leaf lf;
+    locate<N2>(tr, px, py, pz, lf);
+    node_ids[q] = (int64_t)lf.slot;
+    if (hit_mask != nullptr) hit_mask[lf.slot] = 1;
+    const int32_t idx = tr.data[lf.slot];
+    const int K = tr.K;
+    float* v = values + q * K;
+    if (idx >= 0 && (int64_t)idx < tr.M) {
+        data_ids[q] = idx;
+        const float* row = tr.features + (int64_t)idx * K;
+        for (int i = 0; i < K; ++i) v[i] = row[i];
+    } else {
+        data_ids[q] = -1;
+        for (int i = 0; i < K; ++i) v[i] = 0.f;
+    }
+}
+
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+query_bwd_kernel(TreeDev tr, const float* __restrict__ points, int64_t Q,
+                 const float* __restrict__ grad_out, float* __restrict__ grad) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= Q) return;
+    const float* p = points + 3 * q;
+    const float px = tr.offset[0] + tr.scaling[0] * p[0];
+    const float py = tr.offset[1] + tr.scaling[1] * p[1];
+    const float pz = tr.offset[2] + tr.scaling[2] * p[2];
+    Leaf lf;
+    locate<N2>(tr, px, py, pz, lf);
+    const int32_t idx = tr.data[lf.slot];
+    if (idx < 0 || (int64_t)idx >= tr.M) return;
+    const int K = tr.K;
+    for (int i = 0; i < K; ++i) atomicAdd(grad + (int64_t)idx * K + i, grad_out[q * K + i]);
+}
+
+}  // namespace svoxt
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+
+using namespace svoxt;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
+    snprintf(g_err, sizeof(g_err), fmt, a, b);
+    return code;
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SVOXT_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return SVOXT_OK;
+}
+
+int check_tree(const svoxt_tree* t, const char* fn) {
+    if (t == nullptr) return fail(SVOXT_ERR_INVALID, "%s: tree is NULL", fn);
+    if (t->features == nullptr && t->M > 0) return fail(SVOXT_ERR_INVALID, "%s: tree.features is NULL", fn);
+    if (t->data == nullptr || t->child == nullptr) return fail(SVOXT_ERR_INVALID, "%s: tree.data / tree.child is NULL", fn);
+    if (t->offset == nullptr || t->scaling == nullptr) return fail(SVOXT_ERR_INVALID, "%s: tree.offset / tree.scaling is NULL", fn);
+    if (t->K < 1 || t->M < 0) return fail(SVOXT_ERR_INVALID, "%s: bad feature table extents", fn);
+    if (t->N < 2) return fail(SVOXT_ERR_INVALID, "%s: branching factor N must be >= 2", fn);
+    if (t->n_internal < 1) return fail(SVOXT_ERR_INVALID, "%s: n_internal must be >= 1", fn);
+    if ((double)t->n_internal * t->N * t->N * t->N >= 2147483648.0)
+        return fail(SVOXT_ERR_INVALID, "%s: tree too large for 32-bit slot indices", fn);
+    if (t->xform != nullptr)
+        return fail(SVOXT_ERR_UNSUPPORTED, "%s: transformation_matrices are not supported", fn);
+    return SVOXT_OK;
+}
+
+int check_rays(const svoxt_rays* r, const char* fn) {
+    if (r == nullptr) return fail(SVOXT_ERR_INVALID, "%s: rays is NULL", fn);
+    if (r->Q < 0) return fail(SVOXT_ERR_INVALID, "%s: negative ray count", fn);
+    if (r->Q > 0 && (r->origins == nullptr || r->dirs == nullptr || r->vdirs == nullptr))
+        return fail(SVOXT_ERR_INVALID, "%s: rays.origins / dirs / vdirs is NULL", fn);
+    if (r->Q >= (int64_t)kBlock * 2147483647LL) return fail(SVOXT_ERR_INVALID, "%s: too many rays", fn);
+    return SVOXT_OK;
+}
+
+int check_opts(const svoxt_options* o, const svoxt_tree* t, const char* fn, bool needs_basis) {
+    if (o == nullptr) return fail(SVOXT_ERR_INVALID, "%s: options is NULL", fn);
+    if (o->format < SVOXT_FORMAT_RGBA || o->format > SVOXT_FORMAT_ASG)
+        return fail(SVOXT_ERR_INVALID, "%s: unknown data format", fn);
+    if (!needs_basis || o->format == SVOXT_FORMAT_RGBA) return SVOXT_OK;
+    if (o->basis_dim < 1 || o->basis_dim > 25)
+        return fail(SVOXT_ERR_INVALID, "%s: basis_dim must be in [1, 25]", fn);
+    if (o->format == SVOXT_FORMAT_SH && o->basis_dim != 1 && o->basis_dim != 4 && o->basis_dim != 9 &&
+        o->basis_dim != 16 && o->basis_dim != 25)
+        return fail(SVOXT_ERR_INVALID, "%s: SH basis_dim must be 1, 4, 9, 16 or 25", fn);
+    if (o->min_comp < 0 || o->max_comp >= o->basis_dim)
+        return fail(SVOXT_ERR_INVALID, "%s: min_comp / max_comp outside [0, basis_dim)", fn);
+    if (o->format == SVOXT_FORMAT_SG || o->format == SVOXT_FORMAT_ASG) {
+        const int need = o->format == SVOXT_FORMAT_SG ? 4 : 11;
+        if (t->extra_data == nullptr || t->extra_rows < o->basis_dim || t->extra_cols < need)
+            return fail(SVOXT_ERR_INVALID, "%s: SG/ASG formats need extra_data [basis_dim, >=4/11]", fn);
+    }
+    return SVOXT_OK;
+}
+
+TreeDev to_dev(const svoxt_tree* t) {
+    TreeDev d;
+    d.features = t->features; d.M = t->M; d.K = t->K; d.N = t->N;
+    d.data = t->data; d.child = t->child; d.offset = t->offset; d.scaling = t->scaling;
+    d.extra = t->extra_data; d.extra_rows = t->extra_rows; d.extra_cols = t->extra_cols;
+    d.weight_accum = t->weight_accum;
+    return d;
+}
+
+RaysDev to_dev(const svoxt_rays* r) {
+    RaysDev d;
+    d.origins = r->origins; d.dirs = r->dirs; d.vdirs = r->vdirs; d.Q = r->Q;
+    return d;
+}
+
+Opts to_dev(const svoxt_options* o) {
+    Opts d;
+    static_assert(sizeof(Opts) == sizeof(svoxt_options), "options layout");
+    memcpy(&d, o, sizeof(d));
+    return d;
+}
+
+inline unsigned nblocks(int64_t Q) { return (unsigned)((Q + kBlock - 1) / kBlock); }
+
+// Specialised payloads: (format, C, BD) with all components selected.
+struct Payload { int fmt, C, BD; };
+
+bool full_comp(const svoxt_options* o) {
+    return o->format == SVOXT_FORMAT_RGBA || (o->min_comp == 0 && o->max_comp == o->basis_dim - 1);
+}
+
+template <bool N2>
+bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C, float* out,
+                        hipStream_t st) {
+    const unsigned nb = nblocks(rays.Q);
+#define SVOXT_FWD(F, CC, BB)                                                              \
+    hipLaunchKernelGGL((render_fwd_kernel<F, CC, BB, N2>), dim3(nb), dim3(kBlock), 0, st, \
+                       tr, rays, opt, out);                                               \
+    return true;
+    if (opt.format == FMT_RGBA) {
+        if (C == 3) { SVOXT_FWD(FMT_RGBA, 3, 0) }
+        if (C == 31) { SVOXT_FWD(FMT_RGBA, 31, 0) }
+    } else if (opt.format == FMT_SH && C == 3) {
+        switch (opt.basis_dim) {
+            case 1: SVOXT_FWD(FMT_SH, 3, 1)
+            case 4: SVOXT_FWD(FMT_SH, 3, 4)
+            case 9: SVOXT_FWD(FMT_SH, 3, 9)
+            case 16: SVOXT_FWD(FMT_SH, 3, 16)
+            case 25: SVOXT_FWD(FMT_SH, 3, 25)
+        }
+    }
+#undef SVOXT_FWD
+    return false;
+}
+
+template <bool N2>
+bool launch_bwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
+                        const float* grad_out, float* grad, hipStream_t st) {
+    const unsigned nb = nblocks(rays.Q);
+#define SVOXT_BWD(F, CC, BB)                                                              \
+    hipLaunchKernelGGL((render_bwd_kernel<F, CC, BB, N2>), dim3(nb), dim3(kBlock), 0, st, \
+                       tr, rays, opt, grad_out, grad);                                    \
+    return true;
+    if (opt.format == FMT_RGBA) {
+        if (C == 3) { SVOXT_BWD(FMT_RGBA, 3, 0) }
+        if (C == 31) { SVOXT_BWD(FMT_RGBA, 31, 0) }
+    } else if (opt.format == FMT_SH && C == 3) {
+        switch (opt.basis_dim) {
+            case 1: SVOXT_BWD(FMT_SH, 3, 1)
+            case 4: SVOXT_BWD(FMT_SH, 3, 4)
+            case 9: SVOXT_BWD(FMT_SH, 3, 9)
+            case 16: SVOXT_BWD(FMT_SH, 3, 16)
+            case 25: SVOXT_BWD(FMT_SH, 3, 25)
+        }
+    }
+#undef SVOXT_BWD
+    return false;
+}
+
+int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
+               const float* grad_out, int32_t grad_cols, float* grad_features, void* stream,
+               const char* fn) {
+    int rc;
+    if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) ||
+        (rc = check_opts(opt, tree, fn, grad_cols > 1)))
+        return rc;
+    if (grad_features == nullptr && tree->M > 0) return fail(SVOXT_ERR_INVALID, "%s: grad_features is NULL", fn);
+    if (rays->Q > 0 && grad_out == nullptr) return fail(SVOXT_ERR_INVALID, "%s: grad_out is NULL", fn);
+    const int C = grad_cols - 1;
+    if (C < 0) return fail(SVOXT_ERR_INVALID, "%s: grad_cols must be >= 1", fn);
+    if (C > 0) {
+        const int want = svoxt_out_data_dim(opt, tree->K);
+        if (want != grad_cols) return fail(SVOXT_ERR_INVALID, "%s: grad_out columns do not match get_out_data_dim", fn);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (tree->M > 0) {
+        const hipError_t e = hipMemsetAsync(grad_features, 0, sizeof(float) * (size_t)tree->M * tree->K, st);
+        if (e != hipSuccess) return fail(SVOXT_ERR_HIP, "%s: hipMemsetAsync: %s", fn, hipGetErrorString(e));
+    }
+    if (rays->Q == 0 || tree->M == 0) return SVOXT_OK;
+    const TreeDev tr = to_dev(tree);
+    const RaysDev rd = to_dev(rays);
+    const Opts od = to_dev(opt);
+    const bool n2 = tree->N == 2;
+    bool done = false;
+    if (C > 0 && full_comp(opt))
+        done = n2 ? launch_bwd_special<true>(tr, rd, od, C, grad_out, grad_features, st)
+                  : launch_bwd_special<false>(tr, rd, od, C, grad_out, grad_features, st);
+    if (!done) {
+        const unsigned nb = nblocks(rays->Q);
+        if (n2) hipLaunchKernelGGL((render_bwd_generic_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, grad_out, grad_features);
+        else hipLaunchKernelGGL((render_bwd_generic_kernel<false>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, grad_out, grad_features);
+    }
+    return check_launch(fn);
+}
+
+}  // namespace
+
+extern "C" {
+
+int svoxt_abi_version(void) { return SVOXT_ABI_VERSION; }
+
+const char* svoxt_last_error(void) { return g_err; }
+
+int svoxt_out_data_dim(const svoxt_options* opt, int32_t K) {
+    if (opt == nullptr || K < 1) return -1;
+    if (opt->format != SVOXT_FORMAT_RGBA) {
+        if (opt->basis_dim < 1) return -1;
+        return (K - 1) / opt->basis_dim + 1;
+    }
+    return K;
+}
+
+int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
+                            const svoxt_options* opt, float* out, void* stream) {
+    const char* fn = "svoxt_volume_render_fwd";
+    int rc;
+    if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) || (rc = check_opts(opt, tree, fn, true)))
+        return rc;
+    if (rays->Q == 0) return SVOXT_OK;
+    if (out == nullptr) return fail(SVOXT_ERR_INVALID, "%s: out is NULL", fn);
+    const int C = svoxt_out_data_dim(opt, tree->K) - 1;
+    if (C < 0) return fail(SVOXT_ERR_INVALID, "%s: bad output width", fn);
+    if (opt->format != SVOXT_FORMAT_RGBA && (int64_t)C * opt->basis_dim > tree->K - 1)
+        return fail(SVOXT_ERR_INVALID, "%s: data_dim is not channels * basis_dim + 1", fn);
+    hipStream_t st = (hipStream_t)stream;
+    const TreeDev tr = to_dev(tree);
+    const RaysDev rd = to_dev(rays);
+    const Opts od = to_dev(opt);
+    const bool n2 = tree->N == 2;
+    bool done = false;
+    if (full_comp(opt))
+        done = n2 ? launch_fwd_special<true>(tr, rd, od, C, out, st)
+                  : launch_fwd_special<false>(tr, rd, od, C, out, st);
+    if (!done) {
+        const unsigned nb = nblocks(rays->Q);
+        if (n2) hipLaunchKernelGGL((render_fwd_generic_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, out);
+        else hipLaunchKernelGGL((render_fwd_generic_kernel<false>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, out);
+    }
+    return check_launch(fn);
+}
+
+int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
+                            const svoxt_options* opt, const float* grad_out,
+                            int32_t grad_cols, const float* fwd_out,
+                            float* grad_features, void* stream) {
+    (void)fwd_out;  // single-march backward not implemented yet: the two-march path needs no forward output
+    if (grad_cols < 2)
+        return fail(SVOXT_ERR_INVALID, "%s: grad_cols must be C+1 >= 2 (use svoxt_opacity_render_bwd for C = 0)",
+                    "svoxt_volume_render_bwd");
+    return bwd_common(tree, rays, opt, grad_out, grad_cols, grad_features, stream, "svoxt_volume_render_bwd");
+}
+
+int svoxt_opacity_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
+                             const svoxt_options* opt, float* out, void* stream) {
+    const char* fn = "svoxt_opacity_render_fwd";
+    int rc;
+    if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) || (rc = check_opts(opt, tree, fn, false)))
+        return rc;
+    if (rays->Q == 0) return SVOXT_OK;
+    if (out == nullptr) return fail(SVOXT_ERR_INVALID, "%s: out is NULL", fn);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = nblocks(rays->Q);
+    if (tree->N == 2) hipLaunchKernelGGL((opacity_fwd_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), out);
+    else hipLaunchKernelGGL((opacity_fwd_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), out);
+    return check_launch(fn);
+}
+
+int svoxt_opacity_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
+                             const svoxt_options* opt, const float* grad_out,
+                             float* grad_features, void* stream) {
+    return bwd_common(tree, rays, opt, grad_out, 1, grad_features, stream, "svoxt_opacity_render_bwd");
+}
+
+int svoxt_render_depth(const svoxt_tree* tree, const svoxt_rays* rays,
+                       const svoxt_options* opt, float* depth, void* stream) {
+    const char* fn = "svoxt_render_depth";
+    int rc;
+    if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) || (rc = check_opts(opt, tree, fn, false)))
+        return rc;
+    if (rays->Q == 0) return SVOXT_OK;
+    if (depth == nullptr) return fail(SVOXT_ERR_INVALID, "%s: depth is NULL", fn);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = nblocks(rays->Q);
+    if (tree->N == 2) hipLaunchKernelGGL((depth_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), depth);
+    else hipLaunchKernelGGL((depth_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), depth);
+    return check_launch(fn);
+}
+
+int svoxt_query_fwd(const svoxt_tree* tree, const float* points, int64_t Q,
+                    float* values, int64_t* node_ids, int64_t* data_ids,
+                    uint8_t* hit_mask, void* stream) {
+    const char* fn = "svoxt_query_fwd";
+    int rc;
+    if ((rc = check_tree(tree, fn))) return rc;
+    if (Q < 0) return fail(SVOXT_ERR_INVALID, "%s: negative point count", fn);
+    if (Q == 0) return SVOXT_OK;
+    if (points == nullptr || values == nullptr || node_ids == nullptr || data_ids == nullptr)
+        return fail(SVOXT_ERR_INVALID, "%s: points / values / node_ids / data_ids is NULL", fn);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = nblocks(Q);
+    if (tree->N == 2) hipLaunchKernelGGL((query_fwd_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), points, Q, values, node_ids, data_ids, hit_mask);
+    else hipLaunchKernelGGL((query_fwd_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), points, Q, values, node_ids, data_ids, hit_mask);
+    return check_launch(fn);
+}
+
+int svoxt_query_bwd(const svoxt_tree* tree, const float* points, int64_t Q,
+                    const float* grad_out, float* grad_features, void* stream) {
+    const char* fn = "svoxt_query_bwd";
+    int rc;
+    if ((rc = check_tree(tree, fn))) return rc;
+    if (Q < 0) return fail(SVOXT_ERR_INVALID, "%s: negative point count", fn);
+    if (grad_features == nullptr && tree->M > 0) return fail(SVOXT_ERR_INVALID, "%s: grad_features is NULL", fn);
+    hipStream_t st = (hipStream_t)stream;
+    if (tree->M > 0) {
+        const hipError_t e = hipMemsetAsync(grad_features, 0, sizeof(float) * (size_t)tree->M * tree->K, st);
+        if (e != hipSuccess) return fail(SVOXT_ERR_HIP, "%s: hipMemsetAsync: %s", fn, hipGetErrorString(e));
+    }
+    if (Q == 0 || tree->M == 0) return SVOXT_OK;
+    if (points == nullptr || grad_out == nullptr) return fail(SVOXT_ERR_INVALID, "%s: points / grad_out is NULL", fn);
+    const unsigned nb = nblocks(Q);
+    if (tree->N == 2) hipLaunchKernelGGL((query_bwd_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), points, Q, grad_out, grad_features);
+    else hipLaunchKernelGGL((query_bwd_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), points, Q, grad_out, grad_features);
+    return check_launch(fn);
+}
+
+int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
+                    const svoxt_options* opt, int64_t* counters, void* stream) {
+    const char* fn = "svoxt_count_fwd";
+    int rc;
+    if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) || (rc = check_opts(opt, tree, fn, false)))
+        return rc;
+    if (counters == nullptr) return fail(SVOXT_ERR_INVALID, "%s: counters is NULL", fn);
+    if (rays->Q == 0) return SVOXT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = nblocks(rays->Q);
+    unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
+    if (tree->N == 2) hipLaunchKernelGGL((count_fwd_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), c);
+    else hipLaunchKernelGGL((count_fwd_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), c);
+    return check_launch(fn);
+}
+
+}  // extern "C"
