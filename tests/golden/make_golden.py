@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz / *.json by importing the REFERENCE Python
+package on the CPU (this container only; /root/reference never travels).
+
+    python tests/golden/make_golden.py      # needs /root/reference
+
+What can be pinned this way: the reference's render and query
+arithmetic is not reachable without its CUDA extension, but its tree-topology
+code, SH polynomials and small helpers run on CPU.  The fixtures hold only data
+(inputs and the reference's outputs):
+
+  topology_*.npz   child / parent_depth / data / n_internal produced by the
+                   reference's N3Tree.refine -- full refinement and selective
+                   (shell) refinement driven through refine(sel=..., leaf_node=...)
+                   -- plus leaf corners / depths from its CPU _calc_corners
+  sh_bases.npz     sh.eval_sh_bases(deg, dirs) in float64 for deg 0..4, and
+                   sh.eval_sh(deg, coeffs, dirs) (pins the channel-major layout)
+  helpers.json     DataFormat parse table, offset / invradius / world2tree for a
+                   non-unit radius and centre, _pack_index / _unpack_index
+"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+warnings.simplefilter("ignore")
+
+import svox_t as ref                       # noqa: E402  (the reference, CPU only: _C is None)
+from svox_t import sh as ref_sh            # noqa: E402
+from svox_t.helpers import DataFormat as RefDataFormat   # noqa: E402
+
+from svox_t_amd import synth               # noqa: E402  (only for the shell predicate)
+
+
+def ref_tree_arrays(t):
+    n = t.n_internal
+    return dict(child=t.child[:n].numpy().copy(), parent_depth=t.parent_depth[:n].numpy().copy(),
+                data=t.data[:n].numpy().copy(), n_internal=np.int64(n))
+
+
+def full_tree(N, levels):
+    t = ref.N3Tree(N=N, data_dim=4, init_reserve=200000, data_format="RGBA")
+    for _ in range(levels):
+        t.refine(1)                         # refine(repeats>1) crashes upstream (svox.py:521-522)
+    return t
+
+
+def shell_tree_via_reference(depth):
+    """Drive the reference's selective refine with the shell predicate."""
+    t = ref.N3Tree(N=2, data_dim=4, init_reserve=200000, data_format="RGBA")
+    for lvl in range(1, depth):
+        leaves = t._all_leaves()                                  # [L, 4] (node, x, y, z), lexicographic
+        corners = t._calc_corners(leaves, cuda=False).double().numpy()
+        depths = t.parent_depth[leaves[:, 0], 1].numpy()
+        side = 0.5 ** (depths + 1.0)
+        # only the deepest leaves can still meet the shell, but test them all
+        hit = np.zeros(len(leaves), dtype=bool)
+        for s in np.unique(side):
+            m = side == s
+            hit[m] = synth._box_hits_shell(corners[m], float(s))
+        hit &= side == 0.5 ** lvl
+        sel_nodes = leaves[torch.from_numpy(hit)]
+        t.refine(1, sel=(*sel_nodes.T,), leaf_node=sel_nodes)
+    leaves = t._all_leaves()
+    corners = t._calc_corners(leaves, cuda=False).numpy()
+    out = ref_tree_arrays(t)
+    out.update(leaves=leaves.numpy(), corners=corners,
+               depths=t.parent_depth[leaves[:, 0], 1].numpy())
+    return out
+
+
+def main():
+    # ---- topology ---------------------------------------------------------
+    np.savez_compressed(os.path.join(HERE, "topology_full_n2_l3.npz"), **ref_tree_arrays(full_tree(2, 3)))
+    np.savez_compressed(os.path.join(HERE, "topology_full_n3_l2.npz"), **ref_tree_arrays(full_tree(3, 2)))
+    for d in (3, 4, 5):
+        np.savez_compressed(os.path.join(HERE, f"topology_shell_d{d}.npz"), **shell_tree_via_reference(d))
+
+    # ---- SH ---------------------------------------------------------------
+    g = torch.Generator().manual_seed(7)
+    dirs = torch.randn(64, 3, generator=g, dtype=torch.float64)
+    dirs /= dirs.norm(dim=-1, keepdim=True)
+    dirs[0] = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)
+    dirs[1] = torch.tensor([1.0, 0.0, 0.0], dtype=torch.float64)
+    dirs[2] = torch.tensor([0.0, -1.0, 0.0], dtype=torch.float64)
+    out = {"dirs": dirs.numpy()}
+    for deg in range(5):
+        out[f"bases_deg{deg}"] = ref_sh.eval_sh_bases(deg, dirs).numpy()
+    coeffs = torch.randn(64, 3, 9, generator=g, dtype=torch.float64)
+    out["coeffs_deg2"] = coeffs.numpy()
+    out["eval_sh_deg2"] = ref_sh.eval_sh(2, coeffs, dirs).numpy()
+    np.savez_compressed(os.path.join(HERE, "sh_bases.npz"), **out)
+
+    # ---- helpers ------------------------------------------------------------
+    fmt = {}
+    for txt in ["RGBA", "", "SH1", "SH4", "SH9", "SH16", "SH25", "SG25", "ASG8", "XYZ3", "RGBA4"]:
+        f = RefDataFormat(txt)
+        fmt[txt] = {"format": int(f.format), "basis_dim": int(f.basis_dim), "repr": repr(f)}
+    radius, center = [1.0, 1.2, 0.8], [0.1, -0.2, 0.3]
+    t = ref.N3Tree(N=2, data_dim=4, init_reserve=10, radius=radius, center=center, data_format="RGBA")
+    pts = torch.randn(16, 3, generator=g)
+    txyz = torch.tensor([[0, 0, 0, 0], [5, 1, 0, 1], [123, 1, 1, 1], [7, 0, 1, 0]])
+    t3 = ref.N3Tree(N=3, data_dim=4, init_reserve=10)
+    helpers = {
+        "data_format": fmt,
+        "radius": radius, "center": center,
+        "offset": t.offset.tolist(), "invradius": t.invradius.tolist(),
+        "points": pts.tolist(), "world2tree": t.world2tree(pts).tolist(),
+        "txyz": txyz.tolist(),
+        "pack_n2": t._pack_index(txyz).tolist(),
+        "unpack_n2": t._unpack_index(t._pack_index(txyz).clone()).tolist(),
+        "pack_n3": t3._pack_index(txyz).tolist(),
+        "empty_sentinel": int(t.data.flatten()[0].item()),
+    }
+    with open(os.path.join(HERE, "helpers.json"), "w") as f:
+        json.dump(helpers, f, indent=1)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol
+include/svoxt.h declares; argument validation (which runs before any HIP call)
+returns the documented codes; the Python operator layer rejects what the
+reference's TORCH_CHECKs reject.  No compute, no GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import svox_t_amd as svox
+import svox_t_amd.csrc as _C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "svoxt.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(svoxt_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_C.LIB_PATH)
+    names = header_symbols()
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(_C.EXPORTS)          # the ctypes table and the header agree
+    assert lib.svoxt_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # sizes the C compiler gives the three structs (x86-64 SysV): 14 fields / 4 / 11
+    assert ctypes.sizeof(_C._COptions) == 44
+    assert ctypes.sizeof(_C._CRays) == 32
+    assert ctypes.sizeof(_C._CTree) == 96
+
+
+def test_out_data_dim():
+    o = _C.RenderOptions()
+    o.format, o.basis_dim = 0, -1
+    assert _C.get_out_data_dim(o, 4) == 4 and _C.get_out_data_dim(o, 32) == 32
+    o.format, o.basis_dim = 1, 9
+    assert _C.get_out_data_dim(o, 28) == 4
+    o.basis_dim = 0
+    with pytest.raises(RuntimeError):
+        _C.get_out_data_dim(o, 28)
+
+
+def test_validation_codes_without_touching_the_gpu():
+    lib = _C._lib
+    assert lib.svoxt_volume_render_fwd(None, None, None, None, None) == 1      # SVOXT_ERR_INVALID
+    assert b"tree is NULL" in lib.svoxt_last_error()
+    t = _C._CTree()
+    assert lib.svoxt_render_depth(ctypes.byref(t), None, None, None, None) == 1
+    assert b"NULL" in lib.svoxt_last_error()
+    # transformation matrices: valid for the reference, unsupported here
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    t = _C._CTree(features=p, M=1, K=4, N=2, data=p, child=p, n_internal=1, offset=p, scaling=p, xform=p)
+    assert lib.svoxt_opacity_render_fwd(ctypes.byref(t), None, None, None, None) == 2   # SVOXT_ERR_UNSUPPORTED
+    t.xform = None
+    r = _C._CRays(Q=0)
+    o = _C._COptions(format=1, basis_dim=7)
+    assert lib.svoxt_volume_render_fwd(ctypes.byref(t), ctypes.byref(r), ctypes.byref(o), None, None) == 1
+    assert b"basis_dim" in lib.svoxt_last_error()
+    # Q == 0 is a valid no-op (empty ray batch)
+    o = _C._COptions(format=0, basis_dim=-1)
+    assert lib.svoxt_volume_render_fwd(ctypes.byref(t), ctypes.byref(r), ctypes.byref(o), None, None) == 0
+
+
+def test_operator_layer_rejects_cpu_and_noncontiguous_tensors():
+    tree = svox.N3Tree(N=2, data_dim=4, init_reserve=4)
+    r = svox.VolumeRenderer(tree)
+    rays = svox.Rays(torch.zeros(4, 3), torch.ones(4, 3), torch.ones(4, 3))
+    with pytest.raises(RuntimeError, match="GPU"):
+        r(tree.features, rays)                         # tree not on a GPU
+    with pytest.raises(RuntimeError, match="GPU"):
+        r(tree.features, rays, cuda=False)             # the reference asserts here
+    spec = tree._spec(tree.features)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        _C.volume_render(spec, svox.renderer._rays_spec_from_rays(rays), r._get_options())
+    with pytest.raises(RuntimeError, match="GPU"):
+        tree(tree.features, torch.zeros(2, 3))
+    with pytest.raises(NotImplementedError):
+        _C.volume_render_image(None, None, None)
+
+
+def test_spec_and_options_field_mapping():
+    """N3Tree._spec (svox.py:899-925) and VolumeRenderer._get_options
+    (renderer.py:408-439): defaults, `fast`, overrides, max_comp wrap, world=False."""
+    tree = svox.N3Tree(N=2, data_dim=28, init_reserve=4, data_format="SH9",
+                       radius=[1.0, 2.0, 4.0], center=[1.0, 0.0, 0.0])
+    r = svox.VolumeRenderer(tree)
+    o = r._get_options()
+    assert (o.step_size, o.background_brightness, o.format, o.basis_dim) == (1e-3, 1.0, 1, 9)
+    assert (o.min_comp, o.max_comp, o.ndc_width, o.sigma_thresh, o.stop_thresh) == (0, 8, -1, 0.0, 0.0)
+    o = r._get_options(fast=True)
+    assert (o.sigma_thresh, o.stop_thresh) == (1e-2, 1e-2)
+    r.sigma_thresh = 0.5
+    assert r._get_options(fast=True).sigma_thresh == 0.5 and r._get_options().stop_thresh == 0.0
+    r2 = svox.VolumeRenderer(tree, ndc=svox.NDCConfig(640, 480, 500.0), min_comp=1, max_comp=3)
+    o = r2._get_options()
+    assert (o.ndc_width, o.ndc_height, o.ndc_focal, o.min_comp, o.max_comp) == (640, 480, 500.0, 1, 3)
+    s = tree._spec(tree.features)
+    assert s.features is tree.features and s.n_internal == 1
+    assert s.offset is tree.offset and s.scaling is tree.invradius
+    assert s.extra_data.shape == (0, 0) and s.transformation_matrices.shape == (0, 0, 0)
+    assert s._weight_accum.numel() == 0
+    s = tree._spec(tree.features, world=False)
+    assert s.offset.tolist() == [0, 0, 0] and s.scaling.tolist() == [1, 1, 1]
+    with tree.accumulate_weights() as acc:
+        assert tree._spec(tree.features)._weight_accum is acc.value
+        with pytest.raises(RuntimeError, match="locked"):
+            tree.refine(1)
+    assert tree._weight_accum is None

@@ -1,0 +1,245 @@
+"""GPU tests of the point query, generic-N / SG / component-range paths, edge
+cases, and the full-size BASELINE workloads.  Through the Python surface ->
+ctypes -> C ABI."""
+import numpy as np
+import pytest
+import torch
+
+import svox_t_amd as svox
+import svox_t_amd.csrc as _C
+from oracle import oracle as O
+from svox_t_amd import synth
+from svox_t_amd.renderer import _rays_spec_from_rays
+from tests.util import Case, assert_grads_close, assert_outputs_close
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ query
+@pytest.mark.parametrize("world", [True, False])
+def test_query_vertical_matches_oracle(gpu, world):
+    c = Case(depth=5, K=13, data_format="SH4", width=8, height=8,
+             radius=[1.0, 1.2, 0.8], center=[0.1, -0.2, 0.3])
+    tree = c.tree(gpu)
+    g = torch.Generator().manual_seed(11)
+    pts = torch.rand(5000, 3, generator=g)
+    pts[:200] = torch.rand(200, 3, generator=g) * 3 - 1          # some outside the cube: clamped
+    if world:
+        pts = tree.tree2world(pts.to(gpu)).cpu()
+    vals, node_ids, data_ids, leaf_node = tree(tree.features, pts.to(gpu), want_node_ids=True,
+                                               world=world, want_data_ids=True, want_leaf_node=True)
+    ot = c.oracle_tree()
+    if not world:
+        ot = O.Tree(ot.features, ot.data, ot.child)
+    wv, wn, wd = O.query(ot, pts.numpy())
+    np.testing.assert_array_equal(vals.detach().cpu().numpy(), wv)
+    np.testing.assert_array_equal(node_ids.cpu().numpy(), wn)
+    np.testing.assert_array_equal(data_ids.cpu().numpy(), wd)
+    uniq = np.unique(wn)
+    N = 2
+    want_leaf = np.stack([uniq // 8, (uniq // 4) % 2, (uniq // 2) % 2, uniq % 2], -1)
+    np.testing.assert_array_equal(leaf_node.cpu().numpy(), want_leaf)
+    # backward: scatter-add of the upstream rows
+    gout = torch.randn(vals.shape, generator=g)
+    vals.backward(gout.to(gpu))
+    want = O.query_backward(ot, pts.numpy(), gout.numpy())
+    absum = O.query_backward(ot, pts.numpy(), gout.abs().numpy())
+    assert_grads_close(tree.features.grad.cpu().numpy(), want, absum)
+
+
+def test_point_keyed_view_refine_and_construct_tree(gpu):
+    """tree[points].refine() then construct_tree(points): the dynamic set-up
+    sequence of SURVEY.md 3.4, on the GPU."""
+    tree = svox.N3Tree(N=2, data_dim=4, init_reserve=64, map_location=gpu)
+    g = torch.Generator().manual_seed(2)
+    pts = (torch.rand(300, 3, generator=g) * 0.2 + 0.4).to(gpu)     # a blob in the middle
+    for _ in range(3):
+        tree[svox.LocalIndex(pts)].refine()
+    assert tree.max_depth == 3
+    # every point now sits in a depth-3 leaf
+    view = tree[svox.LocalIndex(pts)]
+    assert int(view.depths.min()) == 3
+    tree.construct_tree(tree.tree2world(pts))
+    feats = torch.randn(300, 4, device=gpu)
+    vals, _, data_ids = tree(feats, tree.tree2world(pts), want_node_ids=True, want_data_ids=True)
+    # several points may share a leaf: the leaf keeps one of them; that point reads itself back
+    ids = data_ids.cpu().numpy()
+    assert ids.min() >= 0 and ids.max() < 300
+    np.testing.assert_array_equal(vals.cpu().numpy(), feats.cpu().numpy()[ids])
+
+
+# ------------------------------------------------- generic paths and edge cases
+def _random_full_tree(N, levels, K, seed=0):
+    t = svox.N3Tree(N=N, data_dim=K, init_reserve=8)
+    for _ in range(levels):
+        t.refine(1)
+    leaves = t._all_leaves()
+    g = torch.Generator().manual_seed(seed)
+    occupied = torch.rand(len(leaves), generator=g) < 0.35
+    M = int(occupied.sum())
+    idx = torch.full((len(leaves),), synth.EMPTY_SENTINEL, dtype=torch.int32)
+    idx[occupied] = torch.arange(M, dtype=torch.int32)
+    t.data[tuple(leaves.T)] = idx[:, None]
+    feats = synth.shell_features(M, K, seed=seed)
+    return t, feats
+
+
+@pytest.mark.parametrize("N,levels", [(3, 2), (4, 2)])
+def test_branching_factor_other_than_two(gpu, N, levels):
+    t, feats = _random_full_tree(N, levels, 4)
+    ot = O.Tree(feats.numpy(), t.data[:t.n_internal].numpy(), t.child[:t.n_internal].numpy())
+    o, d, v = synth.pinhole_rays(48, 48)
+    opt = O.make_options()
+    tg = t.to(gpu)
+    r = svox.VolumeRenderer(tg)
+    f = feats.to(gpu).requires_grad_(True)
+    out = r(f, svox.Rays(o.to(gpu), d.to(gpu), v.to(gpu)))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O.volume_render(ot, o.numpy(), d.numpy(), v.numpy(), opt))
+    gout = synth.grad_output(o.shape[0], 4)
+    out.backward(gout.to(gpu))
+    want, absum = O.volume_render_backward(ot, o.numpy(), d.numpy(), v.numpy(), opt, gout.numpy(), want_abs=True)
+    assert_grads_close(f.grad.cpu().numpy(), want, absum)
+
+
+def test_component_subrange_and_sg_format(gpu):
+    c = Case(depth=4, K=28, data_format="SH9", width=40, height=40)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree, min_comp=1, max_comp=5)
+    with torch.no_grad():
+        got = r(tree.features, c.rays_gpu(gpu)).cpu().numpy()
+    want = O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts(min_comp=1, max_comp=5))
+    np.testing.assert_array_equal(got, want)
+    # spherical gaussians: basis from extra_data rows (lambda, mu_xyz)
+    g = torch.Generator().manual_seed(4)
+    lobes = torch.cat([torch.rand(6, 1, generator=g) * 4 + 0.5,
+                       torch.nn.functional.normalize(torch.randn(6, 3, generator=g), dim=-1)], -1)
+    cs = Case(depth=4, K=19, data_format="SG6", width=40, height=40)
+    t = svox.N3Tree.from_arrays(cs.st.child, cs.st.data, cs.st.parent_depth, cs.features,
+                                data_format="SG6", extra_data=lobes, device=gpu)
+    rs = svox.VolumeRenderer(t)
+    f = t.features
+    out = rs(f, cs.rays_gpu(gpu))
+    ot = O.Tree(cs.features.numpy(), cs.st.data, cs.st.child, extra=lobes.numpy())
+    opt = O.make_options(format=O.FORMAT_SG, basis_dim=6)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O.volume_render(ot, *cs.rays_np(), opt))
+    gout = synth.grad_output(cs.Q, 4)
+    out.backward(gout.to(gpu))
+    want, absum = O.volume_render_backward(ot, *cs.rays_np(), opt, gout.numpy(), want_abs=True)
+    assert_grads_close(f.grad.cpu().numpy(), want, absum)
+
+
+@pytest.mark.parametrize("Q", [0, 1, 63, 257])
+def test_ragged_and_empty_ray_batches(gpu, Q):
+    c = Case(depth=4, K=4, data_format="RGBA", width=32, height=32)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    rays = svox.Rays(*(t[:Q].to(gpu) for t in (c.origins, c.dirs, c.vdirs)))
+    out = r(tree.features, rays)
+    assert out.shape == (Q, 4)
+    o, d, v = (a[:Q] for a in c.rays_np())
+    if Q:
+        np.testing.assert_array_equal(out.detach().cpu().numpy(), O.volume_render(c.oracle_tree(), o, d, v, c.oracle_opts()))
+    out.sum().backward()
+    want, absum = O.volume_render_backward(c.oracle_tree(), o, d, v, c.oracle_opts(),
+                                           np.ones((Q, 4), np.float32), want_abs=True)
+    assert_grads_close(tree.features.grad.cpu().numpy(), want, absum)
+
+
+def test_rejects_noncontiguous_and_wrong_dtype(gpu):
+    c = Case(depth=3, K=4, data_format="RGBA", width=8, height=8)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    rays = c.rays_gpu(gpu)
+    bad = svox.Rays(rays.origins.t().contiguous().t(), rays.dirs, rays.viewdirs)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        r(tree.features, bad)
+    with pytest.raises(RuntimeError, match="float"):
+        r(tree.features, svox.Rays(rays.origins.double(), rays.dirs.double(), rays.viewdirs.double()))
+    with pytest.raises(RuntimeError, match="unsupported|not supported"):
+        r(tree.features, rays, transformation_matrices=torch.eye(3, device=gpu).repeat(tree.features.shape[0], 1, 1))
+
+
+def test_weight_accumulation(gpu):
+    """Sum over leaf slots of the accumulated weights == sum over rays of alpha
+    (every composited weight lands in exactly one slot)."""
+    c = Case(depth=5, K=4, data_format="RGBA", width=64, height=64)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    with torch.no_grad(), tree.accumulate_weights() as acc:
+        out = r(tree.features, c.rays_gpu(gpu))
+        w = acc.value.clone()
+        per_leaf = acc()
+    assert w.shape == tree.child.shape and per_leaf.shape[0] == tree.n_leaves
+    total_alpha = out[:, 3].double().sum().item()
+    assert w.double().sum().item() == pytest.approx(total_alpha, rel=1e-4)
+    assert (w[tree.child != 0] == 0).all()              # internal slots never receive weight
+    # occupied slots only
+    empty = (tree.data.squeeze(-1) >= tree.features.shape[0])
+    assert (w[empty] == 0).all()
+
+
+# ------------------------------------------------------------ full-size configs
+@pytest.fixture(scope="module")
+def cfg3():
+    """BASELINE configs[1]/[2]: depth-8 SH9 tree, 800x800 rays."""
+    return Case(depth=8, K=28, data_format="SH9", width=800, height=800)
+
+
+def test_config2_forward_full_size(cfg3, gpu):
+    c = cfg3
+    assert (c.st.n_internal, c.st.n_features) == (123841, 668912)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    with torch.no_grad():
+        got = r(tree.features, c.rays_gpu(gpu)).cpu().numpy()
+    want, cnt = O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), count=True)
+    assert_outputs_close(got, want)
+    np.testing.assert_array_equal(got, want)
+    got_cnt = _C.count_forward(tree._spec(tree.features), _rays_spec_from_rays(c.rays_gpu(gpu)),
+                               r._get_options()).cpu().tolist()
+    assert tuple(got_cnt) == tuple(cnt) == (610128, 18919396, 113601892, 6545320, 5886409)
+    # size-independent properties
+    assert got[:, 3].min() >= 0 and got[:, 3].max() <= 1
+    miss = got[:, 3] == 0
+    assert np.all(got[miss, :3] == 1.0)                 # untouched rays show the white background
+
+
+def test_config3_backward_full_size(cfg3, gpu):
+    c = cfg3
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    out = r(tree.features, c.rays_gpu(gpu))
+    gout = synth.grad_output(c.Q, 4)
+    out.backward(gout.to(gpu))
+    got = tree.features.grad.cpu().numpy()
+    want, absum = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), gout.numpy(), want_abs=True)
+    assert_grads_close(got, want, absum)
+    # linearity in the upstream gradient: backward(2g) == 2 backward(g) up to atomics order
+    tree.features.grad = None
+    out2 = r(tree.features, c.rays_gpu(gpu))
+    out2.backward(2 * gout.to(gpu))
+    assert_grads_close(tree.features.grad.cpu().numpy(), 2 * want, 2 * absum)
+
+
+def test_config4_depth9_features32_and_depth(gpu):
+    """BASELINE configs[3]: depth-9, data_dim 32 (31 features + sigma), 1024x1024:
+    volume_render [Q,32] and render_depth [Q,1]; checked against the oracle on a
+    deterministic subsample of the rays (the full batch is rendered)."""
+    c = Case(depth=9, K=32, data_format="RGBA", width=1024, height=1024)
+    assert (c.st.n_internal, c.st.n_features) == (792753, 4738568)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    rays = c.rays_gpu(gpu)
+    with torch.no_grad():
+        out = r(tree.features, rays)
+        depth = r.render_depth(tree.features, rays)
+    assert out.shape == (c.Q, 32) and depth.shape == (c.Q, 1)
+    sel = np.random.default_rng(0).choice(c.Q, size=60000, replace=False)
+    o, d, v = (a[sel] for a in c.rays_np())
+    ot = c.oracle_tree()
+    np.testing.assert_array_equal(out[sel].cpu().numpy(), O.volume_render(ot, o, d, v, c.oracle_opts()))
+    np.testing.assert_array_equal(depth[sel].cpu().numpy(), O.render_depth(ot, o, d, v, c.oracle_opts()))
+    # depth is 0 exactly where nothing was hit, else inside the cube's extent
+    dn, an = depth.cpu().numpy()[:, 0], out[:, 31].cpu().numpy()
+    assert np.all((dn == 0) == (an == 0))
+    assert dn.max() < 1.6 + 0.9
