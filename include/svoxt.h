@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 1
+#define SVOXT_ABI_VERSION 2
 
 enum {
     SVOXT_OK = 0,
@@ -74,6 +74,10 @@ typedef struct svoxt_tree {
     int32_t        extra_cols;
     float*         weight_accum; /* device [capacity * N^3] or NULL (TreeSpec._weight_accum) */
     const float*   xform;        /* TreeSpec.transformation_matrices [M,3,3]; must be NULL (unsupported) */
+    const void*    accel;        /* device, optional: acceleration grid built by svoxt_accel_build for THIS
+                                    child/data content (N == 2), or NULL.  Pure cache: results are identical
+                                    with or without it; rebuild after any change to child or data. */
+    int32_t        accel_log2;   /* log2 of the grid resolution per axis the grid was built with */
 } svoxt_tree;
 
 /* RaysSpec (data_spec.hpp:52-65) */
@@ -161,6 +165,16 @@ int svoxt_query_bwd(const svoxt_tree* tree, const float* points, int64_t Q,
  * sum(L), crossings with a valid feature index, composited samples. */
 int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
                     const svoxt_options* opt, int64_t* counters, void* stream);
+
+/* Acceleration grid (no counterpart in the reference).  A 2^g x 2^g x 2^g table
+ * that caches, per cell, where the root->leaf descent of common.cuh:63-100
+ * stands after g levels (the leaf and its data word if it ended earlier), so a
+ * march step costs one 8-byte load plus the levels below g instead of a
+ * dependent load per level.  svoxt_accel_bytes returns the buffer size for a
+ * resolution (8 bytes per cell), -1 if log2_res is outside [1, 8];
+ * svoxt_accel_build fills `cells` from tree->child / tree->data. */
+int64_t svoxt_accel_bytes(int32_t log2_res);
+int     svoxt_accel_build(const svoxt_tree* tree, int32_t log2_res, void* cells, void* stream);
 
 #ifdef __cplusplus
 }

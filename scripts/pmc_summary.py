@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/pmc_<tag>/*/.../*_counter_collection.csv: per kernel and
+counter, the mean value per dispatch."""
+import csv, glob, os, sys, collections
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.join("gpurun_out", f"pmc_{tag}")
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"]
+        short = "bwd" if "render_bwd" in k else "fwd" if "render_fwd" in k else None
+        if short is None:
+            continue
+        acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k in ("fwd", "bwd"):
+    print(f"== {k}")
+    for c, v in sorted(acc[k].items()):
+        print(f"  {c:40s} {sum(v)/len(v):18.1f}   (n={len(v)})")

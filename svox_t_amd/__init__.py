@@ -7,7 +7,7 @@ with the reference's `N3Tree` / `VolumeRenderer` / autograd surface on top.
     out = r(features, svox_t.Rays(origins, dirs, viewdirs))
 
 Importing this package loads libsvoxt_hip.so; build it first with
-`python -m svox_t_amd.build` (there is no CPU fallback).
+`python svox_t_amd/build.py` (there is no CPU fallback).
 """
 from svox_t_amd.helpers import DataFormat, LocalIndex, N3TreeView  # noqa: F401
 from svox_t_amd.svox import N3Tree  # noqa: F401

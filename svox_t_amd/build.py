@@ -1,7 +1,8 @@
 """Build libsvoxt_hip.so (the HIP kernels + C ABI) in-tree with hipcc.
 
-Cross-compiles for gfx950 without a GPU.  Usage: ``python -m svox_t_amd.build``
-or ``svox_t_amd.build.build()``.  The library lands next to its sources in
+Cross-compiles for gfx950 without a GPU.  Usage: ``python svox_t_amd/build.py``
+(run as a script: importing the package loads the library, which is what is
+being built) or ``__graft_entry__.build()``.  The library lands next to its sources in
 ``svox_t_amd/csrc/`` (git-ignored, but shipped to the GPU box by gpurun).
 """
 from __future__ import annotations

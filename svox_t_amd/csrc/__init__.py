@@ -32,16 +32,17 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvoxt_hip.so")
+# SVOXT_LIB: load another build of the same ABI (kernel experiments); default in-tree.
+LIB_PATH = os.environ.get("SVOXT_LIB") or os.path.join(_HERE, "libsvoxt_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} not found: the HIP extension is not built. "
-        "Run `python -m svox_t_amd.build` (needs hipcc; cross-compiles for gfx950).")
+        "Run `python svox_t_amd/build.py` (needs hipcc; cross-compiles for gfx950).")
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -55,6 +56,7 @@ class _CTree(ctypes.Structure):          # struct svoxt_tree
         ("extra_data", ctypes.c_void_p),
         ("extra_rows", ctypes.c_int32), ("extra_cols", ctypes.c_int32),
         ("weight_accum", ctypes.c_void_p), ("xform", ctypes.c_void_p),
+        ("accel", ctypes.c_void_p), ("accel_log2", ctypes.c_int32),
     ]
 
 
@@ -90,6 +92,8 @@ EXPORTS = {
     "svoxt_query_fwd": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "svoxt_query_bwd": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp, _vp, _vp]),
     "svoxt_count_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
+    "svoxt_accel_bytes": (ctypes.c_int64, [_i32]),
+    "svoxt_accel_build": (ctypes.c_int, [_P(_CTree), _i32, _vp, _vp]),
 }
 for _name, (_res, _args) in EXPORTS.items():
     _fn = getattr(_lib, _name)       # AttributeError here = library/header mismatch
@@ -228,6 +232,60 @@ def _pack_tree(tree: TreeSpec) -> _CTree:
     return c
 
 
+# ---------------------------------------------------------------------------
+# Acceleration grid cache.  The grid (include/svoxt.h, svoxt_accel_build) is
+# derived from the *contents* of child and data, so it is keyed on the tensors'
+# storage and torch version counters (every in-place torch op bumps them, as
+# N3Tree.refine / construct_tree do): a changed tree gets a fresh grid.
+# SVOXT_ACCEL_LOG2=0 disables it, =g forces a resolution; default: by tree size.
+# ---------------------------------------------------------------------------
+_ACCEL_CACHE: dict = {}
+_ACCEL_CACHE_MAX = 8
+
+
+def _accel_log2_for(n_internal: int, N: int) -> int:
+    env = os.environ.get("SVOXT_ACCEL_LOG2")
+    if env is not None:
+        return max(0, min(8, int(env)))
+    if N != 2 or n_internal < 64:
+        return 0
+    slots = n_internal * 8
+    # about one cell per two leaf slots, between 16^3 and 128^3 cells
+    g = int(round((slots.bit_length() - 1) / 3.0))
+    return max(4, min(7, g))
+
+
+def _accel_for(tree: TreeSpec, ct: _CTree):
+    g = _accel_log2_for(ct.n_internal, ct.N)
+    if g == 0 or ct.N != 2:
+        return None, 0
+    key = (tree.child.data_ptr(), tree.child._version, tree.data.data_ptr(), tree.data._version,
+           ct.n_internal, tree.child.device.index, g)
+    hit = _ACCEL_CACHE.get(key)
+    if hit is not None:
+        return hit, g
+    dev = tree.child.device
+    with torch.cuda.device(dev):
+        cells = torch.empty((1 << (3 * g), 2), dtype=torch.int32, device=dev)
+        assert cells.numel() * 4 == _lib.svoxt_accel_bytes(g)
+        _call("svoxt_accel_build", ctypes.byref(ct), g, _ptr(cells), _stream(dev))
+    if len(_ACCEL_CACHE) >= _ACCEL_CACHE_MAX:
+        _ACCEL_CACHE.pop(next(iter(_ACCEL_CACHE)))
+    _ACCEL_CACHE[key] = cells
+    return cells, g
+
+
+def _pack_tree_accel(tree: TreeSpec) -> _CTree:
+    """_pack_tree + the (cached) acceleration grid for the marching kernels."""
+    ct = _pack_tree(tree)
+    cells, g = _accel_for(tree, ct)
+    if cells is not None:
+        ct.accel = cells.data_ptr()
+        ct.accel_log2 = g
+        ct._keepalive = cells
+    return ct
+
+
 def _pack_rays(rays: RaysSpec) -> _CRays:
     """RaysSpec.check() (data_spec.hpp:57-64)."""
     for nm in ("origins", "dirs", "vdirs"):
@@ -280,7 +338,7 @@ def get_out_data_dim(opt: RenderOptions, K: int) -> int:
 
 def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
     """rt_kernel.cu:1362-1379."""
-    ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
+    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
     with torch.cuda.device(dev):
         out = torch.empty((cr.Q, get_out_data_dim(opt, ct.K)), dtype=torch.float32, device=dev)
@@ -293,7 +351,7 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
                            grad_output: torch.Tensor, fwd_output: torch.Tensor = None) -> torch.Tensor:
     """rt_kernel.cu:1402-1426.  `fwd_output` (optional, not in the reference
     signature) lets the library skip one of the two backward marches."""
-    ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
+    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     _check_input(grad_output, "grad_output")
     if grad_output.dtype != torch.float32 or grad_output.dim() != 2 or grad_output.shape[0] != cr.Q:
         raise RuntimeError("grad_output must be float32 [Q, C+1]")
@@ -311,7 +369,7 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
 
 def render_depth(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
     """rt_kernel.cu:1506-1523."""
-    ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
+    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
     with torch.cuda.device(dev):
         depth = torch.empty((cr.Q, 1), dtype=torch.float32, device=dev)
@@ -322,7 +380,7 @@ def render_depth(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Te
 
 def opacity_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
     """rt_kernel.cu:1574-1591."""
-    ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
+    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
     with torch.cuda.device(dev):
         out = torch.empty((cr.Q, 1), dtype=torch.float32, device=dev)
@@ -334,7 +392,7 @@ def opacity_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.
 def opacity_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
                             grad_output: torch.Tensor) -> torch.Tensor:
     """rt_kernel.cu:1593-1616."""
-    ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
+    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     _check_input(grad_output, "grad_output")
     if grad_output.dtype != torch.float32 or grad_output.numel() != cr.Q:
         raise RuntimeError("grad_output must be float32 [Q, 1]")

@@ -37,6 +37,11 @@ struct TreeDev {
     int extra_rows;
     int extra_cols;
     float* weight_accum;
+    // optional acceleration grid (N == 2 only): 2^G cells per axis, one uint2 per
+    // cell, see locate_accel().  Derived data: a cache of what a root descent
+    // of `child` / `data` would find, never a different answer.
+    const uint2* __restrict__ accel;
+    int accel_g;
 };
 
 struct RaysDev {
@@ -196,6 +201,64 @@ __device__ __forceinline__ void locate(const TreeDev& tr, float px, float py, fl
     }
 }
 
+// Acceleration grid.  Cell (cx,cy,cz) of the 2^G grid caches the state of the
+// root descent after (at most) G levels for any point inside the cell:
+//   .y bit 31 set : the descent ended in a leaf at depth (.y & 0xff) <= G whose
+//                   data word (feature row index) is .x
+//   .y bit 31 clear: the descent is at internal node .x after G levels
+// Built by accel_build_kernel from child/data; the march then needs one 8-byte
+// load instead of up to G dependent 4-byte loads (plus the data word) per step.
+constexpr uint32_t kAccelLeaf = 0x80000000u;
+
+__device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float py, float pz,
+                                             Leaf& lf, int32_t& idx) {
+    px = fmaxf(0.f, fminf(kClampHi, px));
+    py = fmaxf(0.f, fminf(kClampHi, py));
+    pz = fmaxf(0.f, fminf(kClampHi, pz));
+    const float S = (float)(1 << kFixBits);
+    const uint32_t ux = (uint32_t)(px * S);
+    const uint32_t uy = (uint32_t)(py * S);
+    const uint32_t uz = (uint32_t)(pz * S);
+    const int G = tr.accel_g;
+    const int gs = kFixBits - G;
+    const uint32_t ci = ((((ux >> gs) << G) + (uy >> gs)) << G) + (uz >> gs);
+    const uint2 cell = tr.accel[ci];
+    int k;
+    uint32_t slot = 0xffffffffu;
+    if (cell.y & kAccelLeaf) {
+        k = (int)(cell.y & 0xffu);
+        idx = (int32_t)cell.x;
+    } else {
+        int32_t node = (int32_t)cell.x;
+        int32_t skip;
+        k = G + 1;
+#pragma unroll 1
+        for (;; ++k) {
+            const int sh = kFixBits - k;
+            const uint32_t c3 = (((ux >> sh) & 1u) << 2) | (((uy >> sh) & 1u) << 1) | ((uz >> sh) & 1u);
+            slot = ((uint32_t)node << 3) + c3;
+            skip = tr.child[slot];
+            if (skip == 0 || k == kFixBits) break;
+            node += skip;
+        }
+        if (skip != 0) {   // deeper than the fixed-point path resolves: generic float descent
+            const float sc = __int_as_float((127 + k) << 23);
+            const float fx = px * sc, fy = py * sc, fz = pz * sc;
+            descend_generic(tr, node + skip, fx - floorf(fx), fy - floorf(fy), fz - floorf(fz),
+                            sc * 2.f, k, lf);
+            idx = tr.data[lf.slot];
+            return;
+        }
+        idx = tr.data[slot];
+    }
+    const float sc = __int_as_float((127 + k) << 23);   // 2^k
+    const float fx = px * sc, fy = py * sc, fz = pz * sc;
+    lf.slot = slot;
+    lf.lx = fx - floorf(fx); lf.ly = fy - floorf(fy); lf.lz = fz - floorf(fz);
+    lf.cube_sz = sc;
+    lf.levels = k;
+}
+
 struct Sample {
     Leaf leaf;
     int32_t idx;       // feature row, valid iff (int64)idx < M (negative = empty too? no: see below)
@@ -210,8 +273,12 @@ __device__ __forceinline__ void march_step(const TreeDev& tr, const Ray& r, floa
     const float px = r.ox + t * r.dx;
     const float py = r.oy + t * r.dy;
     const float pz = r.oz + t * r.dz;
-    locate<N2>(tr, px, py, pz, s.leaf);
-    s.idx = tr.data[s.leaf.slot];
+    if (N2 && tr.accel != nullptr) {
+        locate_accel(tr, px, py, pz, s.leaf, s.idx);   // leaf.slot / leaf.levels are not reference-accurate here
+    } else {
+        locate<N2>(tr, px, py, pz, s.leaf);
+        s.idx = tr.data[s.leaf.slot];
+    }
     // `*data_idx_ptr >= features.size(0)` compares int32 with int64 (:269); a
     // negative index is therefore "valid" for the reference (and reads out of
     // bounds).  Treat it as empty instead of faulting.

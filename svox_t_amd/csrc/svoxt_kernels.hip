@@ -61,10 +61,10 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) {
         march_step<N2>(tr, r, opt.step_size, t, s);
         if (s.valid) {
             const float* rowp = tr.features + (int64_t)s.idx * K;
-            const float sigma = rowp[K - 1];
+            float row[K];
+            load_row<K>(rowp, row);   // whole row at once: sigma is its last element
+            const float sigma = row[K - 1];
             if (sigma > opt.sigma_thresh) {
-                float row[K];
-                load_row<K>(rowp, row);
                 const float att = pexpf(-s.delta_t * r.delta_scale * sigma);
                 const float weight = light * (1.f - att);
                 if constexpr (FMT == FMT_SH) {
@@ -222,10 +222,10 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             march_step<N2>(tr, r, opt.step_size, t, s);
             if (s.valid) {
                 const float* rowp = tr.features + (int64_t)s.idx * K;
-                const float sigma = rowp[K - 1];
+                float row[K];
+                load_row<K>(rowp, row);   // whole row at once: sigma is its last element
+                const float sigma = row[K - 1];
                 if (sigma > 0.f) {
-                    float row[K];
-                    load_row<K>(rowp, row);
                     const float att = pexpf(-s.delta_t * sigma * r.delta_scale);
                     const float weight = light * (1.f - att);
                     float total_color = 0.f;
@@ -266,12 +266,12 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             march_step<N2>(tr, r, opt.step_size, t, s);
             if (s.valid) {
                 const float* rowp = tr.features + (int64_t)s.idx * K;
-                const float sigma = rowp[K - 1];
+                float row[K];
+                load_row<K>(rowp, row);   // whole row at once: sigma is its last element
+                const float sigma = row[K - 1];
                 if (sigma > 0.f) {
                     active = true;
                     idx = s.idx;
-                    float row[K];
-                    load_row<K>(rowp, row);
                     const float att = pexpf(-s.delta_t * sigma * r.delta_scale);
                     const float weight = light * (1.f - att);
                     float* st = stage + lane * KS;
@@ -598,6 +598,31 @@ query_bwd_kernel(TreeDev tr, const float* __restrict__ points, int64_t Q,
     for (int i = 0; i < K; ++i) atomicAdd(grad + (int64_t)idx * K + i, grad_out[q * K + i]);
 }
 
+// ---------------------------------------------------------------------------
+// Acceleration grid build (N == 2): one thread per cell, see locate_accel()
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(kBlock)
+accel_build_kernel(TreeDev tr, int G, uint2* __restrict__ cells) {
+    const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= (1u << (3 * G))) return;
+    const uint32_t mask = (1u << G) - 1u;
+    const uint32_t cz = c & mask, cy = (c >> G) & mask, cx = c >> (2 * G);
+    int32_t node = 0;
+    for (int k = 1; k <= G; ++k) {
+        const int sh = G - k;
+        const uint32_t c3 = (((cx >> sh) & 1u) << 2) | (((cy >> sh) & 1u) << 1) | ((cz >> sh) & 1u);
+        const uint32_t slot = ((uint32_t)node << 3) + c3;
+        const int32_t skip = tr.child[slot];
+        if (skip == 0) {
+            cells[c] = make_uint2((uint32_t)tr.data[slot], kAccelLeaf | (uint32_t)k);
+            return;
+        }
+        node += skip;
+    }
+    cells[c] = make_uint2((uint32_t)node, 0u);
+}
+
 }  // namespace svoxt
 
 // ===========================================================================
@@ -633,6 +658,8 @@ int check_tree(const svoxt_tree* t, const char* fn) {
         return fail(SVOXT_ERR_INVALID, "%s: tree too large for 32-bit slot indices", fn);
     if (t->xform != nullptr)
         return fail(SVOXT_ERR_UNSUPPORTED, "%s: transformation_matrices are not supported", fn);
+    if (t->accel != nullptr && (t->accel_log2 < 1 || t->accel_log2 > 8))
+        return fail(SVOXT_ERR_INVALID, "%s: accel_log2 must be in [1, 8]", fn);
     return SVOXT_OK;
 }
 
@@ -671,6 +698,10 @@ TreeDev to_dev(const svoxt_tree* t) {
     d.data = t->data; d.child = t->child; d.offset = t->offset; d.scaling = t->scaling;
     d.extra = t->extra_data; d.extra_rows = t->extra_rows; d.extra_cols = t->extra_cols;
     d.weight_accum = t->weight_accum;
+    // the grid caches data words but not slot ids: per-slot weight accumulation takes the plain descent
+    const bool use_accel = t->accel != nullptr && t->N == 2 && t->weight_accum == nullptr;
+    d.accel = use_accel ? reinterpret_cast<const uint2*>(t->accel) : nullptr;
+    d.accel_g = use_accel ? t->accel_log2 : 0;
     return d;
 }
 
@@ -922,8 +953,30 @@ int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
     hipStream_t st = (hipStream_t)stream;
     const unsigned nb = nblocks(rays->Q);
     unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
-    if (tree->N == 2) hipLaunchKernelGGL((count_fwd_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), c);
-    else hipLaunchKernelGGL((count_fwd_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), c);
+    TreeDev tr = to_dev(tree);
+    tr.accel = nullptr;   // the counters are the reference's: levels of the plain root descent
+    if (tree->N == 2) hipLaunchKernelGGL((count_fwd_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, to_dev(rays), to_dev(opt), c);
+    else hipLaunchKernelGGL((count_fwd_kernel<false>), dim3(nb), dim3(kBlock), 0, st, tr, to_dev(rays), to_dev(opt), c);
+    return check_launch(fn);
+}
+
+int64_t svoxt_accel_bytes(int32_t log2_res) {
+    if (log2_res < 1 || log2_res > 8) return -1;
+    return (int64_t)sizeof(uint2) << (3 * log2_res);
+}
+
+int svoxt_accel_build(const svoxt_tree* tree, int32_t log2_res, void* cells, void* stream) {
+    const char* fn = "svoxt_accel_build";
+    int rc;
+    if ((rc = check_tree(tree, fn))) return rc;
+    if (tree->N != 2) return fail(SVOXT_ERR_UNSUPPORTED, "%s: the acceleration grid exists for N == 2 only", fn);
+    if (log2_res < 1 || log2_res > 8) return fail(SVOXT_ERR_INVALID, "%s: log2_res must be in [1, 8]", fn);
+    if (cells == nullptr) return fail(SVOXT_ERR_INVALID, "%s: cells is NULL", fn);
+    TreeDev tr = to_dev(tree);
+    tr.accel = nullptr;
+    const unsigned n = 1u << (3 * log2_res);
+    hipLaunchKernelGGL(accel_build_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       (hipStream_t)stream, tr, (int)log2_res, reinterpret_cast<uint2*>(cells));
     return check_launch(fn);
 }
 

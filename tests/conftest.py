@@ -12,7 +12,10 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # Build the product library (hipcc cross-compiles without a GPU) and the
     # CPU oracle once per session; both are git-ignored artefacts.
-    from svox_t_amd import build as _build
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_svoxt_build", os.path.join(ROOT, "svox_t_amd", "build.py"))
+    _build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(_build)     # by path: importing the package loads the library
     _build.build()
     from oracle import oracle as _oracle
     _oracle.build()

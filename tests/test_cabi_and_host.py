@@ -24,18 +24,18 @@ def header_symbols():
 def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_C.LIB_PATH)
     names = header_symbols()
-    assert len(names) >= 11
+    assert len(names) >= 13
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_C.EXPORTS)          # the ctypes table and the header agree
-    assert lib.svoxt_abi_version() == 1
+    assert lib.svoxt_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     # sizes the C compiler gives the three structs (x86-64 SysV): 14 fields / 4 / 11
     assert ctypes.sizeof(_C._COptions) == 44
     assert ctypes.sizeof(_C._CRays) == 32
-    assert ctypes.sizeof(_C._CTree) == 96
+    assert ctypes.sizeof(_C._CTree) == 112
 
 
 def test_out_data_dim():
