@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 2
+#define SVOXT_ABI_VERSION 3
 
 enum {
     SVOXT_OK = 0,
@@ -115,16 +115,20 @@ int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
                             const svoxt_options* opt, float* out, void* stream);
 
 /* grad_out: device [Q, grad_cols] with grad_cols = C+1.
- * fwd_out : device [Q, C+1] = the matching forward output, or NULL.  When given
- *           (and sigma_thresh == stop_thresh == 0) the backward needs one march
- *           instead of the reference's two.
  * grad_features: device [M, K]; zeroed by this call on `stream`, then
  *           accumulated with float atomics (as the reference: zeros_like +
- *           atomicAdd, rt_kernel.cu:1415,413,486). */
+ *           atomicAdd, rt_kernel.cu:1415,413,486).
+ * workspace: device scratch of `workspace_bytes` bytes, or NULL.  With
+ *           svoxt_bwd_workspace_bytes(Q, S) bytes the first pass records up to
+ *           S composited samples per ray (8 bytes each) and the second pass
+ *           replays them instead of traversing the tree a second time; rays
+ *           with more samples than S march the remainder, so any S >= 0 gives
+ *           the same result.  Contents on return are unspecified. */
+int64_t svoxt_bwd_workspace_bytes(int64_t Q, int32_t max_samples);
 int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
                             const svoxt_options* opt, const float* grad_out,
-                            int32_t grad_cols, const float* fwd_out,
-                            float* grad_features, void* stream);
+                            int32_t grad_cols, float* grad_features,
+                            void* workspace, int64_t workspace_bytes, void* stream);
 
 /* out: device [Q, 1] = accumulated opacity (alpha). */
 int svoxt_opacity_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,

@@ -42,7 +42,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -85,7 +85,8 @@ EXPORTS = {
     "svoxt_last_error": (ctypes.c_char_p, []),
     "svoxt_out_data_dim": (ctypes.c_int, [_P(_COptions), _i32]),
     "svoxt_volume_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
-    "svoxt_volume_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _vp, _vp]),
+    "svoxt_volume_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _vp, _i64, _vp]),
+    "svoxt_bwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
     "svoxt_opacity_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
     "svoxt_opacity_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp]),
     "svoxt_render_depth": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
@@ -347,23 +348,25 @@ def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.T
     return out
 
 
+# Samples recorded per ray by the backward's first pass (8 bytes each); rays
+# with more composited samples march the remainder.  0 = always march twice.
+BWD_LIST_SAMPLES = int(os.environ.get("SVOXT_BWD_LIST", "64"))
+
+
 def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
-                           grad_output: torch.Tensor, fwd_output: torch.Tensor = None) -> torch.Tensor:
-    """rt_kernel.cu:1402-1426.  `fwd_output` (optional, not in the reference
-    signature) lets the library skip one of the two backward marches."""
+                           grad_output: torch.Tensor) -> torch.Tensor:
+    """rt_kernel.cu:1402-1426."""
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     _check_input(grad_output, "grad_output")
     if grad_output.dtype != torch.float32 or grad_output.dim() != 2 or grad_output.shape[0] != cr.Q:
         raise RuntimeError("grad_output must be float32 [Q, C+1]")
-    if fwd_output is not None:
-        _check_input(fwd_output, "fwd_output")
-        if fwd_output.shape != grad_output.shape or fwd_output.dtype != torch.float32:
-            raise RuntimeError("fwd_output must match grad_output")
     dev = tree.features.device
     with torch.cuda.device(dev):
         grad = torch.empty_like(tree.features)
+        ws_bytes = _lib.svoxt_bwd_workspace_bytes(cr.Q, BWD_LIST_SAMPLES)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
         _call("svoxt_volume_render_bwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
-              _ptr(grad_output), grad_output.shape[1], _ptr(fwd_output), _ptr(grad), _stream(dev))
+              _ptr(grad_output), grad_output.shape[1], _ptr(grad), _ptr(ws), ws_bytes, _stream(dev))
     return grad
 
 

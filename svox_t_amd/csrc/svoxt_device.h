@@ -305,11 +305,11 @@ __device__ __forceinline__ void march_step(const TreeDev& tr, const Ray& r, floa
 // reference's CUDA expf is specified to 2 ulp).  Results below 2^-126
 // (x < -87) are returned as 0, above FLT_MAX as +inf.
 __device__ __forceinline__ float pexpf(float x) {
-    if (x != x) return x;
-    if (x > 88.72283905206835f) return __int_as_float(0x7f800000);
-    if (x < -87.0f) return 0.0f;
-    const float n = rintf(x * 1.44269504088896341f);
-    float r = __builtin_fmaf(n, -0.693359375f, x);
+    // Branch-free: evaluate on a clamped argument, then select the special
+    // cases (identical results to the early-return form in oracle/).
+    const float xc = fminf(fmaxf(x, -87.0f), 88.72283905206835f);
+    const float n = rintf(xc * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, xc);
     r = __builtin_fmaf(n, 2.12194440e-4f, r);
     float p = 1.9875691500e-4f;
     p = __builtin_fmaf(p, r, 1.3981999507e-3f);
@@ -322,7 +322,10 @@ __device__ __forceinline__ float pexpf(float x) {
     const int ni = (int)n;
     const int n1 = ni >> 1, n2 = ni - n1;
     y = y * __int_as_float((n1 + 127) << 23);
-    return y * __int_as_float((n2 + 127) << 23);
+    y = y * __int_as_float((n2 + 127) << 23);
+    y = (x > 88.72283905206835f) ? __int_as_float(0x7f800000) : y;
+    y = (x < -87.0f) ? 0.0f : y;
+    return (x != x) ? x : y;
 }
 
 // SH constants, `const float` in the reference (rt_kernel.cu:54-84).

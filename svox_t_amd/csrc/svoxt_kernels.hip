@@ -163,39 +163,136 @@ render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __re
 // Backward: trace_ray_backward (rt_kernel.cu:331-496) + kernel (:675-694)
 // ---------------------------------------------------------------------------
 
-// Specialised backward.  Two marches like the reference, but arranged for
-// CDNA4's memory-side float atomics (MI355X_MICROARCH.md "Global float
-// atomics": a wave-instruction that adds one dword per lane into 64 different
-// rows runs ~17x below the rate of one that covers contiguous row segments):
+// Specialised backward, arranged for CDNA4's memory-side float atomics
+// (MI355X_MICROARCH.md "Global float atomics": a wave-instruction that adds one
+// dword per lane into 64 different rows runs ~17x below the rate of one that
+// covers contiguous row segments -- 9.8 ms for this kernel written the
+// reference's way).
 //
-//   march 1  builds `accum` and the final transmittance only -- no atomics
-//            (the reference's pass 1 also scatters the colour gradients,
-//            rt_kernel.cu:410-425; they are deferred to march 2, where the same
-//            values are recomputed from the same operands).
-//   march 2  runs wave-synchronously.  Every lane with an active sample writes
-//            its K gradient values (colour terms + sigma term) to an LDS staging
-//            row; the wave then flushes staged rows cooperatively: lanes 0..31
-//            and 32..63 each take one row per round and issue ONE atomic
-//            instruction covering two contiguous K-float segments.  Adjacent
-//            lanes that hit the same leaf (neighbouring pixels usually do) are
-//            summed in LDS first, so they cost one segment, not several.
+//   pass 1  marches the ray once (rt_kernel.cu:365-437 without the atomics):
+//           builds `accum` and the final transmittance and, when a workspace is
+//           given, records every composited sample as (feature row, delta_t)
+//           in a per-ray list rec[k][q] (up to S entries).
+//   pass 2  runs wave-synchronously over the samples.  With the list it does
+//           not traverse the tree again: it replays the recorded samples (a
+//           ray whose list overflowed continues by marching from where the
+//           list ends; without a workspace every ray marches, as in the
+//           reference's second pass, :439-494).  Every lane with a sample
+//           writes its K gradient values -- the colour terms the reference
+//           scatters in pass 1 (:410-425), recomputed from the same operands,
+//           and the sigma term (:486-490) -- to an LDS staging row; the wave
+//           then flushes the staged rows cooperatively: lanes 0..31 and 32..63
+//           each take one row per round and issue ONE atomic instruction
+//           covering two contiguous K-float segments.  Adjacent lanes that hit
+//           the same leaf (neighbouring pixels usually do) are summed in LDS
+//           first, so they cost one segment, not several.
 //
 // Per-contribution values are bit-identical to the reference formulas; only
 // the order in which floats are accumulated differs (as it does between any
 // two runs of the reference's own atomics).
-template <int FMT, int C, int BD, bool N2>
-__global__ void __launch_bounds__(kBlock)
-render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
-                  float* __restrict__ grad) {
-    constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
-    constexpr int KS = K | 1;                         // odd LDS row stride: conflict-free column writes
+
+// Colour / sigma contributions of one sample -> staging row `st`; advances the
+// ray's transmittance and the running `accum` exactly as pass 2 of the
+// reference does.
+template <int FMT, int C, int BD, int K>
+__device__ __forceinline__ void stage_sample(const float (&row)[K], const float* basis, const float* g,
+                                             float delta_t, float delta_scale, float light_ray,
+                                             float& light, float& accum, float* __restrict__ st) {
+    const float sigma = row[K - 1];
+    const float att = pexpf(-delta_t * sigma * delta_scale);
+    const float weight = light * (1.f - att);
+    float total_color = 0.f;
+    if constexpr (FMT == FMT_SH) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float tmp = 0.f;
+#pragma unroll
+            for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
+            const double sd = sigmoid_d(tmp);
+            const float sig = (float)sd;
+            const float gsig = (float)((double)sig * (1.0 - (double)sig));
+#pragma unroll
+            for (int i = 0; i < BD; ++i) st[c * BD + i] = weight * basis[i] * gsig * g[c];
+            total_color = (float)((double)total_color + sd * (double)g[c]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const double sd = sigmoid_d(row[j]);
+            const float sig = (float)sd;
+            st[j] = weight * sig * (1.f - sig) * g[j];
+            total_color = (float)((double)total_color + sd * (double)g[j]);
+        }
+    }
+    light *= att;
+    accum -= weight * total_color;
+    st[K - 1] = delta_t * delta_scale * (total_color * light - accum)
+              + delta_t * delta_scale * g[C] * light_ray;
+}
+
+// Cooperative flush of the rows staged by the lanes in `active` (row of lane l
+// at stage[l*KS], destined for feature row `idx`).
+template <int K, int KS>
+__device__ __forceinline__ void flush_staged(const float* __restrict__ stage, bool active, int32_t idx,
+                                             int lane, float* __restrict__ grad) {
     constexpr int ROWS = (K <= 32) ? 2 : 1;           // staged rows flushed per atomic instruction
     constexpr int LPR = 64 / ROWS;                    // lanes per row
     constexpr int CHUNKS = (K + LPR - 1) / LPR;       // instructions per row (K > 64 only)
+    const unsigned long long amask = __ballot(active);
+    if (amask == 0ull) return;
+    const int32_t prev_idx = __shfl_up(idx, 1, 64);
+    const bool leader = active && !(lane > 0 && ((amask >> (lane - 1)) & 1ull) && prev_idx == idx);
+    unsigned long long lmask = __ballot(leader);
+    const unsigned long long follow = amask & ~lmask;   // lanes merged into the run on their left
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int half = (ROWS == 2) ? (lane >> 5) : 0;
+    const int j = (ROWS == 2) ? (lane & 31) : lane;
+    while (lmask != 0ull) {
+        // leaders of this round: La for rows handled by lanes 0..LPR-1, Lb for the upper half
+        const int La = __ffsll((long long)lmask) - 1;
+        lmask &= lmask - 1;
+        int Lb = -1;
+        if (ROWS == 2 && lmask != 0ull) {
+            Lb = __ffsll((long long)lmask) - 1;
+            lmask &= lmask - 1;
+        }
+        // La / Lb are wave-uniform: read the leaders' row indices with readlane
+        // *outside* the per-half branch (a cross-lane read from a lane that is
+        // masked off must not be relied upon).
+        const int32_t idxA = __builtin_amdgcn_readlane(idx, __builtin_amdgcn_readfirstlane(La));
+        const int32_t idxB = __builtin_amdgcn_readlane(idx, __builtin_amdgcn_readfirstlane(Lb < 0 ? 0 : Lb));
+        const int L = half ? Lb : La;
+        if (L >= 0) {
+            // run = leader + the followers immediately to its right
+            const unsigned long long rest = (L == 63) ? 0ull : (follow >> (L + 1));
+            const int len = 1 + (rest == ~0ull ? 64 : __ffsll((long long)~rest) - 1);
+            const int32_t ridx = half ? idxB : idxA;
+#pragma unroll
+            for (int ch = 0; ch < CHUNKS; ++ch) {
+                const int col = j + ch * LPR;
+                if (col < K) {
+                    float sum = 0.f;
+                    for (int i = 0; i < len; ++i) sum += stage[(L + i) * KS + col];
+                    atomicAdd(grad + (int64_t)ridx * K + col, sum);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int FMT, int C, int BD, bool N2>
+__global__ void __launch_bounds__(kBlock)
+render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
+                  float* __restrict__ grad, uint2* __restrict__ rec, int S) {
+    constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
+    constexpr int KS = K | 1;                         // odd LDS row stride: conflict-free column writes
     __shared__ float stage_all[(kBlock / 64) * 64 * KS];
 
     const int lane = threadIdx.x & 63;
     float* stage = stage_all + (threadIdx.x >> 6) * (64 * KS);
+    float* st = stage + lane * KS;
     const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     Ray r;
     bool alive = q < rays.Q;
@@ -215,8 +312,13 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 
     float accum = 0.f;
     float light_ray = 1.f;
-    if (alive) {   // march 1 (rt_kernel.cu:365-437 minus the atomics)
+    int nrec = 0;                 // samples recorded for this ray
+    float t_resume = 0.f;         // where pass 2 resumes marching
+    float tmax2 = -1.f;           // ... and until where (-1: nothing left to march)
+    if (alive) {   // pass 1
         float light = 1.f, t = r.tmin;
+        t_resume = r.tmin;
+        tmax2 = (S > 0) ? -1.f : r.tmax;
         while (t < r.tmax) {
             Sample s;
             march_step<N2>(tr, r, opt.step_size, t, s);
@@ -226,6 +328,15 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 load_row<K>(rowp, row);   // whole row at once: sigma is its last element
                 const float sigma = row[K - 1];
                 if (sigma > 0.f) {
+                    if (S > 0) {
+                        if (nrec < S) {
+                            rec[(int64_t)nrec * rays.Q + q] = make_uint2((uint32_t)s.idx, __float_as_uint(s.delta_t));
+                            ++nrec;
+                        } else if (tmax2 < 0.f) {   // list full: pass 2 marches from this step on
+                            t_resume = t;
+                            tmax2 = r.tmax;
+                        }
+                    }
                     const float att = pexpf(-s.delta_t * sigma * r.delta_scale);
                     const float weight = light * (1.f - att);
                     float total_color = 0.f;
@@ -254,102 +365,39 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         light_ray = light;
     }
 
-    // march 2 (rt_kernel.cu:439-494 plus the deferred colour terms), wave-synchronous
+    // pass 2, wave-synchronous: replay the recorded samples, then (rays with
+    // unrecorded samples only) march the rest.
     float light = 1.f;
-    float t = alive ? r.tmin : 0.f;
-    const float tmax = alive ? r.tmax : -1.f;
-    while (__any(t < tmax)) {
+    int k = 0;
+    float t = t_resume;
+    while (__any(k < nrec || t < tmax2)) {
         bool active = false;
         int32_t idx = -1;
-        if (t < tmax) {
+        if (k < nrec) {
+            const uint2 e = rec[(int64_t)k * rays.Q + q];
+            ++k;
+            idx = (int32_t)e.x;
+            float row[K];
+            load_row<K>(tr.features + (int64_t)idx * K, row);
+            active = true;
+            stage_sample<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, light_ray,
+                                        light, accum, st);
+        } else if (t < tmax2) {
             Sample s;
             march_step<N2>(tr, r, opt.step_size, t, s);
             if (s.valid) {
-                const float* rowp = tr.features + (int64_t)s.idx * K;
                 float row[K];
-                load_row<K>(rowp, row);   // whole row at once: sigma is its last element
-                const float sigma = row[K - 1];
-                if (sigma > 0.f) {
+                load_row<K>(tr.features + (int64_t)s.idx * K, row);
+                if (row[K - 1] > 0.f) {
                     active = true;
                     idx = s.idx;
-                    const float att = pexpf(-s.delta_t * sigma * r.delta_scale);
-                    const float weight = light * (1.f - att);
-                    float* st = stage + lane * KS;
-                    float total_color = 0.f;
-                    if constexpr (FMT == FMT_SH) {
-#pragma unroll
-                        for (int c = 0; c < C; ++c) {
-                            float tmp = 0.f;
-#pragma unroll
-                            for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
-                            const double sd = sigmoid_d(tmp);
-                            const float sig = (float)sd;
-                            const float gsig = (float)((double)sig * (1.0 - (double)sig));
-#pragma unroll
-                            for (int i = 0; i < BD; ++i) st[c * BD + i] = weight * basis[i] * gsig * g[c];
-                            total_color = (float)((double)total_color + sd * (double)g[c]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < C; ++j) {
-                            const double sd = sigmoid_d(row[j]);
-                            const float sig = (float)sd;
-                            st[j] = weight * sig * (1.f - sig) * g[j];
-                            total_color = (float)((double)total_color + sd * (double)g[j]);
-                        }
-                    }
-                    light *= att;
-                    accum -= weight * total_color;
-                    st[K - 1] = s.delta_t * r.delta_scale * (total_color * light - accum)
-                              + s.delta_t * r.delta_scale * g[C] * light_ray;
+                    stage_sample<FMT, C, BD, K>(row, basis, g, s.delta_t, r.delta_scale, light_ray,
+                                                light, accum, st);
                 }
             }
             t += s.delta_t;
         }
-        // ---- cooperative flush of this iteration's staged rows ----
-        const unsigned long long amask = __ballot(active);
-        if (amask != 0ull) {
-            const int32_t prev_idx = __shfl_up(idx, 1, 64);
-            const bool leader = active && !(lane > 0 && ((amask >> (lane - 1)) & 1ull) && prev_idx == idx);
-            unsigned long long lmask = __ballot(leader);
-            const unsigned long long follow = amask & ~lmask;   // lanes merged into the run on their left
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int half = (ROWS == 2) ? (lane >> 5) : 0;
-            const int j = (ROWS == 2) ? (lane & 31) : lane;
-            while (lmask != 0ull) {
-                // leaders of this round: La for rows handled by lanes 0..LPR-1, Lb for the upper half
-                const int La = __ffsll((long long)lmask) - 1;
-                lmask &= lmask - 1;
-                int Lb = -1;
-                if (ROWS == 2 && lmask != 0ull) {
-                    Lb = __ffsll((long long)lmask) - 1;
-                    lmask &= lmask - 1;
-                }
-                // La / Lb are wave-uniform: read the leaders' row indices with
-                // readlane *outside* the per-half branch (a cross-lane read
-                // from a lane that is masked off must not be relied upon).
-                const int32_t idxA = __builtin_amdgcn_readlane(idx, __builtin_amdgcn_readfirstlane(La));
-                const int32_t idxB = __builtin_amdgcn_readlane(idx, __builtin_amdgcn_readfirstlane(Lb < 0 ? 0 : Lb));
-                const int L = half ? Lb : La;
-                if (L >= 0) {
-                    // run = leader + the followers immediately to its right
-                    const unsigned long long rest = (L == 63) ? 0ull : (follow >> (L + 1));
-                    const int len = 1 + (rest == ~0ull ? 64 : __ffsll((long long)~rest) - 1);
-                    const int32_t ridx = half ? idxB : idxA;
-#pragma unroll
-                    for (int ch = 0; ch < CHUNKS; ++ch) {
-                        const int col = j + ch * LPR;
-                        if (col < K) {
-                            float sum = 0.f;
-                            for (int i = 0; i < len; ++i) sum += stage[(L + i) * KS + col];
-                            atomicAdd(grad + (int64_t)ridx * K + col, sum);
-                        }
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+        flush_staged<K, KS>(stage, active, idx, lane, grad);
     }
 }
 
@@ -753,11 +801,11 @@ bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
 
 template <bool N2>
 bool launch_bwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
-                        const float* grad_out, float* grad, hipStream_t st) {
+                        const float* grad_out, float* grad, uint2* rec, int S, hipStream_t st) {
     const unsigned nb = nblocks(rays.Q);
 #define SVOXT_BWD(F, CC, BB)                                                              \
     hipLaunchKernelGGL((render_bwd_kernel<F, CC, BB, N2>), dim3(nb), dim3(kBlock), 0, st, \
-                       tr, rays, opt, grad_out, grad);                                    \
+                       tr, rays, opt, grad_out, grad, rec, S);                            \
     return true;
     if (opt.format == FMT_RGBA) {
         if (C == 3) { SVOXT_BWD(FMT_RGBA, 3, 0) }
@@ -776,8 +824,8 @@ bool launch_bwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
 }
 
 int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
-               const float* grad_out, int32_t grad_cols, float* grad_features, void* stream,
-               const char* fn) {
+               const float* grad_out, int32_t grad_cols, float* grad_features,
+               void* workspace, int64_t workspace_bytes, void* stream, const char* fn) {
     int rc;
     if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) ||
         (rc = check_opts(opt, tree, fn, grad_cols > 1)))
@@ -802,8 +850,14 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
     const bool n2 = tree->N == 2;
     bool done = false;
     if (C > 0 && full_comp(opt))
-        done = n2 ? launch_bwd_special<true>(tr, rd, od, C, grad_out, grad_features, st)
-                  : launch_bwd_special<false>(tr, rd, od, C, grad_out, grad_features, st);
+    {
+        // per-ray sample lists: S entries of 8 bytes per ray, laid out rec[k][q]
+        int64_t S = (workspace != nullptr && workspace_bytes > 0) ? workspace_bytes / (8 * rays->Q) : 0;
+        if (S > 4096) S = 4096;
+        uint2* rec = S > 0 ? reinterpret_cast<uint2*>(workspace) : nullptr;
+        done = n2 ? launch_bwd_special<true>(tr, rd, od, C, grad_out, grad_features, rec, (int)S, st)
+                  : launch_bwd_special<false>(tr, rd, od, C, grad_out, grad_features, rec, (int)S, st);
+    }
     if (!done) {
         const unsigned nb = nblocks(rays->Q);
         if (n2) hipLaunchKernelGGL((render_bwd_generic_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, grad_out, grad_features);
@@ -860,13 +914,14 @@ int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
 
 int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
                             const svoxt_options* opt, const float* grad_out,
-                            int32_t grad_cols, const float* fwd_out,
-                            float* grad_features, void* stream) {
-    (void)fwd_out;  // single-march backward not implemented yet: the two-march path needs no forward output
+                            int32_t grad_cols, float* grad_features,
+                            void* workspace, int64_t workspace_bytes, void* stream) {
     if (grad_cols < 2)
         return fail(SVOXT_ERR_INVALID, "%s: grad_cols must be C+1 >= 2 (use svoxt_opacity_render_bwd for C = 0)",
                     "svoxt_volume_render_bwd");
-    return bwd_common(tree, rays, opt, grad_out, grad_cols, grad_features, stream, "svoxt_volume_render_bwd");
+    if (workspace_bytes < 0) return fail(SVOXT_ERR_INVALID, "%s: negative workspace size", "svoxt_volume_render_bwd");
+    return bwd_common(tree, rays, opt, grad_out, grad_cols, grad_features, workspace, workspace_bytes, stream,
+                      "svoxt_volume_render_bwd");
 }
 
 int svoxt_opacity_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
@@ -887,7 +942,7 @@ int svoxt_opacity_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
 int svoxt_opacity_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
                              const svoxt_options* opt, const float* grad_out,
                              float* grad_features, void* stream) {
-    return bwd_common(tree, rays, opt, grad_out, 1, grad_features, stream, "svoxt_opacity_render_bwd");
+    return bwd_common(tree, rays, opt, grad_out, 1, grad_features, nullptr, 0, stream, "svoxt_opacity_render_bwd");
 }
 
 int svoxt_render_depth(const svoxt_tree* tree, const svoxt_rays* rays,
@@ -958,6 +1013,11 @@ int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
     if (tree->N == 2) hipLaunchKernelGGL((count_fwd_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, to_dev(rays), to_dev(opt), c);
     else hipLaunchKernelGGL((count_fwd_kernel<false>), dim3(nb), dim3(kBlock), 0, st, tr, to_dev(rays), to_dev(opt), c);
     return check_launch(fn);
+}
+
+int64_t svoxt_bwd_workspace_bytes(int64_t Q, int32_t max_samples) {
+    if (Q < 0 || max_samples < 0) return -1;
+    return Q * (int64_t)max_samples * 8;
 }
 
 int64_t svoxt_accel_bytes(int32_t log2_res) {

@@ -95,3 +95,21 @@ def test_counters_match_oracle(case, gpu):
                            r._get_options()).cpu().tolist()
     _, want = O.volume_render(case.oracle_tree(), *case.rays_np(), case.oracle_opts(), count=True)
     assert tuple(cnt) == tuple(want)
+
+
+@pytest.mark.parametrize("list_samples", [0, 1, 3, 64])
+def test_backward_sample_list_capacity_does_not_change_results(gpu, list_samples, monkeypatch):
+    """The backward records up to S samples per ray in pass 1 and replays them in
+    pass 2; rays with more samples march the rest.  Any S gives the same
+    gradient (S = 0: march twice like the reference)."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd import synth
+    monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", list_samples)
+    c = Case(depth=6, K=28, data_format="SH9", width=96, height=96)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    out = r(tree.features, c.rays_gpu(gpu))
+    g = synth.grad_output(c.Q, 4)
+    out.backward(g.to(gpu))
+    want, abs_sum = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.numpy(), want_abs=True)
+    assert_grads_close(tree.features.grad.cpu().numpy(), want, abs_sum)
