@@ -114,7 +114,7 @@ def main():
         features.grad = None
         e = ev[i] if i is not None else None
         if e: e[0].record()
-        out = renderer(features, rays)
+        out = renderer(features, rays, image_shape=(H, W))   # the batch is an H x W render
         if e: e[1].record()
         if not args.forward_only:
             out.backward(gout)

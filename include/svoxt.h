@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 3
+#define SVOXT_ABI_VERSION 4
 
 enum {
     SVOXT_OK = 0,
@@ -86,6 +86,9 @@ typedef struct svoxt_rays {
     const float* dirs;           /* device [Q, 3] */
     const float* vdirs;          /* device [Q, 3] */
     int64_t      Q;
+    int32_t      image_width;    /* optional hint (no counterpart in the reference): if the batch is a   */
+    int32_t      image_height;   /* row-major W x H image (Q == W*H, both multiples of 8) the kernels walk
+                                    it in 8x8 pixel tiles; 0 = no hint.  Results do not depend on it. */
 } svoxt_rays;
 
 /* RenderOptions (data_spec.hpp:129-145), same fields in the same order. */

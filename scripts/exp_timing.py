@@ -39,6 +39,9 @@ print("depth          %.3f ms" % timeit(lambda: _C.render_depth(spec, rs, opt)))
 print("count          %.3f ms" % timeit(lambda: _C.count_forward(spec, rs, opt)))
 print("bwd            %.3f ms" % timeit(lambda: _C.volume_render_backward(spec, rs, opt, gout)))
 print("opacity bwd    %.3f ms" % timeit(lambda: _C.opacity_render_backward(spec, rs, opt, gout[:, :1].contiguous())))
+rsh = _rays_spec_from_rays(rays, (H, W))
+print("fwd hint       %.3f ms" % timeit(lambda: _C.volume_render(spec, rsh, opt)))
+print("bwd hint       %.3f ms" % timeit(lambda: _C.volume_render_backward(spec, rsh, opt, gout)))
 if len(sys.argv) > 1 and sys.argv[1] == "perm":
     # same rays in random order: what does coherence buy?
     p = torch.randperm(W * H, device=dev)

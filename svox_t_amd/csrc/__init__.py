@@ -42,7 +42,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -62,7 +62,8 @@ class _CTree(ctypes.Structure):          # struct svoxt_tree
 
 class _CRays(ctypes.Structure):          # struct svoxt_rays
     _fields_ = [("origins", ctypes.c_void_p), ("dirs", ctypes.c_void_p),
-                ("vdirs", ctypes.c_void_p), ("Q", ctypes.c_int64)]
+                ("vdirs", ctypes.c_void_p), ("Q", ctypes.c_int64),
+                ("image_width", ctypes.c_int32), ("image_height", ctypes.c_int32)]
 
 
 class _COptions(ctypes.Structure):       # struct svoxt_options
@@ -114,6 +115,10 @@ class RaysSpec:
         self.origins = None
         self.dirs = None
         self.vdirs = None
+        # optional (not in the reference): the batch is a row-major image of this
+        # size; the kernels then walk it in 8x8 tiles.  0 = unknown.
+        self.image_width = 0
+        self.image_height = 0
 
 
 class TreeSpec:
@@ -304,6 +309,9 @@ def _pack_rays(rays: RaysSpec) -> _CRays:
     c = _CRays()
     c.origins, c.dirs, c.vdirs = _ptr(rays.origins), _ptr(rays.dirs), _ptr(rays.vdirs)
     c.Q = Q
+    w, h = int(getattr(rays, "image_width", 0) or 0), int(getattr(rays, "image_height", 0) or 0)
+    if w * h == Q:
+        c.image_width, c.image_height = w, h
     return c
 
 

@@ -49,7 +49,23 @@ struct RaysDev {
     const float* __restrict__ dirs;
     const float* __restrict__ vdirs;
     int64_t Q;
+    int tiles_per_row;   // > 0: rays are a row-major W x H image (W = 8 * tiles_per_row), walk it in 8x8 tiles
 };
+
+// Which ray a thread works on.  By default thread i takes ray i (a wavefront =
+// 64 consecutive rays).  When the caller states that the batch is a row-major
+// image, a wavefront takes an 8x8 pixel tile instead: neighbouring rays then
+// traverse the same leaves in both image directions (fewer divergent
+// iterations, better cache reuse, more gradient rows merged before the
+// atomics).  Only the assignment of rays to lanes changes; every ray's result
+// is the same and is written at the ray's own index.
+__device__ __forceinline__ int64_t ray_of_thread(const RaysDev& rays, int64_t tid) {
+    if (rays.tiles_per_row <= 0) return tid;
+    const int64_t tile = tid >> 6;
+    const int within = (int)(tid & 63);
+    const int64_t ty = tile / rays.tiles_per_row, tx = tile - ty * rays.tiles_per_row;
+    return ((ty << 3) + (within >> 3)) * ((int64_t)rays.tiles_per_row << 3) + (tx << 3) + (within & 7);
+}
 
 // svox_t/csrc/include/data_spec.hpp:129-145
 struct Opts {

@@ -33,7 +33,7 @@ template <int FMT, int C, int BD, bool N2>
 __global__ void __launch_bounds__(kBlock)
 render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) {
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
-    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     if (q >= rays.Q) return;
     float* o = out + q * (C + 1);
 
@@ -104,7 +104,7 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) {
 template <bool N2>
 __global__ void __launch_bounds__(kBlock)
 render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __restrict__ out) {
-    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     if (q >= rays.Q) return;
     float* o = out + q * (C + 1);
     const int K = tr.K;
@@ -293,7 +293,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     const int lane = threadIdx.x & 63;
     float* stage = stage_all + (threadIdx.x >> 6) * (64 * KS);
     float* st = stage + lane * KS;
-    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     Ray r;
     bool alive = q < rays.Q;
     if (alive) alive = setup_ray(tr, rays, q, r);
@@ -407,7 +407,7 @@ template <bool N2>
 __global__ void __launch_bounds__(kBlock)
 render_bwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
                           const float* __restrict__ grad_out, float* __restrict__ grad) {
-    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     if (q >= rays.Q) return;
     Ray r;
     if (!setup_ray(tr, rays, q, r)) return;
@@ -504,7 +504,7 @@ render_bwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
 template <bool N2>
 __global__ void __launch_bounds__(kBlock)
 opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) {
-    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     if (q >= rays.Q) return;
     Ray r;
     if (!setup_ray(tr, rays, q, r)) { out[q] = 0.f; return; }
@@ -528,7 +528,7 @@ opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) 
 template <bool N2>
 __global__ void __launch_bounds__(kBlock)
 depth_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ depth) {
-    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     if (q >= rays.Q) return;
     Ray r;
     float d = 0.f;
@@ -561,7 +561,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 template <bool N2>
 __global__ void __launch_bounds__(kBlock)
 count_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, unsigned long long* __restrict__ counters) {
-    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     unsigned long long hit = 0, steps = 0, levels = 0, valid = 0, active = 0;
     Ray r;
     if (q < rays.Q && setup_ray(tr, rays, q, r)) {
@@ -717,6 +717,7 @@ int check_rays(const svoxt_rays* r, const char* fn) {
     if (r->Q > 0 && (r->origins == nullptr || r->dirs == nullptr || r->vdirs == nullptr))
         return fail(SVOXT_ERR_INVALID, "%s: rays.origins / dirs / vdirs is NULL", fn);
     if (r->Q >= (int64_t)kBlock * 2147483647LL) return fail(SVOXT_ERR_INVALID, "%s: too many rays", fn);
+    if (r->image_width < 0 || r->image_height < 0) return fail(SVOXT_ERR_INVALID, "%s: negative image extent", fn);
     return SVOXT_OK;
 }
 
@@ -756,6 +757,10 @@ TreeDev to_dev(const svoxt_tree* t) {
 RaysDev to_dev(const svoxt_rays* r) {
     RaysDev d;
     d.origins = r->origins; d.dirs = r->dirs; d.vdirs = r->vdirs; d.Q = r->Q;
+    // image hint: usable only if the batch is exactly a W x H image of 8x8 tiles
+    const bool tiled = r->image_width > 0 && r->image_height > 0 && r->image_width % 8 == 0 &&
+                       r->image_height % 8 == 0 && (int64_t)r->image_width * r->image_height == r->Q;
+    d.tiles_per_row = tiled ? r->image_width / 8 : 0;
     return d;
 }
 

@@ -26,11 +26,13 @@ Rays = namedtuple("Rays", ["origins", "dirs", "viewdirs"])
 _C = _get_c_extension()
 
 
-def _rays_spec_from_rays(rays):
+def _rays_spec_from_rays(rays, image_shape=None):
     spec = _C.RaysSpec()
     spec.origins = rays.origins
     spec.dirs = rays.dirs
     spec.vdirs = rays.viewdirs
+    if image_shape is not None:
+        spec.image_height, spec.image_width = int(image_shape[0]), int(image_shape[1])
     return spec
 
 
@@ -108,32 +110,37 @@ class VolumeRenderer(nn.Module):
             raise RuntimeError(f"VolumeRenderer.{what}: only the GPU (HIP) path exists "
                                "(the reference asserts on its non-CUDA branch too)")
 
-    def forward(self, features, rays: Rays, transformation_matrices=None, cuda=True, fast=False):
+    def forward(self, features, rays: Rays, transformation_matrices=None, cuda=True, fast=False,
+                image_shape=None):
         """Render a ray batch; differentiable wrt `features`.
 
         :param features: float32 [M, data_dim] leaf feature table (on the GPU)
         :param rays: Rays(origins [Q,3], dirs [Q,3], viewdirs [Q,3]) in world space
         :param fast: sigma_thresh = stop_thresh = 1e-2 (early termination)
+        :param image_shape: optional (H, W) (not in the reference): states that the
+               rays are the row-major pixels of an H x W image, which lets the kernels
+               walk them in 8x8 tiles; results are unchanged
         :return: [Q, C+1]: C colour/feature channels then accumulated alpha
         """
         self._require_gpu(cuda, "forward")
         return _VolumeRenderFunction.apply(
             features,
             self.tree._spec(features, transformation_matrices=transformation_matrices),
-            _rays_spec_from_rays(rays),
+            _rays_spec_from_rays(rays, image_shape),
             self._get_options(fast))
 
-    def render_depth(self, features, rays: Rays, cuda=True, fast=False):
+    def render_depth(self, features, rays: Rays, cuda=True, fast=False, image_shape=None):
         """[Q, 1] distance to the first sample with sigma > sigma_thresh (0 if none)."""
         self._require_gpu(cuda, "render_depth")
-        return _C.render_depth(self.tree._spec(features), _rays_spec_from_rays(rays),
+        return _C.render_depth(self.tree._spec(features), _rays_spec_from_rays(rays, image_shape),
                                self._get_options(fast))
 
-    def opacity_render(self, features, rays: Rays, cuda=True, fast=False):
+    def opacity_render(self, features, rays: Rays, cuda=True, fast=False, image_shape=None):
         """[Q, 1] accumulated alpha only; differentiable wrt `features`."""
         self._require_gpu(cuda, "opacity_render")
         return _OpacityRenderFunction.apply(
-            features, self.tree._spec(features), _rays_spec_from_rays(rays), self._get_options(fast))
+            features, self.tree._spec(features), _rays_spec_from_rays(rays, image_shape),
+            self._get_options(fast))
 
     def _get_options(self, fast=False):
         """RenderOptions for the operator boundary (svox_t/renderer.py:408-439)."""

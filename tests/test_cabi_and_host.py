@@ -28,13 +28,13 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_C.EXPORTS)          # the ctypes table and the header agree
-    assert lib.svoxt_abi_version() == 3
+    assert lib.svoxt_abi_version() == 4
 
 
 def test_struct_layouts_match_header():
     # sizes the C compiler gives the three structs (x86-64 SysV): 14 fields / 4 / 11
     assert ctypes.sizeof(_C._COptions) == 44
-    assert ctypes.sizeof(_C._CRays) == 32
+    assert ctypes.sizeof(_C._CRays) == 40
     assert ctypes.sizeof(_C._CTree) == 112
 
 

@@ -208,12 +208,13 @@ def test_config3_backward_full_size(cfg3, gpu):
     c = cfg3
     tree = c.tree(gpu)
     r = svox.VolumeRenderer(tree)
-    out = r(tree.features, c.rays_gpu(gpu))
+    out = r(tree.features, c.rays_gpu(gpu), image_shape=(800, 800))     # as bench.py runs it
     gout = synth.grad_output(c.Q, 4)
     out.backward(gout.to(gpu))
     got = tree.features.grad.cpu().numpy()
     want, absum = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), gout.numpy(), want_abs=True)
     assert_grads_close(got, want, absum)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts()))
     # linearity in the upstream gradient: backward(2g) == 2 backward(g) up to atomics order
     tree.features.grad = None
     out2 = r(tree.features, c.rays_gpu(gpu))

@@ -113,3 +113,25 @@ def test_backward_sample_list_capacity_does_not_change_results(gpu, list_samples
     out.backward(g.to(gpu))
     want, abs_sum = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.numpy(), want_abs=True)
     assert_grads_close(tree.features.grad.cpu().numpy(), want, abs_sum)
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (40, 72), (60, 64)])      # last: H not a multiple of 8 -> hint ignored
+def test_image_tile_hint_changes_nothing_but_the_lane_assignment(gpu, shape):
+    H, W = shape
+    c = Case(depth=5, K=28, data_format="SH9", width=W, height=H)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    rays = c.rays_gpu(gpu)
+    want = O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts())
+    out = r(tree.features, rays, image_shape=(H, W))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
+    from svox_t_amd import synth
+    g = synth.grad_output(c.Q, 4)
+    out.backward(g.to(gpu))
+    gw, ab = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.numpy(), want_abs=True)
+    assert_grads_close(tree.features.grad.cpu().numpy(), gw, ab)
+    with torch.no_grad():
+        d = r.render_depth(tree.features, rays, image_shape=(H, W)).cpu().numpy()
+        a = r.opacity_render(tree.features, rays, image_shape=(H, W)).cpu().numpy()
+    np.testing.assert_array_equal(d, O.render_depth(c.oracle_tree(), *c.rays_np(), c.oracle_opts()))
+    np.testing.assert_array_equal(a, O.opacity_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts()))
