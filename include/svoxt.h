@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 4
+#define SVOXT_ABI_VERSION 5
 
 enum {
     SVOXT_OK = 0,
@@ -132,6 +132,32 @@ int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
                             const svoxt_options* opt, const float* grad_out,
                             int32_t grad_cols, float* grad_features,
                             void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Sample lists (no counterpart in the reference).  When a forward will be
+ * followed by a backward, the forward can record which samples each ray
+ * composited -- rec[k][q] = (feature row, step length) for k < max_samples, and
+ * aux[q] = (count, overflow flag, resume point) -- and the backward then replays
+ * those samples instead of traversing the tree again (twice, in the reference:
+ * rt_kernel.cu:365-494).  Rays with more than max_samples composited samples
+ * march the remainder, so the result does not depend on max_samples.  Needs
+ * sigma_thresh == stop_thresh == 0 (the reference's backward ignores both) and
+ * one of the specialised payloads (svoxt_can_record returns 1); the lists are
+ * valid for the tree, features' sign of sigma, rays and options they were
+ * recorded with. */
+typedef struct svoxt_sample_lists {
+    void*   rec;           /* device, max_samples * Q * 8 bytes */
+    void*   aux;           /* device, Q * 8 bytes */
+    int32_t max_samples;   /* S, 1..4096 */
+} svoxt_sample_lists;
+
+int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt);
+int svoxt_volume_render_fwd_record(const svoxt_tree* tree, const svoxt_rays* rays,
+                                   const svoxt_options* opt, float* out,
+                                   const svoxt_sample_lists* lists, void* stream);
+int svoxt_volume_render_bwd_replay(const svoxt_tree* tree, const svoxt_rays* rays,
+                                   const svoxt_options* opt, const float* grad_out,
+                                   int32_t grad_cols, float* grad_features,
+                                   const svoxt_sample_lists* lists, void* stream);
 
 /* out: device [Q, 1] = accumulated opacity (alpha). */
 int svoxt_opacity_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,

@@ -42,7 +42,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -77,6 +77,10 @@ class _COptions(ctypes.Structure):       # struct svoxt_options
     ]
 
 
+class _CLists(ctypes.Structure):         # struct svoxt_sample_lists
+    _fields_ = [("rec", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("max_samples", ctypes.c_int32)]
+
+
 _P = ctypes.POINTER
 _vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
 
@@ -88,6 +92,9 @@ EXPORTS = {
     "svoxt_volume_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
     "svoxt_volume_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _vp, _i64, _vp]),
     "svoxt_bwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
+    "svoxt_can_record": (ctypes.c_int, [_P(_CTree), _P(_COptions)]),
+    "svoxt_volume_render_fwd_record": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _P(_CLists), _vp]),
+    "svoxt_volume_render_bwd_replay": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _P(_CLists), _vp]),
     "svoxt_opacity_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
     "svoxt_opacity_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp]),
     "svoxt_render_depth": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
@@ -345,25 +352,54 @@ def get_out_data_dim(opt: RenderOptions, K: int) -> int:
 # Hot-path operators
 # ---------------------------------------------------------------------------
 
-def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
-    """rt_kernel.cu:1362-1379."""
-    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
-    dev = tree.features.device
-    with torch.cuda.device(dev):
-        out = torch.empty((cr.Q, get_out_data_dim(opt, ct.K)), dtype=torch.float32, device=dev)
-        _call("svoxt_volume_render_fwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
-              _ptr(out), _stream(dev))
-    return out
-
-
-# Samples recorded per ray by the backward's first pass (8 bytes each); rays
-# with more composited samples march the remainder.  0 = always march twice.
+# Samples kept per ray for the backward (8 bytes each; rays with more composited
+# samples march the remainder, so this only trades memory for speed).
+# 0 = never record: the backward then traverses the tree itself.
 BWD_LIST_SAMPLES = int(os.environ.get("SVOXT_BWD_LIST", "64"))
 
 
+class SampleLists:
+    """Per-ray lists of composited samples recorded by a forward (see
+    include/svoxt.h, svoxt_sample_lists).  Opaque to callers: pass it back to
+    volume_render_backward."""
+
+    def __init__(self, Q, S, device):
+        self.rec = torch.empty((S, Q, 2), dtype=torch.int32, device=device)
+        self.aux = torch.empty((Q, 2), dtype=torch.int32, device=device)
+        self.S = S
+
+    def c_struct(self):
+        return _CLists(self.rec.data_ptr(), self.aux.data_ptr(), self.S)
+
+
+def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bool = False):
+    """rt_kernel.cu:1362-1379.
+
+    `record=True` (not in the reference) asks for the sample lists a following
+    volume_render_backward can replay; the call then returns (out, lists), with
+    lists = None when recording does not apply (non-zero thresholds, a payload
+    without a specialised kernel, SVOXT_BWD_LIST=0)."""
+    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
+    dev = tree.features.device
+    lists = None
+    with torch.cuda.device(dev):
+        out = torch.empty((cr.Q, get_out_data_dim(opt, ct.K)), dtype=torch.float32, device=dev)
+        if record and BWD_LIST_SAMPLES > 0 and cr.Q > 0 and \
+                _lib.svoxt_can_record(ctypes.byref(ct), ctypes.byref(co)):
+            lists = SampleLists(cr.Q, BWD_LIST_SAMPLES, dev)
+            cl = lists.c_struct()
+            _call("svoxt_volume_render_fwd_record", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+                  _ptr(out), ctypes.byref(cl), _stream(dev))
+        else:
+            _call("svoxt_volume_render_fwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+                  _ptr(out), _stream(dev))
+    return (out, lists) if record else out
+
+
 def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
-                           grad_output: torch.Tensor) -> torch.Tensor:
-    """rt_kernel.cu:1402-1426."""
+                           grad_output: torch.Tensor, lists: SampleLists = None) -> torch.Tensor:
+    """rt_kernel.cu:1402-1426.  `lists` (optional, not in the reference): what
+    volume_render(..., record=True) returned for the same tree / rays / options."""
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     _check_input(grad_output, "grad_output")
     if grad_output.dtype != torch.float32 or grad_output.dim() != 2 or grad_output.shape[0] != cr.Q:
@@ -371,10 +407,17 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
     dev = tree.features.device
     with torch.cuda.device(dev):
         grad = torch.empty_like(tree.features)
-        ws_bytes = _lib.svoxt_bwd_workspace_bytes(cr.Q, BWD_LIST_SAMPLES)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
-        _call("svoxt_volume_render_bwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
-              _ptr(grad_output), grad_output.shape[1], _ptr(grad), _ptr(ws), ws_bytes, _stream(dev))
+        if lists is not None:
+            if lists.aux.shape[0] != cr.Q or lists.aux.device != dev:
+                raise RuntimeError("sample lists do not belong to this ray batch")
+            cl = lists.c_struct()
+            _call("svoxt_volume_render_bwd_replay", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+                  _ptr(grad_output), grad_output.shape[1], _ptr(grad), ctypes.byref(cl), _stream(dev))
+        else:
+            ws_bytes = _lib.svoxt_bwd_workspace_bytes(cr.Q, BWD_LIST_SAMPLES)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
+            _call("svoxt_volume_render_bwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+                  _ptr(grad_output), grad_output.shape[1], _ptr(grad), _ptr(ws), ws_bytes, _stream(dev))
     return grad
 
 

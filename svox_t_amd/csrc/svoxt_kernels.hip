@@ -29,9 +29,19 @@ constexpr int kBlock = 256;
 // ---------------------------------------------------------------------------
 
 // FMT: FMT_RGBA or FMT_SH (specialised);  C: colour channels;  BD: basis dim.
-template <int FMT, int C, int BD, bool N2>
+// REC: also record every composited sample as (feature row, delta_t) in
+// rec[k][q] (k < S) and, per ray, aux[q] = {count | overflow << 31, t at which
+// the first unrecorded sample starts}, for svoxt_volume_render_bwd_replay.
+// REC requires sigma_thresh == stop_thresh == 0 (the backward ignores both,
+// rt_kernel.cu:382,456); the march is then not cut short when the
+// transmittance underflows to exactly 0 -- the remaining samples have weight
+// 0 and leave the output bits unchanged, but they belong in the list.
+constexpr uint32_t kRecOverflow = 0x80000000u;
+
+template <int FMT, int C, int BD, bool N2, bool REC>
 __global__ void __launch_bounds__(kBlock)
-render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) {
+render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
+                  uint2* __restrict__ rec, int S, uint2* __restrict__ aux) {
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     if (q >= rays.Q) return;
@@ -42,8 +52,12 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) {
 #pragma unroll
         for (int j = 0; j < C; ++j) o[j] = opt.background_brightness;
         o[C] = 0.f;
+        if constexpr (REC) aux[q] = make_uint2(0u, 0u);
         return;
     }
+    int nrec = 0;
+    bool over = false;
+    float t_resume = 0.f;
     float basis[BD > 0 ? BD : 1];
     if constexpr (FMT == FMT_SH) {
         const float* vd = rays.vdirs + 3 * q;
@@ -65,6 +79,15 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) {
             load_row<K>(rowp, row);   // whole row at once: sigma is its last element
             const float sigma = row[K - 1];
             if (sigma > opt.sigma_thresh) {
+                if constexpr (REC) {
+                    if (nrec < S) {
+                        rec[(int64_t)nrec * rays.Q + q] = make_uint2((uint32_t)s.idx, __float_as_uint(s.delta_t));
+                        ++nrec;
+                    } else if (!over) {
+                        over = true;
+                        t_resume = t;
+                    }
+                }
                 const float att = pexpf(-s.delta_t * r.delta_scale * sigma);
                 const float weight = light * (1.f - att);
                 if constexpr (FMT == FMT_SH) {
@@ -82,7 +105,9 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) {
                 }
                 light *= att;
                 if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + s.leaf.slot, weight);
-                if (light <= opt.stop_thresh) { stopped = true; break; }
+                if constexpr (!REC) {
+                    if (light <= opt.stop_thresh) { stopped = true; break; }
+                }
             }
         }
         t += s.delta_t;
@@ -97,6 +122,7 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) {
         for (int j = 0; j < C; ++j) o[j] = acc[j] + bg;
     }
     o[C] = 1.f - light;
+    if constexpr (REC) aux[q] = make_uint2((uint32_t)nrec | (over ? kRecOverflow : 0u), __float_as_uint(t_resume));
 }
 
 // Generic fallback: any K, any format, component sub-range; accumulators in
@@ -230,6 +256,30 @@ __device__ __forceinline__ void stage_sample(const float (&row)[K], const float*
               + delta_t * delta_scale * g[C] * light_ray;
 }
 
+// Pass-1 bookkeeping of one sample (rt_kernel.cu:397-428 without the atomics).
+template <int FMT, int C, int BD, int K>
+__device__ __forceinline__ void accum_sample(const float (&row)[K], const float* basis, const float* g,
+                                             float delta_t, float delta_scale, float& light, float& accum) {
+    const float sigma = row[K - 1];
+    const float att = pexpf(-delta_t * sigma * delta_scale);
+    const float weight = light * (1.f - att);
+    float total_color = 0.f;
+    if constexpr (FMT == FMT_SH) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float tmp = 0.f;
+#pragma unroll
+            for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
+            total_color += (float)sigmoid_d(tmp) * g[c];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < C; ++j) total_color += (float)sigmoid_d(row[j]) * g[j];
+    }
+    light *= att;
+    accum += weight * total_color;
+}
+
 // Cooperative flush of the rows staged by the lanes in `active` (row of lane l
 // at stage[l*KS], destined for feature row `idx`).
 template <int K, int KS>
@@ -282,10 +332,13 @@ __device__ __forceinline__ void flush_staged(const float* __restrict__ stage, bo
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int FMT, int C, int BD, bool N2>
+// REPLAY: rec / aux were filled by render_fwd_kernel<..., REC=true> for the
+// same tree, rays and options: pass 1 walks the list instead of the tree.
+template <int FMT, int C, int BD, bool N2, bool REPLAY>
 __global__ void __launch_bounds__(kBlock)
 render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
-                  float* __restrict__ grad, uint2* __restrict__ rec, int S) {
+                  float* __restrict__ grad, uint2* __restrict__ rec, int S,
+                  const uint2* __restrict__ aux) {
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     constexpr int KS = K | 1;                         // odd LDS row stride: conflict-free column writes
     __shared__ float stage_all[(kBlock / 64) * 64 * KS];
@@ -319,41 +372,37 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         float light = 1.f, t = r.tmin;
         t_resume = r.tmin;
         tmax2 = (S > 0) ? -1.f : r.tmax;
+        if constexpr (REPLAY) {
+            const uint2 a = aux[q];
+            nrec = (int)(a.x & ~kRecOverflow);
+            if (a.x & kRecOverflow) { t_resume = __uint_as_float(a.y); tmax2 = r.tmax; }
+            for (int k = 0; k < nrec; ++k) {
+                const uint2 e = rec[(int64_t)k * rays.Q + q];
+                float row[K];
+                load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
+                accum_sample<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, light, accum);
+            }
+            t = (tmax2 < 0.f) ? r.tmax : t_resume;      // march only what the list does not cover
+        }
         while (t < r.tmax) {
             Sample s;
             march_step<N2>(tr, r, opt.step_size, t, s);
             if (s.valid) {
-                const float* rowp = tr.features + (int64_t)s.idx * K;
                 float row[K];
-                load_row<K>(rowp, row);   // whole row at once: sigma is its last element
-                const float sigma = row[K - 1];
-                if (sigma > 0.f) {
-                    if (S > 0) {
-                        if (nrec < S) {
-                            rec[(int64_t)nrec * rays.Q + q] = make_uint2((uint32_t)s.idx, __float_as_uint(s.delta_t));
-                            ++nrec;
-                        } else if (tmax2 < 0.f) {   // list full: pass 2 marches from this step on
-                            t_resume = t;
-                            tmax2 = r.tmax;
+                load_row<K>(tr.features + (int64_t)s.idx * K, row);   // whole row: sigma is its last element
+                if (row[K - 1] > 0.f) {
+                    if constexpr (!REPLAY) {
+                        if (S > 0) {
+                            if (nrec < S) {
+                                rec[(int64_t)nrec * rays.Q + q] = make_uint2((uint32_t)s.idx, __float_as_uint(s.delta_t));
+                                ++nrec;
+                            } else if (tmax2 < 0.f) {   // list full: pass 2 marches from this step on
+                                t_resume = t;
+                                tmax2 = r.tmax;
+                            }
                         }
                     }
-                    const float att = pexpf(-s.delta_t * sigma * r.delta_scale);
-                    const float weight = light * (1.f - att);
-                    float total_color = 0.f;
-                    if constexpr (FMT == FMT_SH) {
-#pragma unroll
-                        for (int c = 0; c < C; ++c) {
-                            float tmp = 0.f;
-#pragma unroll
-                            for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
-                            total_color += (float)sigmoid_d(tmp) * g[c];
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < C; ++j) total_color += (float)sigmoid_d(row[j]) * g[j];
-                    }
-                    light *= att;
-                    accum += weight * total_color;
+                    accum_sample<FMT, C, BD, K>(row, basis, g, s.delta_t, r.delta_scale, light, accum);
                 }
             }
             t += s.delta_t;
@@ -780,13 +829,13 @@ bool full_comp(const svoxt_options* o) {
     return o->format == SVOXT_FORMAT_RGBA || (o->min_comp == 0 && o->max_comp == o->basis_dim - 1);
 }
 
-template <bool N2>
+template <bool N2, bool REC>
 bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C, float* out,
-                        hipStream_t st) {
+                        uint2* rec, int S, uint2* aux, hipStream_t st) {
     const unsigned nb = nblocks(rays.Q);
-#define SVOXT_FWD(F, CC, BB)                                                              \
-    hipLaunchKernelGGL((render_fwd_kernel<F, CC, BB, N2>), dim3(nb), dim3(kBlock), 0, st, \
-                       tr, rays, opt, out);                                               \
+#define SVOXT_FWD(F, CC, BB)                                                                   \
+    hipLaunchKernelGGL((render_fwd_kernel<F, CC, BB, N2, REC>), dim3(nb), dim3(kBlock), 0, st, \
+                       tr, rays, opt, out, rec, S, aux);                                       \
     return true;
     if (opt.format == FMT_RGBA) {
         if (C == 3) { SVOXT_FWD(FMT_RGBA, 3, 0) }
@@ -804,13 +853,14 @@ bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
     return false;
 }
 
-template <bool N2>
+template <bool N2, bool REPLAY>
 bool launch_bwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
-                        const float* grad_out, float* grad, uint2* rec, int S, hipStream_t st) {
+                        const float* grad_out, float* grad, uint2* rec, int S, const uint2* aux,
+                        hipStream_t st) {
     const unsigned nb = nblocks(rays.Q);
-#define SVOXT_BWD(F, CC, BB)                                                              \
-    hipLaunchKernelGGL((render_bwd_kernel<F, CC, BB, N2>), dim3(nb), dim3(kBlock), 0, st, \
-                       tr, rays, opt, grad_out, grad, rec, S);                            \
+#define SVOXT_BWD(F, CC, BB)                                                                      \
+    hipLaunchKernelGGL((render_bwd_kernel<F, CC, BB, N2, REPLAY>), dim3(nb), dim3(kBlock), 0, st, \
+                       tr, rays, opt, grad_out, grad, rec, S, aux);                               \
     return true;
     if (opt.format == FMT_RGBA) {
         if (C == 3) { SVOXT_BWD(FMT_RGBA, 3, 0) }
@@ -830,7 +880,8 @@ bool launch_bwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
 
 int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
                const float* grad_out, int32_t grad_cols, float* grad_features,
-               void* workspace, int64_t workspace_bytes, void* stream, const char* fn) {
+               void* workspace, int64_t workspace_bytes, const svoxt_sample_lists* lists,
+               void* stream, const char* fn) {
     int rc;
     if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) ||
         (rc = check_opts(opt, tree, fn, grad_cols > 1)))
@@ -860,8 +911,18 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
         int64_t S = (workspace != nullptr && workspace_bytes > 0) ? workspace_bytes / (8 * rays->Q) : 0;
         if (S > 4096) S = 4096;
         uint2* rec = S > 0 ? reinterpret_cast<uint2*>(workspace) : nullptr;
-        done = n2 ? launch_bwd_special<true>(tr, rd, od, C, grad_out, grad_features, rec, (int)S, st)
-                  : launch_bwd_special<false>(tr, rd, od, C, grad_out, grad_features, rec, (int)S, st);
+        if (lists != nullptr) {
+            uint2* lrec = reinterpret_cast<uint2*>(lists->rec);
+            const uint2* laux = reinterpret_cast<const uint2*>(lists->aux);
+            done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, lrec, lists->max_samples, laux, st)
+                      : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, lrec, lists->max_samples, laux, st);
+            if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no specialised kernel for this payload", fn);
+        } else {
+            done = n2 ? launch_bwd_special<true, false>(tr, rd, od, C, grad_out, grad_features, rec, (int)S, nullptr, st)
+                      : launch_bwd_special<false, false>(tr, rd, od, C, grad_out, grad_features, rec, (int)S, nullptr, st);
+        }
+    } else if (lists != nullptr) {
+        return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists need a specialised payload", fn);
     }
     if (!done) {
         const unsigned nb = nblocks(rays->Q);
@@ -888,12 +949,21 @@ int svoxt_out_data_dim(const svoxt_options* opt, int32_t K) {
     return K;
 }
 
-int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
-                            const svoxt_options* opt, float* out, void* stream) {
-    const char* fn = "svoxt_volume_render_fwd";
+static int check_lists(const svoxt_sample_lists* l, const svoxt_options* opt, const char* fn) {
+    if (l == nullptr) return fail(SVOXT_ERR_INVALID, "%s: lists is NULL", fn);
+    if (l->rec == nullptr || l->aux == nullptr || l->max_samples < 1 || l->max_samples > 4096)
+        return fail(SVOXT_ERR_INVALID, "%s: lists need rec, aux and 1 <= max_samples <= 4096", fn);
+    if (opt->sigma_thresh != 0.f || opt->stop_thresh != 0.f)
+        return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists require sigma_thresh == stop_thresh == 0", fn);
+    return SVOXT_OK;
+}
+
+static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt, float* out,
+                      const svoxt_sample_lists* lists, void* stream, const char* fn) {
     int rc;
     if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) || (rc = check_opts(opt, tree, fn, true)))
         return rc;
+    if (lists != nullptr && (rc = check_lists(lists, opt, fn))) return rc;
     if (rays->Q == 0) return SVOXT_OK;
     if (out == nullptr) return fail(SVOXT_ERR_INVALID, "%s: out is NULL", fn);
     const int C = svoxt_out_data_dim(opt, tree->K) - 1;
@@ -906,15 +976,60 @@ int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
     const Opts od = to_dev(opt);
     const bool n2 = tree->N == 2;
     bool done = false;
-    if (full_comp(opt))
-        done = n2 ? launch_fwd_special<true>(tr, rd, od, C, out, st)
-                  : launch_fwd_special<false>(tr, rd, od, C, out, st);
+    if (full_comp(opt)) {
+        if (lists != nullptr) {
+            uint2* rec = reinterpret_cast<uint2*>(lists->rec);
+            uint2* aux = reinterpret_cast<uint2*>(lists->aux);
+            done = n2 ? launch_fwd_special<true, true>(tr, rd, od, C, out, rec, lists->max_samples, aux, st)
+                      : launch_fwd_special<false, true>(tr, rd, od, C, out, rec, lists->max_samples, aux, st);
+        } else {
+            done = n2 ? launch_fwd_special<true, false>(tr, rd, od, C, out, nullptr, 0, nullptr, st)
+                      : launch_fwd_special<false, false>(tr, rd, od, C, out, nullptr, 0, nullptr, st);
+        }
+    }
     if (!done) {
+        if (lists != nullptr) return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists need a specialised payload", fn);
         const unsigned nb = nblocks(rays->Q);
         if (n2) hipLaunchKernelGGL((render_fwd_generic_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, out);
         else hipLaunchKernelGGL((render_fwd_generic_kernel<false>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, out);
     }
     return check_launch(fn);
+}
+
+int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
+                            const svoxt_options* opt, float* out, void* stream) {
+    return fwd_common(tree, rays, opt, out, nullptr, stream, "svoxt_volume_render_fwd");
+}
+
+int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt) {
+    if (tree == nullptr || opt == nullptr) return 0;
+    if (opt->sigma_thresh != 0.f || opt->stop_thresh != 0.f || !full_comp(opt)) return 0;
+    const int C = svoxt_out_data_dim(opt, tree->K) - 1;
+    if (opt->format == SVOXT_FORMAT_RGBA) return (C == 3 || C == 31) ? 1 : 0;
+    if (opt->format == SVOXT_FORMAT_SH && C == 3 && tree->K == 3 * opt->basis_dim + 1)
+        return (opt->basis_dim == 1 || opt->basis_dim == 4 || opt->basis_dim == 9 || opt->basis_dim == 16 ||
+                opt->basis_dim == 25) ? 1 : 0;
+    return 0;
+}
+
+int svoxt_volume_render_fwd_record(const svoxt_tree* tree, const svoxt_rays* rays,
+                                   const svoxt_options* opt, float* out,
+                                   const svoxt_sample_lists* lists, void* stream) {
+    const char* fn = "svoxt_volume_render_fwd_record";
+    if (lists == nullptr) return fail(SVOXT_ERR_INVALID, "%s: lists is NULL", fn);
+    return fwd_common(tree, rays, opt, out, lists, stream, fn);
+}
+
+int svoxt_volume_render_bwd_replay(const svoxt_tree* tree, const svoxt_rays* rays,
+                                   const svoxt_options* opt, const float* grad_out,
+                                   int32_t grad_cols, float* grad_features,
+                                   const svoxt_sample_lists* lists, void* stream) {
+    const char* fn = "svoxt_volume_render_bwd_replay";
+    int rc;
+    if (grad_cols < 2) return fail(SVOXT_ERR_INVALID, "%s: grad_cols must be C+1 >= 2", fn);
+    if (opt == nullptr) return fail(SVOXT_ERR_INVALID, "%s: options is NULL", fn);
+    if ((rc = check_lists(lists, opt, fn))) return rc;
+    return bwd_common(tree, rays, opt, grad_out, grad_cols, grad_features, nullptr, 0, lists, stream, fn);
 }
 
 int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
@@ -925,8 +1040,8 @@ int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
         return fail(SVOXT_ERR_INVALID, "%s: grad_cols must be C+1 >= 2 (use svoxt_opacity_render_bwd for C = 0)",
                     "svoxt_volume_render_bwd");
     if (workspace_bytes < 0) return fail(SVOXT_ERR_INVALID, "%s: negative workspace size", "svoxt_volume_render_bwd");
-    return bwd_common(tree, rays, opt, grad_out, grad_cols, grad_features, workspace, workspace_bytes, stream,
-                      "svoxt_volume_render_bwd");
+    return bwd_common(tree, rays, opt, grad_out, grad_cols, grad_features, workspace, workspace_bytes, nullptr,
+                      stream, "svoxt_volume_render_bwd");
 }
 
 int svoxt_opacity_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
@@ -947,7 +1062,8 @@ int svoxt_opacity_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
 int svoxt_opacity_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
                              const svoxt_options* opt, const float* grad_out,
                              float* grad_features, void* stream) {
-    return bwd_common(tree, rays, opt, grad_out, 1, grad_features, nullptr, 0, stream, "svoxt_opacity_render_bwd");
+    return bwd_common(tree, rays, opt, grad_out, 1, grad_features, nullptr, 0, nullptr, stream,
+                      "svoxt_opacity_render_bwd");
 }
 
 int svoxt_render_depth(const svoxt_tree* tree, const svoxt_rays* rays,

@@ -43,7 +43,12 @@ class _VolumeRenderFunction(autograd.Function):
 
     @staticmethod
     def forward(ctx, data, tree, rays, opt):
-        out = _C.volume_render(tree, rays, opt)
+        # When a backward will follow, the forward also records which samples
+        # each ray composited so that the backward need not traverse the tree.
+        if ctx.needs_input_grad[0]:
+            out, ctx.lists = _C.volume_render(tree, rays, opt, record=True)
+        else:
+            out, ctx.lists = _C.volume_render(tree, rays, opt), None
         ctx.tree = tree
         ctx.rays = rays
         ctx.opt = opt
@@ -52,8 +57,8 @@ class _VolumeRenderFunction(autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         if ctx.needs_input_grad[0]:
-            return _C.volume_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out.contiguous()), \
-                None, None, None
+            return _C.volume_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out.contiguous(),
+                                             lists=ctx.lists), None, None, None
         return None, None, None, None
 
 

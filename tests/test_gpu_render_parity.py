@@ -98,7 +98,8 @@ def test_counters_match_oracle(case, gpu):
 
 
 @pytest.mark.parametrize("list_samples", [0, 1, 3, 64])
-def test_backward_sample_list_capacity_does_not_change_results(gpu, list_samples, monkeypatch):
+@pytest.mark.parametrize("from_forward", [True, False])
+def test_backward_sample_list_capacity_does_not_change_results(gpu, list_samples, from_forward, monkeypatch):
     """The backward records up to S samples per ray in pass 1 and replays them in
     pass 2; rays with more samples march the rest.  Any S gives the same
     gradient (S = 0: march twice like the reference)."""
@@ -108,9 +109,16 @@ def test_backward_sample_list_capacity_does_not_change_results(gpu, list_samples
     c = Case(depth=6, K=28, data_format="SH9", width=96, height=96)
     tree = c.tree(gpu)
     r = svox.VolumeRenderer(tree)
-    out = r(tree.features, c.rays_gpu(gpu))
     g = synth.grad_output(c.Q, 4)
-    out.backward(g.to(gpu))
+    if from_forward:        # lists recorded by the forward, replayed by the backward
+        out = r(tree.features, c.rays_gpu(gpu))
+        np.testing.assert_array_equal(out.detach().cpu().numpy(),
+                                      O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts()))
+        out.backward(g.to(gpu))
+    else:                   # stand-alone backward: records in its own first pass
+        from svox_t_amd.renderer import _rays_spec_from_rays
+        tree.features.grad = _C.volume_render_backward(tree._spec(tree.features), _rays_spec_from_rays(c.rays_gpu(gpu)),
+                                                       r._get_options(), g.to(gpu))
     want, abs_sum = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.numpy(), want_abs=True)
     assert_grads_close(tree.features.grad.cpu().numpy(), want, abs_sum)
 
