@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="d8_sh9_800", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for dry runs")
+    ap.add_argument("--share-device", action="store_true",
+                    help="dry run: put every rank on cuda:0 (to rehearse the N>1 code path on a 1-GPU box)")
     ap.add_argument("--forward-only", action="store_true")
     args = ap.parse_args()
 
@@ -72,13 +75,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)
+        kw = {"device_id": dev} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, timeout=datetime.timedelta(seconds=300), **kw)
 
     import svox_t_amd as svox
     import svox_t_amd.csrc as _C
@@ -116,13 +123,21 @@ def main():
         if e: e[0].record()
         out = renderer(features, rays, image_shape=(H, W))   # the batch is an H x W render
         if e: e[1].record()
+        gather = None
+        if dist is not None:
+            # the pixels are final after the forward: gather them while the backward runs
+            if args.backend == "nccl":
+                gather = dist.all_gather_into_tensor(gathered, out.detach(), async_op=True)
+            else:   # gloo dry run
+                dist.all_gather(list(gathered.chunk(world)), out.detach())
         if not args.forward_only:
             out.backward(gout)
         if e: e[2].record()
         if dist is not None:
-            dist.all_gather_into_tensor(gathered, out.detach())
             if not args.forward_only:
                 dist.all_reduce(features.grad)
+            if gather is not None:
+                gather.wait()
         return out
 
     for _ in range(args.warmup):
