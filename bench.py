@@ -36,6 +36,26 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
+# Memory-side traffic of the two hot kernels, from separate rocprofv3 --pmc passes
+# of this same command (scripts/pmc_passes.sh -> scripts/pmc_summary.py), committed
+# under profiles/.  FETCH_SIZE / WRITE_SIZE are KiB per dispatch.
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_c_pmc.json")
+
+
+def pmc_traffic(which):
+    """(bytes per launch, note) for kernel "fwd" / "bwd", or (None, reason)."""
+    try:
+        with open(PMC_FILE) as f:
+            c = json.load(f)["counters"][which]
+        raw = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        return int(raw), ("(FETCH_SIZE + WRITE_SIZE) * 1024 from " + os.path.relpath(PMC_FILE, ROOT) +
+                          "; TCC_EA0 requests, Infinity-Cache hits included; gfx950 FETCH_SIZE reads 1/2 of a wide "
+                          "coalesced stream and is uncalibrated for these 4-16 B gathers (true read part: 1-2x); "
+                          "WRITE_SIZE counts a 64 B request per partial line (scattered 8 B records, 112 B atomic rows)")
+    except Exception as exc:   # no profile committed for this build
+        return None, f"no PMC summary ({exc.__class__.__name__})"
+
+
 WORKLOADS = {
     # name: (depth, K, data_format, width, height)
     "d8_sh9_800": (8, 28, "SH9", 800, 800),          # BASELINE configs[1]/[2] -- the metric's config
@@ -170,6 +190,8 @@ def main():
         else:
             dom, dom_ms, dom_bytes = "render_bwd_kernel (+ grad memset)", bwd_ms, bytes_bwd
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        traffic, traffic_note = pmc_traffic("fwd" if dom.startswith("render_fwd") else "bwd") \
+            if args.workload == "d8_sh9_800" and world == 1 else (None, "PMC profile exists for the default workload at N=1 only")
         res = {
             "metric": "Mrays/s fwd+bwd, 800×800 render, depth-8 SH9 N3Tree, 1→8 MI355X"
                       if args.workload == "d8_sh9_800" and not args.forward_only
@@ -204,7 +226,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": traffic_note,
             },
         }
         if not args.no_cpu_baseline:

@@ -12,7 +12,15 @@ for f in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
         if short is None:
             continue
         acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+out = {}
 for k in ("fwd", "bwd"):
     print(f"== {k}")
+    out[k] = {}
     for c, v in sorted(acc[k].items()):
         print(f"  {c:40s} {sum(v)/len(v):18.1f}   (n={len(v)})")
+        out[k][c] = sum(v) / len(v)
+if len(sys.argv) > 2:
+    import json
+    json.dump({"tag": tag, "units": "mean counter value per dispatch; FETCH_SIZE / WRITE_SIZE in KiB",
+               "kernels": {"fwd": "render_fwd_kernel<SH,3,9,N2,REC>", "bwd": "render_bwd_kernel<SH,3,9,N2,REPLAY>"},
+               "counters": out}, open(sys.argv[2], "w"), indent=1)
