@@ -141,7 +141,11 @@ def main():
         features.grad = None
         e = ev[i] if i is not None else None
         if e: e[0].record()
-        out = renderer(features, rays, image_shape=(H, W))   # the batch is an H x W render
+        if args.forward_only:
+            with torch.no_grad():                              # inference: nothing is recorded for a backward
+                out = renderer(features, rays, image_shape=(H, W))
+        else:
+            out = renderer(features, rays, image_shape=(H, W))   # the batch is an H x W render
         if e: e[1].record()
         gather = None
         if dist is not None:

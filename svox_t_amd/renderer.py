@@ -36,6 +36,45 @@ def _rays_spec_from_rays(rays, image_shape=None):
     return spec
 
 
+def pinhole_rays(c2w, width, height, fx, fy, ndc: NDCConfig = None, near=1.0):
+    """Row-major [H*W, 3] float32 (origins, dirs, viewdirs) of a pinhole camera.
+
+    cam2world_ray (svox_t/csrc/rt_kernel.cu:1153-1166), with its mixed
+    float/double arithmetic: x = (ix - 0.5 W)/fx and y = -(iy - 0.5 H)/fy are
+    formed in double and rounded to float, z = sqrtf(x*x + y*y + 1.0).  With an
+    NDC config, origins and dirs are then warped as maybe_world2ndc (:1170-1190)
+    does; viewdirs keep the un-warped directions.
+    """
+    dev = c2w.device
+    ix = torch.arange(width, device=dev, dtype=torch.float64)
+    iy = torch.arange(height, device=dev, dtype=torch.float64)
+    x = ((ix - 0.5 * width) / float(torch.tensor(fx, dtype=torch.float32))).float()
+    y = (-(iy - 0.5 * height) / float(torch.tensor(fy, dtype=torch.float32))).float()
+    X = x[None, :].expand(height, width).reshape(-1)
+    Y = y[:, None].expand(height, width).reshape(-1)
+    Z = torch.sqrt(((X * X + Y * Y).double() + 1.0).float())
+    X, Y, Z = X / Z, Y / Z, -1.0 / Z
+    R = c2w[:3, :3]
+    dirs = torch.stack([(R[i, 0] * X + R[i, 1] * Y) + R[i, 2] * Z for i in range(3)], dim=-1).contiguous()
+    origins = c2w[:3, 3].expand(width * height, 3).contiguous()
+    vdirs = dirs
+    if ndc is not None and ndc.width >= 0:
+        t = -(near + origins[:, 2]) / dirs[:, 2]
+        cen = origins + t[:, None] * dirs
+        sx, sy = (2 * ndc.focal) / ndc.width, (2 * ndc.focal) / ndc.height
+        d0 = -sx * (dirs[:, 0] / dirs[:, 2] - cen[:, 0] / cen[:, 2])
+        d1 = -sy * (dirs[:, 1] / dirs[:, 2] - cen[:, 1] / cen[:, 2])
+        d2 = -2 * near / cen[:, 2]
+        o0 = -sx * (cen[:, 0] / cen[:, 2])
+        o1 = -sy * (cen[:, 1] / cen[:, 2])
+        o2 = 1 + 2 * near / cen[:, 2]
+        nd = torch.stack([d0, d1, d2], -1)
+        dirs = (nd / torch.norm(nd, dim=-1, keepdim=True)).contiguous()
+        origins = torch.stack([o0, o1, o2], -1).contiguous()
+        vdirs = vdirs.clone()
+    return origins, dirs, vdirs
+
+
 class _VolumeRenderFunction(autograd.Function):
     """Argument order (data, tree_spec, rays_spec, opt) and "gradient for
     argument 0 only" as in svox_t/renderer.py:60-77.  The specs are kept on the
@@ -133,6 +172,29 @@ class VolumeRenderer(nn.Module):
             self.tree._spec(features, transformation_matrices=transformation_matrices),
             _rays_spec_from_rays(rays, image_shape),
             self._get_options(fast))
+
+    def render_persp(self, features, c2w, width=800, height=800, fx=1111.111, fy=None,
+                     cuda=True, fast=False):
+        """Render a perspective image; differentiable wrt `features`.
+
+        Same signature as the reference (svox_t/renderer.py:310-366), whose CUDA
+        route for it cannot run (it allocates and dispatches on the int32 index
+        tensor, svox_t/csrc/rt_kernel.cu:1390-1393).  Here the pinhole rays of
+        `cam2world_ray` (:1153-1166) -- and the NDC warp of `maybe_world2ndc`
+        (:1170-1190) when the renderer has an `ndc` config -- are generated on
+        the GPU with torch ops and fed to the ray-batch kernels, walked in 8x8
+        pixel tiles.
+
+        :param c2w: (3, 4) or (4, 4) camera-to-world matrix (OpenGL axes: -z forward)
+        :return: (height, width, C+1)
+        """
+        self._require_gpu(cuda, "render_persp")
+        if fy is None:
+            fy = fx
+        origins, dirs, vdirs = pinhole_rays(c2w.to(device=self.tree.data.device, dtype=torch.float32),
+                                            width, height, fx, fy, self.ndc_config)
+        out = self.forward(features, Rays(origins, dirs, vdirs), fast=fast, image_shape=(height, width))
+        return out.reshape(height, width, -1)
 
     def render_depth(self, features, rays: Rays, cuda=True, fast=False, image_shape=None):
         """[Q, 1] distance to the first sample with sigma > sigma_thresh (0 if none)."""
