@@ -1,0 +1,103 @@
+"""Randomised parity stress: irregular trees (random selective refinement),
+adversarial features (zero / negative / huge sigma, large coefficients) and
+rays (origins inside the volume, axis-parallel directions, grazing and missing
+rays, non-unit direction lengths, anisotropic world scaling).  Everything except
+the gradient sum order must match the oracle bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+import svox_t_amd as svox
+from oracle import oracle as O
+from svox_t_amd import synth
+from tests.util import assert_grads_close
+
+pytestmark = pytest.mark.gpu
+
+
+def random_tree(seed, N=2, max_depth=6, data_format="SH4", K=13, p_refine=0.45, p_occ=0.6,
+                radius=(0.7, 1.3, 0.9), center=(0.2, -0.1, 0.4)):
+    g = torch.Generator().manual_seed(seed)
+    t = svox.N3Tree(N=N, data_dim=K, init_reserve=4, depth_limit=max_depth, data_format=data_format,
+                    radius=list(radius), center=list(center))
+    for _ in range(max_depth):
+        leaves = t._all_leaves()
+        depth_ok = t.parent_depth[leaves[:, 0], 1] < max_depth - 1
+        pick = (torch.rand(len(leaves), generator=g) < p_refine) & depth_ok
+        if pick.any():
+            sel = leaves[pick]
+            t.refine(1, sel=tuple(sel.T), leaf_node=sel)
+    leaves = t._all_leaves()
+    occ = torch.rand(len(leaves), generator=g) < p_occ
+    M = int(occ.sum())
+    idx = torch.full((len(leaves),), synth.EMPTY_SENTINEL, dtype=torch.int32)
+    idx[occ] = torch.randperm(M, generator=g).to(torch.int32)          # not in leaf order
+    t.data[tuple(leaves.T)] = idx[:, None]
+    feats = torch.randn(M, K, generator=g) * 3.0
+    sig = torch.pow(10.0, torch.rand(M, generator=g) * 6.0 - 2.0)      # 1e-2 .. 1e4
+    kind = torch.rand(M, generator=g)
+    sig[kind < 0.1] = 0.0
+    sig[(kind >= 0.1) & (kind < 0.2)] = -5.0
+    feats[:, K - 1] = sig
+    feats[torch.rand(M, generator=g) < 0.05, :K - 1] = 40.0            # saturated sigmoids
+    return t, feats
+
+
+def random_rays(seed, Q, t):
+    g = torch.Generator().manual_seed(seed)
+    lo = (t.tree2world(torch.zeros(1, 3)))[0]
+    hi = (t.tree2world(torch.ones(1, 3)))[0]
+    ext = hi - lo
+    o = lo + (torch.rand(Q, 3, generator=g) * 2.0 - 0.5) * ext           # inside and outside the cube
+    target = lo + torch.rand(Q, 3, generator=g) * ext
+    d = target - o
+    d = d * (0.2 + 3.0 * torch.rand(Q, 1, generator=g))                  # not unit length
+    # axis-parallel and plane-parallel directions (zero components)
+    n = Q // 8
+    d[:n] = torch.eye(3)[torch.randint(0, 3, (n,), generator=g)] * torch.where(torch.rand(n, 1, generator=g) < 0.5, -1.0, 1.0)
+    d[n:2 * n, torch.randint(0, 3, (1,), generator=g).item()] = 0.0
+    # some rays that miss: point away from the cube
+    d[2 * n:2 * n + n // 2] = (o[2 * n:2 * n + n // 2] - (lo + 0.5 * ext)) + 1e-3
+    v = torch.nn.functional.normalize(torch.randn(Q, 3, generator=g), dim=-1)
+    return o.contiguous(), d.contiguous(), v.contiguous()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+@pytest.mark.parametrize("N,fmt,K", [(2, "SH4", 13), (2, "RGBA", 4), (3, "SH1", 4)])
+def test_random_tree_and_rays(gpu, seed, N, fmt, K):
+    t, feats = random_tree(seed, N=N, max_depth=6 if N == 2 else 3, data_format=fmt, K=K)
+    n = t.n_internal
+    o, d, v = random_rays(100 + seed, 6000, t)
+    data_np, child_np = t.data[:n].numpy().copy(), t.child[:n].numpy().copy()
+    ot = O.Tree(feats.numpy(), data_np, child_np,
+                offset=t.offset.numpy().copy(), scaling=t.invradius.numpy().copy())
+    df = svox.DataFormat(fmt)
+    tg = t.to(gpu)          # nn.Module.to moves the buffers in place: host copies were taken above
+    r = svox.VolumeRenderer(tg, step_size=2e-3, background_brightness=0.5)
+    rays = svox.Rays(o.to(gpu), d.to(gpu), v.to(gpu))
+    rnp = (o.numpy(), d.numpy(), v.numpy())
+    for fast in (False, True):
+        th = 1e-2 if fast else 0.0
+        opt = O.make_options(step_size=2e-3, background_brightness=0.5, format=df.format,
+                             basis_dim=df.basis_dim, sigma_thresh=th, stop_thresh=th)
+        f = feats.to(gpu).requires_grad_(True)
+        out = r(f, rays, fast=fast)
+        want, cnt = O.volume_render(ot, *rnp, opt, count=True)
+        np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
+        assert cnt.active > 0 and cnt.rays_hit < len(o)
+        with torch.no_grad():
+            np.testing.assert_array_equal(r.render_depth(f, rays, fast=fast).cpu().numpy(), O.render_depth(ot, *rnp, opt))
+            np.testing.assert_array_equal(r.opacity_render(f, rays, fast=fast).cpu().numpy(), O.opacity_render(ot, *rnp, opt))
+        gout = synth.grad_output(len(o), out.shape[1], seed=seed)
+        out.backward(gout.to(gpu))
+        # the backward ignores both thresholds (rt_kernel.cu:382,456): same oracle call either way
+        opt0 = O.make_options(step_size=2e-3, background_brightness=0.5, format=df.format, basis_dim=df.basis_dim)
+        gw, ab = O.volume_render_backward(ot, *rnp, opt0, gout.numpy(), want_abs=True)
+        assert_grads_close(f.grad.cpu().numpy(), gw, ab)
+    # point query on the same irregular tree
+    pts = torch.rand(4000, 3, generator=torch.Generator().manual_seed(seed)) * 1.2 - 0.1
+    vals, nid, did = tg(feats.to(gpu), pts.to(gpu), want_node_ids=True, want_data_ids=True, world=False)
+    wv, wn, wd = O.query(O.Tree(feats.numpy(), data_np, child_np), pts.numpy())
+    np.testing.assert_array_equal(vals.cpu().numpy(), wv)
+    np.testing.assert_array_equal(nid.cpu().numpy(), wn)
+    np.testing.assert_array_equal(did.cpu().numpy(), wd)
