@@ -28,6 +28,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -247,13 +248,15 @@ def _pack_tree(tree: TreeSpec) -> _CTree:
 
 # ---------------------------------------------------------------------------
 # Acceleration grid cache.  The grid (include/svoxt.h, svoxt_accel_build) is
-# derived from the *contents* of child and data, so it is keyed on the tensors'
-# storage and torch version counters (every in-place torch op bumps them, as
-# N3Tree.refine / construct_tree do): a changed tree gets a fresh grid.
-# SVOXT_ACCEL_LOG2=0 disables it, =g forces a resolution; default: by tree size.
+# derived from the *contents* of child and data.  An entry therefore hangs off
+# the `child` tensor OBJECT (weakly: it dies with the tensor, so a recycled
+# device address can never alias a stale grid) and is valid only while the torch
+# version counters of child and data are unchanged (every in-place torch op
+# bumps them, as N3Tree.refine / construct_tree do) and `data` is the same
+# tensor object.  SVOXT_ACCEL_LOG2=0 disables the grid, =g forces a resolution;
+# default: chosen from the tree size.
 # ---------------------------------------------------------------------------
-_ACCEL_CACHE: dict = {}
-_ACCEL_CACHE_MAX = 8
+_ACCEL_CACHE: dict = {}     # id(child tensor) -> (weakref to it, ...); entries are dropped when the tensor dies
 
 
 def _accel_log2_for(n_internal: int, N: int) -> int:
@@ -272,19 +275,21 @@ def _accel_for(tree: TreeSpec, ct: _CTree):
     g = _accel_log2_for(ct.n_internal, ct.N)
     if g == 0 or ct.N != 2:
         return None, 0
-    key = (tree.child.data_ptr(), tree.child._version, tree.data.data_ptr(), tree.data._version,
-           ct.n_internal, tree.child.device.index, g)
-    hit = _ACCEL_CACHE.get(key)
-    if hit is not None:
-        return hit, g
+    key = id(tree.child)
+    ent = _ACCEL_CACHE.get(key)
+    if ent is not None:
+        cref, cv, dref, dv, n_int, eg, cells = ent
+        if cref() is tree.child and cv == tree.child._version and dref() is tree.data \
+                and dv == tree.data._version and n_int == ct.n_internal and eg == g:
+            return cells, g
     dev = tree.child.device
     with torch.cuda.device(dev):
         cells = torch.empty((1 << (3 * g), 2), dtype=torch.int32, device=dev)
         assert cells.numel() * 4 == _lib.svoxt_accel_bytes(g)
         _call("svoxt_accel_build", ctypes.byref(ct), g, _ptr(cells), _stream(dev))
-    if len(_ACCEL_CACHE) >= _ACCEL_CACHE_MAX:
-        _ACCEL_CACHE.pop(next(iter(_ACCEL_CACHE)))
-    _ACCEL_CACHE[key] = cells
+    _ACCEL_CACHE[key] = (weakref.ref(tree.child, lambda _r, _k=key: _ACCEL_CACHE.pop(_k, None)),
+                         tree.child._version, weakref.ref(tree.data), tree.data._version,
+                         ct.n_internal, g, cells)
     return cells, g
 
 

@@ -165,6 +165,7 @@ class N3Tree(nn.Module):
                 elif leaf_node is None:
                     leaf_node = torch.stack(sel, dim=-1).to(self.data.device)
                 sel = tuple(s.to(self.data.device).long() for s in sel)
+                leaf_node = leaf_node.to(self.data.device)
                 n_new = sel[0].shape[0]
                 if n_new == 0:
                     return resized

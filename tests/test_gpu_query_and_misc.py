@@ -273,3 +273,47 @@ def test_render_persp_matches_ray_batch_render(gpu):
     with torch.no_grad():
         imgn = rn.render_persp(tree.features, c2w.to(gpu), width=64, height=48, fx=fx)
     assert torch.isfinite(imgn).all()
+
+
+def test_acceleration_grid_never_goes_stale(gpu):
+    """The grid is a cache of child/data: a new tree at a recycled device address,
+    an in-place refine, and an in-place change of `data` must each be seen."""
+    import gc
+    c = Case(depth=5, K=4, data_format="RGBA", width=40, height=40)
+    rays = c.rays_gpu(gpu)
+    opt = c.oracle_opts()
+    outs = []
+    for variant in range(3):          # same shapes, different contents, allocated one after the other
+        st = c.st
+        data = st.data.copy()
+        if variant:
+            flat = data.reshape(-1)
+            occ = np.flatnonzero(flat != synth.EMPTY_SENTINEL)
+            flat[occ] = np.random.default_rng(variant).permutation(flat[occ])
+        tree = svox.N3Tree.from_arrays(st.child, data, st.parent_depth, c.features, device=gpu)
+        r = svox.VolumeRenderer(tree)
+        with torch.no_grad():
+            got = r(tree.features, rays).cpu().numpy()
+        want = O.volume_render(O.Tree(c.features.numpy(), data, st.child), *c.rays_np(), opt)
+        np.testing.assert_array_equal(got, want)
+        outs.append(got)
+        del tree, r
+        gc.collect()
+    assert not np.array_equal(outs[0], outs[1])
+    # in-place topology and data changes on a live tree
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    with torch.no_grad():
+        r(tree.features, rays)                                     # builds the grid
+        leaves = tree._all_leaves()
+        sel = leaves[tree.parent_depth[leaves[:, 0].to(gpu), 1].cpu() == 4][:50]
+        tree.refine(1, sel=tuple(sel.T), leaf_node=sel)            # children inherit the parent's row
+        got = r(tree.features, rays).cpu().numpy()
+    n = tree.n_internal
+    ot = O.Tree(c.features.numpy(), tree.data[:n].cpu().numpy(), tree.child[:n].cpu().numpy())
+    np.testing.assert_array_equal(got, O.volume_render(ot, *c.rays_np(), opt))
+    with torch.no_grad():
+        tree.data[tree.data < tree.features.shape[0]] = 7          # every occupied leaf -> row 7
+        got = r(tree.features, rays).cpu().numpy()
+    ot = O.Tree(c.features.numpy(), tree.data[:n].cpu().numpy(), tree.child[:n].cpu().numpy())
+    np.testing.assert_array_equal(got, O.volume_render(ot, *c.rays_np(), opt))
