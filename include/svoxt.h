@@ -73,7 +73,8 @@ typedef struct svoxt_tree {
     int32_t        extra_rows;
     int32_t        extra_cols;
     float*         weight_accum; /* device [capacity * N^3] or NULL (TreeSpec._weight_accum) */
-    const float*   xform;        /* TreeSpec.transformation_matrices [M,3,3]; must be NULL (unsupported) */
+    const float*   xform;        /* device [M,3,3] TreeSpec.transformation_matrices (per-leaf rotation of the view
+                                    direction, rt_kernel.cu:283-291) or NULL; volume_render fwd/bwd only */
     const void*    accel;        /* device, optional: acceleration grid built by svoxt_accel_build for THIS
                                     child/data content (N == 2), or NULL.  Pure cache: results are identical
                                     with or without it; rebuild after any change to child or data. */

@@ -150,6 +150,22 @@ def _rays(tree: Tree, origins, dirs, vdirs):
     return o, d, v
 
 
+class transformation_matrices:
+    """`with transformation_matrices(x):` -- per-leaf [M, 3, 3] view rotations
+    (TreeSpec.transformation_matrices) for the f32 render / backward calls inside."""
+
+    def __init__(self, xform):
+        self.x = _c(xform, np.float32)
+        assert self.x.ndim == 3 and self.x.shape[1:] == (3, 3)
+
+    def __enter__(self):
+        lib().svoxt_oracle_set_transformation_matrices(_p(self.x))
+        return self
+
+    def __exit__(self, *exc):
+        lib().svoxt_oracle_set_transformation_matrices(None)
+
+
 def volume_render(tree: Tree, origins, dirs, vdirs, opt: RenderOptions, count=False):
     o, d, v = _rays(tree, origins, dirs, vdirs)
     Q = o.shape[0]

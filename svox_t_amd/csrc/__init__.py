@@ -242,7 +242,10 @@ def _pack_tree(tree: TreeSpec) -> _CTree:
             raise RuntimeError("_weight_accum must be float32 with one entry per leaf slot")
         c.weight_accum = tree._weight_accum.data_ptr()
     if _numel(tree.transformation_matrices):
-        c.xform = tree.transformation_matrices.data_ptr()   # rejected by the library (unsupported)
+        x = tree.transformation_matrices
+        if x.dtype != torch.float32 or x.dim() != 3 or tuple(x.shape) != (tree.features.shape[0], 3, 3):
+            raise RuntimeError("transformation_matrices must be float32 [M, 3, 3]")
+        c.xform = x.data_ptr()
     return c
 
 

@@ -37,6 +37,7 @@ struct TreeDev {
     int extra_rows;
     int extra_cols;
     float* weight_accum;
+    const float* __restrict__ xform;   // transformation_matrices [M, 3, 3] or null (generic kernels only)
     // optional acceleration grid (N == 2 only): 2^G cells per axis, one uint2 per
     // cell, see locate_accel().  Derived data: a cache of what a root descent
     // of `child` / `data` would find, never a different answer.
@@ -422,6 +423,17 @@ __device__ __forceinline__ void precalc_basis(int format, int basis_dim_rt, cons
             out[i] = S * pexpf(-lobe[0] * dot_x * dot_x - lobe[1] * dot_y * dot_y) / (float)bd;
         }
     }
+}
+
+// Per-leaf view-direction rotation (rt_kernel.cu:283-291, :387-395): the basis
+// is re-evaluated for ray_dir = M[idx] * vdir.
+__device__ __forceinline__ void rotated_basis(const TreeDev& tr, int format, int basis_dim, int32_t idx,
+                                              const float* vdir, float* basis) {
+    const float* m = tr.xform + (int64_t)idx * 9;
+    const float x = m[0] * vdir[0] + m[1] * vdir[1] + m[2] * vdir[2];
+    const float y = m[3] * vdir[0] + m[4] * vdir[1] + m[5] * vdir[2];
+    const float z = m[6] * vdir[0] + m[7] * vdir[1] + m[8] * vdir[2];
+    precalc_basis<0>(format, basis_dim, tr, x, y, z, basis);
 }
 
 // The reference's `w / (1.0 + expf(-x))` family is evaluated in double

@@ -158,6 +158,7 @@ render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __re
             if (sigma > opt.sigma_thresh) {
                 const float att = pexpf(-s.delta_t * r.delta_scale * sigma);
                 const float weight = light * (1.f - att);
+                if (tr.xform != nullptr) rotated_basis(tr, opt.format, opt.basis_dim, s.idx, rays.vdirs + 3 * q, basis);
                 if (opt.format != FMT_RGBA) {
                     for (int c = 0; c < C; ++c) {
                         const int off = c * opt.basis_dim;
@@ -471,6 +472,8 @@ render_bwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
                 const float sigma = row[K - 1];
                 if (sigma > 0.f) {
                     float* grow = grad + (int64_t)s.idx * K;
+                    // pass 1 re-evaluates the rotated basis; pass 2 keeps the last one
+                    if (tr.xform != nullptr) rotated_basis(tr, opt.format, opt.basis_dim, s.idx, rays.vdirs + 3 * q, basis);
                     const float att = pexpf(-s.delta_t * sigma * r.delta_scale);
                     const float weight = light * (1.f - att);
                     float total_color = 0.f;
@@ -745,8 +748,6 @@ int check_tree(const svoxt_tree* t, const char* fn) {
     if (t->n_internal < 1) return fail(SVOXT_ERR_INVALID, "%s: n_internal must be >= 1", fn);
     if ((double)t->n_internal * t->N * t->N * t->N >= 2147483648.0)
         return fail(SVOXT_ERR_INVALID, "%s: tree too large for 32-bit slot indices", fn);
-    if (t->xform != nullptr)
-        return fail(SVOXT_ERR_UNSUPPORTED, "%s: transformation_matrices are not supported", fn);
     if (t->accel != nullptr && (t->accel_log2 < 1 || t->accel_log2 > 8))
         return fail(SVOXT_ERR_INVALID, "%s: accel_log2 must be in [1, 8]", fn);
     return SVOXT_OK;
@@ -788,6 +789,7 @@ TreeDev to_dev(const svoxt_tree* t) {
     d.data = t->data; d.child = t->child; d.offset = t->offset; d.scaling = t->scaling;
     d.extra = t->extra_data; d.extra_rows = t->extra_rows; d.extra_cols = t->extra_cols;
     d.weight_accum = t->weight_accum;
+    d.xform = t->xform;   // consulted by the generic render kernels only
     // the grid caches data words but not slot ids: per-slot weight accumulation takes the plain descent
     const bool use_accel = t->accel != nullptr && t->N == 2 && t->weight_accum == nullptr;
     d.accel = use_accel ? reinterpret_cast<const uint2*>(t->accel) : nullptr;
@@ -816,6 +818,12 @@ inline unsigned nblocks(int64_t Q) { return (unsigned)((Q + kBlock - 1) / kBlock
 
 // Specialised payloads: (format, C, BD) with all components selected.
 struct Payload { int fmt, C, BD; };
+
+// transformation_matrices only matter for view-dependent formats (for RGBA the
+// reference's per-sample basis re-evaluation is a no-op, rt_kernel.cu:181-183)
+bool uses_xform(const svoxt_tree* t, const svoxt_options* o) {
+    return t->xform != nullptr && o->format != SVOXT_FORMAT_RGBA;
+}
 
 bool full_comp(const svoxt_options* o) {
     return o->format == SVOXT_FORMAT_RGBA || (o->min_comp == 0 && o->max_comp == o->basis_dim - 1);
@@ -897,7 +905,9 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
     const Opts od = to_dev(opt);
     const bool n2 = tree->N == 2;
     bool done = false;
-    if (C > 0 && full_comp(opt))
+    if (uses_xform(tree, opt) && lists != nullptr)
+        return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists with transformation_matrices", fn);
+    if (C > 0 && full_comp(opt) && !uses_xform(tree, opt))
     {
         // per-ray sample lists: S entries of 8 bytes per ray, laid out rec[k][q]
         int64_t S = (workspace != nullptr && workspace_bytes > 0) ? workspace_bytes / (8 * rays->Q) : 0;
@@ -956,6 +966,8 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
     if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) || (rc = check_opts(opt, tree, fn, true)))
         return rc;
     if (lists != nullptr && (rc = check_lists(lists, opt, fn))) return rc;
+    if (lists != nullptr && uses_xform(tree, opt))
+        return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists with transformation_matrices", fn);
     if (rays->Q == 0) return SVOXT_OK;
     if (out == nullptr) return fail(SVOXT_ERR_INVALID, "%s: out is NULL", fn);
     const int C = svoxt_out_data_dim(opt, tree->K) - 1;
@@ -968,7 +980,10 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
     const Opts od = to_dev(opt);
     const bool n2 = tree->N == 2;
     bool done = false;
-    if (full_comp(opt)) {
+    if (uses_xform(tree, opt)) {
+        // per-leaf view rotations re-evaluate the basis per sample: generic kernel only
+        if (lists != nullptr) return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists with transformation_matrices", fn);
+    } else if (full_comp(opt)) {
         if (lists != nullptr) {
             uint2* rec = reinterpret_cast<uint2*>(lists->rec);
             uint2* aux = reinterpret_cast<uint2*>(lists->aux);
@@ -994,7 +1009,7 @@ int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
 }
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt) {
-    if (tree == nullptr || opt == nullptr) return 0;
+    if (tree == nullptr || opt == nullptr || uses_xform(tree, opt)) return 0;
     if (opt->sigma_thresh != 0.f || opt->stop_thresh != 0.f || !full_comp(opt)) return 0;
     const int C = svoxt_out_data_dim(opt, tree->K) - 1;
     if (opt->format == SVOXT_FORMAT_RGBA) return (C == 3 || C == 31) ? 1 : 0;

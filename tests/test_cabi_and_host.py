@@ -56,12 +56,19 @@ def test_validation_codes_without_touching_the_gpu():
     t = _C._CTree()
     assert lib.svoxt_render_depth(ctypes.byref(t), None, None, None, None) == 1
     assert b"NULL" in lib.svoxt_last_error()
-    # transformation matrices: valid for the reference, unsupported here
     buf = (ctypes.c_float * 64)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    t = _C._CTree(features=p, M=1, K=4, N=2, data=p, child=p, n_internal=1, offset=p, scaling=p, xform=p)
-    assert lib.svoxt_opacity_render_fwd(ctypes.byref(t), None, None, None, None) == 2   # SVOXT_ERR_UNSUPPORTED
+    t = _C._CTree(features=p, M=1, K=13, N=2, data=p, child=p, n_internal=1, offset=p, scaling=p, xform=p)
+    # sample lists cannot be combined with per-leaf view rotations
+    o = _C._COptions(format=1, basis_dim=4, min_comp=0, max_comp=3)
+    r = _C._CRays(Q=0)
+    l = _C._CLists(rec=p, aux=p, max_samples=4)
+    assert lib.svoxt_volume_render_fwd_record(ctypes.byref(t), ctypes.byref(r), ctypes.byref(o), None,
+                                              ctypes.byref(l), None) == 2       # SVOXT_ERR_UNSUPPORTED
+    assert lib.svoxt_can_record(ctypes.byref(t), ctypes.byref(o)) == 0
     t.xform = None
+    assert lib.svoxt_can_record(ctypes.byref(t), ctypes.byref(o)) == 1
+    t.K = 4
     r = _C._CRays(Q=0)
     o = _C._COptions(format=1, basis_dim=7)
     assert lib.svoxt_volume_render_fwd(ctypes.byref(t), ctypes.byref(r), ctypes.byref(o), None, None) == 1

@@ -155,8 +155,8 @@ def test_rejects_noncontiguous_and_wrong_dtype(gpu):
         r(tree.features, bad)
     with pytest.raises(RuntimeError, match="float"):
         r(tree.features, svox.Rays(rays.origins.double(), rays.dirs.double(), rays.viewdirs.double()))
-    with pytest.raises(RuntimeError, match="unsupported|not supported"):
-        r(tree.features, rays, transformation_matrices=torch.eye(3, device=gpu).repeat(tree.features.shape[0], 1, 1))
+    with pytest.raises(RuntimeError, match="M, 3, 3"):
+        r(tree.features, rays, transformation_matrices=torch.eye(3, device=gpu).repeat(5, 1, 1))
 
 
 def test_weight_accumulation(gpu):
@@ -317,3 +317,32 @@ def test_acceleration_grid_never_goes_stale(gpu):
         got = r(tree.features, rays).cpu().numpy()
     ot = O.Tree(c.features.numpy(), tree.data[:n].cpu().numpy(), tree.child[:n].cpu().numpy())
     np.testing.assert_array_equal(got, O.volume_render(ot, *c.rays_np(), opt))
+
+
+def test_transformation_matrices(gpu):
+    """Per-leaf rotation of the view direction (rt_kernel.cu:283-291, :387-395),
+    including the reference's quirk that pass 2 of the backward keeps the basis
+    of the last sample of pass 1."""
+    c = Case(depth=5, K=28, data_format="SH9", width=48, height=48)
+    tree = c.tree(gpu)
+    M = tree.features.shape[0]
+    g = torch.Generator().manual_seed(9)
+    A = torch.randn(M, 3, 3, generator=g)
+    Qm, _ = torch.linalg.qr(A)                                # random rotations
+    r = svox.VolumeRenderer(tree)
+    rays = c.rays_gpu(gpu)
+    out = r(tree.features, rays, transformation_matrices=Qm.to(gpu).contiguous())
+    with O.transformation_matrices(Qm.numpy()):
+        want = O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts())
+        gout = synth.grad_output(c.Q, 4)
+        gw, ab = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), gout.numpy(), want_abs=True)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
+    plain = O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts())
+    assert np.abs(plain - want).max() > 1e-3                  # the rotations do change the image
+    out.backward(gout.to(gpu))
+    assert_grads_close(tree.features.grad.cpu().numpy(), gw, ab)
+    # identity matrices reproduce the plain render exactly
+    eye = torch.eye(3).repeat(M, 1, 1).contiguous()
+    with torch.no_grad():
+        same = r(tree.features, rays, transformation_matrices=eye.to(gpu)).cpu().numpy()
+    np.testing.assert_array_equal(same, plain)
