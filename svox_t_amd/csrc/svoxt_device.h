@@ -345,6 +345,15 @@ __device__ __forceinline__ float pexpf(float x) {
     return (x != x) ? x : y;
 }
 
+// t += delta_t (rt_kernel.cu:321), guarded: if the step is too small to move t
+// in float (step_size <= 0 on a degenerate crossing, or ~1e-8 of t) the
+// reference loops forever; here the march ends instead of hanging the GPU.
+// Never triggers for a step that advances, so results are unchanged.
+__device__ __forceinline__ float march_advance(float t, float delta_t) {
+    const float tn = t + delta_t;
+    return (tn > t) ? tn : __int_as_float(0x7f800000);
+}
+
 // SH constants, `const float` in the reference (rt_kernel.cu:54-84).
 __device__ __constant__ const float kC0 = 0.28209479177387814;
 __device__ __constant__ const float kC1 = 0.4886025119029199;

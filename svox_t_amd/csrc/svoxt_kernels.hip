@@ -110,7 +110,7 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
                 }
             }
         }
-        t += s.delta_t;
+        t = march_advance(t, s.delta_t);
     }
     if (stopped) {
         const float scale = (float)(1.0 / (1.0 - (double)light));
@@ -180,7 +180,7 @@ render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __re
                 }
             }
         }
-        t += s.delta_t;
+        t = march_advance(t, s.delta_t);
     }
     for (int j = 0; j < C; ++j) o[j] += light * opt.background_brightness;
     o[C] = 1.f - light;
@@ -394,7 +394,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                     accum_sample<FMT, C, BD, K>(row, basis, g, s.delta_t, r.delta_scale, light, accum);
                 }
             }
-            t += s.delta_t;
+            t = march_advance(t, s.delta_t);
         }
         float total_grad = 0.f;
 #pragma unroll
@@ -425,7 +425,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             Sample s;
             march_step<N2>(tr, r, opt.step_size, t, s);
             delta_t = s.delta_t;
-            t += s.delta_t;
+            t = march_advance(t, s.delta_t);
             if (s.valid) {
                 load_row<K>(tr.features + (int64_t)s.idx * K, row);
                 if (row[K - 1] > 0.f) { active = true; idx = s.idx; }
@@ -499,7 +499,7 @@ render_bwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
                     accum += weight * total_color;
                 }
             }
-            t += s.delta_t;
+            t = march_advance(t, s.delta_t);
         }
         float total_grad = 0.f;
         for (int j = 0; j < C; ++j) total_grad += g[j];
@@ -536,7 +536,7 @@ render_bwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
                     atomicAdd(grad + (int64_t)s.idx * K + (K - 1), toadd);
                 }
             }
-            t += s.delta_t;
+            t = march_advance(t, s.delta_t);
         }
     }
 }
@@ -564,7 +564,7 @@ opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) 
                 if (light <= opt.stop_thresh) break;
             }
         }
-        t += s.delta_t;
+        t = march_advance(t, s.delta_t);
     }
     out[q] = 1.f - light;
 }
@@ -586,7 +586,7 @@ depth_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ depth) {
                 const float sigma = tr.features[(int64_t)s.idx * K + (K - 1)];
                 if (sigma > opt.sigma_thresh) { d = r.delta_scale * t; break; }
             }
-            t += s.delta_t;
+            t = march_advance(t, s.delta_t);
         }
     }
     depth[q] = d;
@@ -626,7 +626,7 @@ count_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, unsigned long long* __restr
                     if (light <= opt.stop_thresh) break;
                 }
             }
-            t += s.delta_t;
+            t = march_advance(t, s.delta_t);
         }
     }
     hit = wave_sum(hit); steps = wave_sum(steps); levels = wave_sum(levels);
