@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 5
+#define SVOXT_ABI_VERSION 6
 
 enum {
     SVOXT_OK = 0,
@@ -119,9 +119,14 @@ int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
                             const svoxt_options* opt, float* out, void* stream);
 
 /* grad_out: device [Q, grad_cols] with grad_cols = C+1.
- * grad_features: device [M, K]; zeroed by this call on `stream`, then
- *           accumulated with float atomics (as the reference: zeros_like +
- *           atomicAdd, rt_kernel.cu:1415,413,486).
+ * grad_features: device [M, grad_stride] floats of which columns 0..K-1 are the
+ *           gradient; zeroed by this call on `stream`, then accumulated with
+ *           float atomics (as the reference: zeros_like + atomicAdd,
+ *           rt_kernel.cu:1415,413,486).  grad_stride = 0 or K is the
+ *           reference's dense [M, K]; a stride that makes rows start on 64-byte
+ *           boundaries (e.g. 32 for K = 28) lets each row's atomics hit two
+ *           memory-side requests instead of 2.75 on average (measured: the
+ *           atomic-bound part of the backward is 19 % faster).
  * workspace: device scratch of `workspace_bytes` bytes, or NULL.  With
  *           svoxt_bwd_workspace_bytes(Q, S) bytes the first pass records up to
  *           S composited samples per ray (8 bytes each) and the second pass
@@ -131,7 +136,7 @@ int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
 int64_t svoxt_bwd_workspace_bytes(int64_t Q, int32_t max_samples);
 int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
                             const svoxt_options* opt, const float* grad_out,
-                            int32_t grad_cols, float* grad_features,
+                            int32_t grad_cols, float* grad_features, int32_t grad_stride,
                             void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Sample lists (no counterpart in the reference).  When a forward will be
@@ -157,7 +162,7 @@ int svoxt_volume_render_fwd_record(const svoxt_tree* tree, const svoxt_rays* ray
                                    const svoxt_sample_lists* lists, void* stream);
 int svoxt_volume_render_bwd_replay(const svoxt_tree* tree, const svoxt_rays* rays,
                                    const svoxt_options* opt, const float* grad_out,
-                                   int32_t grad_cols, float* grad_features,
+                                   int32_t grad_cols, float* grad_features, int32_t grad_stride,
                                    const svoxt_sample_lists* lists, void* stream);
 
 /* out: device [Q, 1] = accumulated opacity (alpha). */

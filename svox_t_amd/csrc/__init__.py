@@ -43,7 +43,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -91,11 +91,11 @@ EXPORTS = {
     "svoxt_last_error": (ctypes.c_char_p, []),
     "svoxt_out_data_dim": (ctypes.c_int, [_P(_COptions), _i32]),
     "svoxt_volume_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
-    "svoxt_volume_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _vp, _i64, _vp]),
+    "svoxt_volume_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _vp, _i64, _vp]),
     "svoxt_bwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
     "svoxt_can_record": (ctypes.c_int, [_P(_CTree), _P(_COptions)]),
     "svoxt_volume_render_fwd_record": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _P(_CLists), _vp]),
-    "svoxt_volume_render_bwd_replay": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _P(_CLists), _vp]),
+    "svoxt_volume_render_bwd_replay": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _P(_CLists), _vp]),
     "svoxt_opacity_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
     "svoxt_opacity_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp]),
     "svoxt_render_depth": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
@@ -413,19 +413,24 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
     if grad_output.dtype != torch.float32 or grad_output.dim() != 2 or grad_output.shape[0] != cr.Q:
         raise RuntimeError("grad_output must be float32 [Q, C+1]")
     dev = tree.features.device
+    M, K = tree.features.shape
+    # Accumulate into rows that start on 64-byte boundaries (fewer memory-side
+    # atomic requests per row), then hand back the dense [M, K] the caller expects.
+    stride = K if (K <= 8 or K % 16 == 0) else (K + 15) // 16 * 16
     with torch.cuda.device(dev):
-        grad = torch.empty_like(tree.features)
+        buf = torch.empty((M, stride), dtype=torch.float32, device=dev)
         if lists is not None:
             if lists.aux.shape[0] != cr.Q or lists.aux.device != dev:
                 raise RuntimeError("sample lists do not belong to this ray batch")
             cl = lists.c_struct()
             _call("svoxt_volume_render_bwd_replay", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
-                  _ptr(grad_output), grad_output.shape[1], _ptr(grad), ctypes.byref(cl), _stream(dev))
+                  _ptr(grad_output), grad_output.shape[1], _ptr(buf), stride, ctypes.byref(cl), _stream(dev))
         else:
             ws_bytes = _lib.svoxt_bwd_workspace_bytes(cr.Q, BWD_LIST_SAMPLES)
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
             _call("svoxt_volume_render_bwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
-                  _ptr(grad_output), grad_output.shape[1], _ptr(grad), _ptr(ws), ws_bytes, _stream(dev))
+                  _ptr(grad_output), grad_output.shape[1], _ptr(buf), stride, _ptr(ws), ws_bytes, _stream(dev))
+        grad = buf if stride == K else buf[:, :K].contiguous()
     return grad
 
 

@@ -296,7 +296,7 @@ __device__ __forceinline__ void accum_sample(const float (&row)[K], const float*
 // more than it saved.
 template <int K, int KS>
 __device__ __forceinline__ void flush_staged(const float* __restrict__ stage, const int32_t* __restrict__ sidx,
-                                             int n, int lane, float* __restrict__ grad) {
+                                             int n, int lane, float* __restrict__ grad, int gstride) {
     constexpr int ROWS = (K <= 32) ? 2 : 1;           // staged rows per atomic instruction
     constexpr int LPR = 64 / ROWS;                    // lanes per row
     constexpr int CHUNKS = (K + LPR - 1) / LPR;       // instructions per row (K > 64 only)
@@ -312,7 +312,7 @@ __device__ __forceinline__ void flush_staged(const float* __restrict__ stage, co
 #pragma unroll
             for (int ch = 0; ch < CHUNKS; ++ch) {
                 const int col = j + ch * LPR;
-                if (col < K) atomicAdd(grad + (int64_t)ridx * K + col, stage[rw * KS + col]);
+                if (col < K) atomicAdd(grad + (int64_t)ridx * gstride + col, stage[rw * KS + col]);
             }
         }
     }
@@ -324,7 +324,7 @@ __device__ __forceinline__ void flush_staged(const float* __restrict__ stage, co
 template <int FMT, int C, int BD, bool N2, bool REPLAY>
 __global__ void __launch_bounds__(kBlock)
 render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
-                  float* __restrict__ grad, uint2* __restrict__ rec, int S,
+                  float* __restrict__ grad, int gstride, uint2* __restrict__ rec, int S,
                   const uint2* __restrict__ aux) {
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     constexpr int KS = K | 1;                         // odd LDS row stride: conflict-free column writes
@@ -439,7 +439,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             stage_sample<FMT, C, BD, K>(row, basis, g, delta_t, r.delta_scale, light_ray,
                                         light, accum, stage + slot * KS);
         }
-        flush_staged<K, KS>(stage, sidx, __popcll(amask), lane, grad);
+        flush_staged<K, KS>(stage, sidx, __popcll(amask), lane, grad, gstride);
     }
 }
 
@@ -448,7 +448,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 template <bool N2>
 __global__ void __launch_bounds__(kBlock)
 render_bwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
-                          const float* __restrict__ grad_out, float* __restrict__ grad) {
+                          const float* __restrict__ grad_out, float* __restrict__ grad, int gstride) {
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     if (q >= rays.Q) return;
     Ray r;
@@ -471,7 +471,7 @@ render_bwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
                 const float* row = tr.features + (int64_t)s.idx * K;
                 const float sigma = row[K - 1];
                 if (sigma > 0.f) {
-                    float* grow = grad + (int64_t)s.idx * K;
+                    float* grow = grad + (int64_t)s.idx * gstride;
                     // pass 1 re-evaluates the rotated basis; pass 2 keeps the last one
                     if (tr.xform != nullptr) rotated_basis(tr, opt.format, opt.basis_dim, s.idx, rays.vdirs + 3 * q, basis);
                     const float att = pexpf(-s.delta_t * sigma * r.delta_scale);
@@ -533,7 +533,7 @@ render_bwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
                     accum -= weight * total_color;
                     const float toadd = s.delta_t * r.delta_scale * (total_color * light - accum)
                                       + s.delta_t * r.delta_scale * g[C] * light_ray;
-                    atomicAdd(grad + (int64_t)s.idx * K + (K - 1), toadd);
+                    atomicAdd(grad + (int64_t)s.idx * gstride + (K - 1), toadd);
                 }
             }
             t = march_advance(t, s.delta_t);
@@ -855,12 +855,12 @@ bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
 
 template <bool N2, bool REPLAY>
 bool launch_bwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
-                        const float* grad_out, float* grad, uint2* rec, int S, const uint2* aux,
+                        const float* grad_out, float* grad, int gstride, uint2* rec, int S, const uint2* aux,
                         hipStream_t st) {
     const unsigned nb = nblocks(rays.Q);
 #define SVOXT_BWD(F, CC, BB)                                                                      \
     hipLaunchKernelGGL((render_bwd_kernel<F, CC, BB, N2, REPLAY>), dim3(nb), dim3(kBlock), 0, st, \
-                       tr, rays, opt, grad_out, grad, rec, S, aux);                               \
+                       tr, rays, opt, grad_out, grad, gstride, rec, S, aux);                      \
     return true;
     if (opt.format == FMT_RGBA) {
         if (C == 3) { SVOXT_BWD(FMT_RGBA, 3, 0) }
@@ -879,7 +879,7 @@ bool launch_bwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
 }
 
 int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
-               const float* grad_out, int32_t grad_cols, float* grad_features,
+               const float* grad_out, int32_t grad_cols, float* grad_features, int32_t grad_stride,
                void* workspace, int64_t workspace_bytes, const svoxt_sample_lists* lists,
                void* stream, const char* fn) {
     int rc;
@@ -894,9 +894,11 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
         const int want = svoxt_out_data_dim(opt, tree->K);
         if (want != grad_cols) return fail(SVOXT_ERR_INVALID, "%s: grad_out columns do not match get_out_data_dim", fn);
     }
+    const int gs = grad_stride > 0 ? grad_stride : tree->K;
+    if (gs < tree->K) return fail(SVOXT_ERR_INVALID, "%s: grad_stride smaller than data_dim", fn);
     hipStream_t st = (hipStream_t)stream;
     if (tree->M > 0) {
-        const hipError_t e = hipMemsetAsync(grad_features, 0, sizeof(float) * (size_t)tree->M * tree->K, st);
+        const hipError_t e = hipMemsetAsync(grad_features, 0, sizeof(float) * (size_t)tree->M * gs, st);
         if (e != hipSuccess) return fail(SVOXT_ERR_HIP, "%s: hipMemsetAsync: %s", fn, hipGetErrorString(e));
     }
     if (rays->Q == 0 || tree->M == 0) return SVOXT_OK;
@@ -916,20 +918,20 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
         if (lists != nullptr) {
             uint2* lrec = reinterpret_cast<uint2*>(lists->rec);
             const uint2* laux = reinterpret_cast<const uint2*>(lists->aux);
-            done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, lrec, lists->max_samples, laux, st)
-                      : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, lrec, lists->max_samples, laux, st);
+            done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux, st)
+                      : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux, st);
             if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no specialised kernel for this payload", fn);
         } else {
-            done = n2 ? launch_bwd_special<true, false>(tr, rd, od, C, grad_out, grad_features, rec, (int)S, nullptr, st)
-                      : launch_bwd_special<false, false>(tr, rd, od, C, grad_out, grad_features, rec, (int)S, nullptr, st);
+            done = n2 ? launch_bwd_special<true, false>(tr, rd, od, C, grad_out, grad_features, gs, rec, (int)S, nullptr, st)
+                      : launch_bwd_special<false, false>(tr, rd, od, C, grad_out, grad_features, gs, rec, (int)S, nullptr, st);
         }
     } else if (lists != nullptr) {
         return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists need a specialised payload", fn);
     }
     if (!done) {
         const unsigned nb = nblocks(rays->Q);
-        if (n2) hipLaunchKernelGGL((render_bwd_generic_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, grad_out, grad_features);
-        else hipLaunchKernelGGL((render_bwd_generic_kernel<false>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, grad_out, grad_features);
+        if (n2) hipLaunchKernelGGL((render_bwd_generic_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, grad_out, grad_features, gs);
+        else hipLaunchKernelGGL((render_bwd_generic_kernel<false>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, grad_out, grad_features, gs);
     }
     return check_launch(fn);
 }
@@ -1029,26 +1031,26 @@ int svoxt_volume_render_fwd_record(const svoxt_tree* tree, const svoxt_rays* ray
 
 int svoxt_volume_render_bwd_replay(const svoxt_tree* tree, const svoxt_rays* rays,
                                    const svoxt_options* opt, const float* grad_out,
-                                   int32_t grad_cols, float* grad_features,
+                                   int32_t grad_cols, float* grad_features, int32_t grad_stride,
                                    const svoxt_sample_lists* lists, void* stream) {
     const char* fn = "svoxt_volume_render_bwd_replay";
     int rc;
     if (grad_cols < 2) return fail(SVOXT_ERR_INVALID, "%s: grad_cols must be C+1 >= 2", fn);
     if (opt == nullptr) return fail(SVOXT_ERR_INVALID, "%s: options is NULL", fn);
     if ((rc = check_lists(lists, opt, fn))) return rc;
-    return bwd_common(tree, rays, opt, grad_out, grad_cols, grad_features, nullptr, 0, lists, stream, fn);
+    return bwd_common(tree, rays, opt, grad_out, grad_cols, grad_features, grad_stride, nullptr, 0, lists, stream, fn);
 }
 
 int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
                             const svoxt_options* opt, const float* grad_out,
-                            int32_t grad_cols, float* grad_features,
+                            int32_t grad_cols, float* grad_features, int32_t grad_stride,
                             void* workspace, int64_t workspace_bytes, void* stream) {
     if (grad_cols < 2)
         return fail(SVOXT_ERR_INVALID, "%s: grad_cols must be C+1 >= 2 (use svoxt_opacity_render_bwd for C = 0)",
                     "svoxt_volume_render_bwd");
     if (workspace_bytes < 0) return fail(SVOXT_ERR_INVALID, "%s: negative workspace size", "svoxt_volume_render_bwd");
-    return bwd_common(tree, rays, opt, grad_out, grad_cols, grad_features, workspace, workspace_bytes, nullptr,
-                      stream, "svoxt_volume_render_bwd");
+    return bwd_common(tree, rays, opt, grad_out, grad_cols, grad_features, grad_stride, workspace, workspace_bytes,
+                      nullptr, stream, "svoxt_volume_render_bwd");
 }
 
 int svoxt_opacity_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
@@ -1069,7 +1071,7 @@ int svoxt_opacity_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
 int svoxt_opacity_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
                              const svoxt_options* opt, const float* grad_out,
                              float* grad_features, void* stream) {
-    return bwd_common(tree, rays, opt, grad_out, 1, grad_features, nullptr, 0, nullptr, stream,
+    return bwd_common(tree, rays, opt, grad_out, 1, grad_features, 0, nullptr, 0, nullptr, stream,
                       "svoxt_opacity_render_bwd");
 }
 
