@@ -165,6 +165,10 @@ int svoxt_volume_render_bwd_replay(const svoxt_tree* tree, const svoxt_rays* ray
                                    int32_t grad_cols, float* grad_features, int32_t grad_stride,
                                    const svoxt_sample_lists* lists, void* stream);
 
+/* Copy the first K columns of src [M, stride] into dense dst [M, K] (streaming,
+ * non-temporal): turns a strided gradient buffer into the reference's layout. */
+int svoxt_compact_rows(const float* src, int64_t M, int32_t K, int32_t stride, float* dst, void* stream);
+
 /* out: device [Q, 1] = accumulated opacity (alpha). */
 int svoxt_opacity_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
                              const svoxt_options* opt, float* out, void* stream);

@@ -94,6 +94,7 @@ EXPORTS = {
     "svoxt_volume_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _vp, _i64, _vp]),
     "svoxt_bwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
     "svoxt_can_record": (ctypes.c_int, [_P(_CTree), _P(_COptions)]),
+    "svoxt_compact_rows": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "svoxt_volume_render_fwd_record": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _P(_CLists), _vp]),
     "svoxt_volume_render_bwd_replay": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _P(_CLists), _vp]),
     "svoxt_opacity_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
@@ -430,7 +431,11 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
             _call("svoxt_volume_render_bwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(grad_output), grad_output.shape[1], _ptr(buf), stride, _ptr(ws), ws_bytes, _stream(dev))
-        grad = buf if stride == K else buf[:, :K].contiguous()
+        if stride == K:
+            grad = buf
+        else:
+            grad = torch.empty((M, K), dtype=torch.float32, device=dev)
+            _call("svoxt_compact_rows", _ptr(buf), M, K, stride, _ptr(grad), _stream(dev))
     return grad
 
 

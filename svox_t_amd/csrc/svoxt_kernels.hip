@@ -703,6 +703,21 @@ query_bwd_kernel(TreeDev tr, const float* __restrict__ points, int64_t Q,
 }
 
 // ---------------------------------------------------------------------------
+// [M, stride] -> dense [M, K] (the backward accumulates into 64-byte-aligned rows)
+// ---------------------------------------------------------------------------
+
+// streaming copy: non-temporal both ways, the data is not re-read by these kernels
+template <typename V>
+__global__ void __launch_bounds__(kBlock)
+compact_rows_kernel(const V* __restrict__ src, int64_t n, int Kv, int stride_v, V* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / Kv;
+        const int c = (int)(i - r * Kv);
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + r * stride_v + c), dst + i);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Acceleration grid build (N == 2): one thread per cell, see locate_accel()
 // ---------------------------------------------------------------------------
 
@@ -1160,6 +1175,25 @@ int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
 int64_t svoxt_bwd_workspace_bytes(int64_t Q, int32_t max_samples) {
     if (Q < 0 || max_samples < 0) return -1;
     return Q * (int64_t)max_samples * 8;
+}
+
+int svoxt_compact_rows(const float* src, int64_t M, int32_t K, int32_t stride, float* dst, void* stream) {
+    const char* fn = "svoxt_compact_rows";
+    if (M < 0 || K < 1 || stride < K) return fail(SVOXT_ERR_INVALID, "%s: bad extents", fn);
+    if (M == 0) return SVOXT_OK;
+    if (src == nullptr || dst == nullptr) return fail(SVOXT_ERR_INVALID, "%s: src / dst is NULL", fn);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const bool vec = K % 4 == 0 && stride % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0);
+    const int64_t n = vec ? M * (K / 4) : M * K;
+    const int64_t want = (n + kBlock - 1) / kBlock;
+    const unsigned nb = (unsigned)(want < 16384 ? want : 16384);
+    if (vec)
+        hipLaunchKernelGGL((compact_rows_kernel<v4f>), dim3(nb), dim3(kBlock), 0, (hipStream_t)stream,
+                           reinterpret_cast<const v4f*>(src), n, (int)(K / 4), (int)(stride / 4), reinterpret_cast<v4f*>(dst));
+    else
+        hipLaunchKernelGGL((compact_rows_kernel<float>), dim3(nb), dim3(kBlock), 0, (hipStream_t)stream,
+                           src, n, (int)K, (int)stride, dst);
+    return check_launch(fn);
 }
 
 int64_t svoxt_accel_bytes(int32_t log2_res) {
