@@ -192,7 +192,7 @@ def main():
         if args.forward_only or fwd_ms >= bwd_ms:
             dom, dom_ms, dom_bytes = "render_fwd_kernel", fwd_ms, bytes_fwd
         else:
-            dom, dom_ms, dom_bytes = "render_bwd_kernel (+ grad memset)", bwd_ms, bytes_bwd
+            dom, dom_ms, dom_bytes = "render_bwd_kernel (+ grad memset, row compaction)", bwd_ms, bytes_bwd
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic, traffic_note = pmc_traffic("fwd" if dom.startswith("render_fwd") else "bwd") \
             if args.workload == "d8_sh9_800" and world == 1 else (None, "PMC profile exists for the default workload at N=1 only")
