@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 6
+#define SVOXT_ABI_VERSION 7
 
 enum {
     SVOXT_OK = 0,
@@ -152,7 +152,7 @@ int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
  * recorded with. */
 typedef struct svoxt_sample_lists {
     void*   rec;           /* device, max_samples * Q * 8 bytes */
-    void*   aux;           /* device, Q * 8 bytes */
+    void*   aux;           /* device, Q * 16 bytes: count | overflow, resume point, final transmittance, pad */
     int32_t max_samples;   /* S, 1..4096 */
 } svoxt_sample_lists;
 
@@ -163,7 +163,15 @@ int svoxt_volume_render_fwd_record(const svoxt_tree* tree, const svoxt_rays* ray
 int svoxt_volume_render_bwd_replay(const svoxt_tree* tree, const svoxt_rays* rays,
                                    const svoxt_options* opt, const float* grad_out,
                                    int32_t grad_cols, float* grad_features, int32_t grad_stride,
-                                   const svoxt_sample_lists* lists, void* stream);
+                                   const svoxt_sample_lists* lists, const float* fwd_out, void* stream);
+/* fwd_out: device [Q, C+1] = the output svoxt_volume_render_fwd_record produced
+ * with these lists, or NULL.  NULL: two list walks per ray, every gradient
+ * contribution bit-identical to the reference's formulas.  Given: ONE walk --
+ * the reference's first pass only computes accum = sum_c g_c * out_c and the
+ * final transmittance, both known from the forward; the value of accum then
+ * differs from the sequentially accumulated one by float rounding (~1e-7 of the
+ * summed magnitudes), which reaches the sigma column only (well inside the 1e-5
+ * parity tolerance); colour gradients stay bit-identical. */
 
 /* Copy the first K columns of src [M, stride] into dense dst [M, K] (streaming,
  * non-temporal): turns a strided gradient buffer into the reference's layout. */

@@ -43,7 +43,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -96,7 +96,7 @@ EXPORTS = {
     "svoxt_can_record": (ctypes.c_int, [_P(_CTree), _P(_COptions)]),
     "svoxt_compact_rows": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "svoxt_volume_render_fwd_record": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _P(_CLists), _vp]),
-    "svoxt_volume_render_bwd_replay": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _P(_CLists), _vp]),
+    "svoxt_volume_render_bwd_replay": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _P(_CLists), _vp, _vp]),
     "svoxt_opacity_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
     "svoxt_opacity_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp]),
     "svoxt_render_depth": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
@@ -374,7 +374,7 @@ class SampleLists:
 
     def __init__(self, Q, S, device):
         self.rec = torch.empty((S, Q, 2), dtype=torch.int32, device=device)
-        self.aux = torch.empty((Q, 2), dtype=torch.int32, device=device)
+        self.aux = torch.empty((Q, 4), dtype=torch.int32, device=device)
         self.S = S
 
     def c_struct(self):
@@ -405,10 +405,19 @@ def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bo
     return (out, lists) if record else out
 
 
+# SVOXT_BWD_EXACT=1: never use the forward output in the backward (two list walks,
+# every contribution bit-identical to the reference formulas; ~0.2 ms slower on
+# the headline workload).
+BWD_EXACT = os.environ.get("SVOXT_BWD_EXACT", "0") not in ("", "0")
+
+
 def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
-                           grad_output: torch.Tensor, lists: SampleLists = None) -> torch.Tensor:
+                           grad_output: torch.Tensor, lists: SampleLists = None,
+                           fwd_output: torch.Tensor = None) -> torch.Tensor:
     """rt_kernel.cu:1402-1426.  `lists` (optional, not in the reference): what
-    volume_render(..., record=True) returned for the same tree / rays / options."""
+    volume_render(..., record=True) returned for the same tree / rays / options;
+    `fwd_output` (optional): the output of that forward, which saves the
+    backward its first pass (include/svoxt.h, svoxt_volume_render_bwd_replay)."""
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     _check_input(grad_output, "grad_output")
     if grad_output.dtype != torch.float32 or grad_output.dim() != 2 or grad_output.shape[0] != cr.Q:
@@ -424,8 +433,15 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
             if lists.aux.shape[0] != cr.Q or lists.aux.device != dev:
                 raise RuntimeError("sample lists do not belong to this ray batch")
             cl = lists.c_struct()
+            fo = None
+            if fwd_output is not None and not BWD_EXACT:
+                _check_input(fwd_output, "fwd_output")
+                if fwd_output.shape != grad_output.shape or fwd_output.dtype != torch.float32:
+                    raise RuntimeError("fwd_output must match grad_output")
+                fo = fwd_output
             _call("svoxt_volume_render_bwd_replay", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
-                  _ptr(grad_output), grad_output.shape[1], _ptr(buf), stride, ctypes.byref(cl), _stream(dev))
+                  _ptr(grad_output), grad_output.shape[1], _ptr(buf), stride, ctypes.byref(cl), _ptr(fo),
+                  _stream(dev))
         else:
             ws_bytes = _lib.svoxt_bwd_workspace_bytes(cr.Q, BWD_LIST_SAMPLES)
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes > 0 else None

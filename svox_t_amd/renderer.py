@@ -91,13 +91,16 @@ class _VolumeRenderFunction(autograd.Function):
         ctx.tree = tree
         ctx.rays = rays
         ctx.opt = opt
+        if ctx.lists is not None:
+            ctx.save_for_backward(out)      # with the lists it spares the backward its first pass
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         if ctx.needs_input_grad[0]:
+            fwd_out = ctx.saved_tensors[0] if ctx.lists is not None else None
             return _C.volume_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out.contiguous(),
-                                             lists=ctx.lists), None, None, None
+                                             lists=ctx.lists, fwd_output=fwd_out), None, None, None
         return None, None, None, None
 
 

@@ -98,7 +98,7 @@ def test_counters_match_oracle(case, gpu):
 
 
 @pytest.mark.parametrize("list_samples", [0, 1, 3, 64])
-@pytest.mark.parametrize("from_forward", [True, False])
+@pytest.mark.parametrize("from_forward", [True, False, "exact"])
 def test_backward_sample_list_capacity_does_not_change_results(gpu, list_samples, from_forward, monkeypatch):
     """The backward records up to S samples per ray in pass 1 and replays them in
     pass 2; rays with more samples march the rest.  Any S gives the same
@@ -106,6 +106,9 @@ def test_backward_sample_list_capacity_does_not_change_results(gpu, list_samples
     import svox_t_amd.csrc as _C
     from svox_t_amd import synth
     monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", list_samples)
+    # "exact": lists from the forward, but two list walks instead of using the
+    # forward's output for accum (SVOXT_BWD_EXACT=1)
+    monkeypatch.setattr(_C, "BWD_EXACT", from_forward == "exact")
     c = Case(depth=6, K=28, data_format="SH9", width=96, height=96)
     tree = c.tree(gpu)
     r = svox.VolumeRenderer(tree)
