@@ -16,6 +16,12 @@
  *                             <- TreeSpec / RaysSpec / RenderOptions
  *                                                         svox_t/csrc/include/data_spec.hpp:52-145
  *
+ * Entry points without a counterpart in the reference, all optional and
+ * result-neutral (a caller that ignores them gets the same numbers, slower):
+ *   svoxt_accel_build / svoxt_accel_bytes            cached prefix of the root descent
+ *   svoxt_volume_render_fwd_record / _bwd_replay     backward without tree traversal
+ *   svoxt_can_record, svoxt_bwd_workspace_bytes, svoxt_compact_rows, svoxt_count_fwd
+ *
  * Conventions
  *   - Every pointer marked "device" is HBM memory of the current HIP device;
  *     the caller owns all buffers (inputs are borrowed, outputs are written in

@@ -1,12 +1,24 @@
 // svoxt_kernels.hip -- hand-written CDNA4 (gfx950) kernels for svox_t's
 // volume-render hot path and the C ABI declared in include/svoxt.h.
 //
-// Mapping: one ray per wavefront lane, 256-thread workgroups (4 waves).  The
-// per-ray output accumulators live in registers for the specialised payloads
-// (RGBA C=3 / C=31, SH with 1/4/9/16/25 basis functions x 3 channels) and in
-// global memory only for the generic fallback (any K / SG / ASG / component
-// sub-ranges), which mirrors the reference's read-modify-write of `out`
-// (svox_t/csrc/rt_kernel.cu:300,304).
+// Mapping: one ray per wavefront lane, 256-thread workgroups (4 waves); a
+// wavefront takes 64 consecutive rays, or an 8x8 pixel tile when the caller says
+// the batch is an image.  The per-ray output accumulators live in registers for
+// the specialised payloads (RGBA C=3 / C=31, SH with 1/4/9/16/25 basis functions
+// x 3 channels) and in global memory only for the generic fallback (any K / SG /
+// ASG / component sub-ranges / per-leaf view rotations), which mirrors the
+// reference's read-modify-write of `out` (svox_t/csrc/rt_kernel.cu:300,304).
+//
+// Kernels, in file order:
+//   render_fwd_kernel          trace_ray; optionally records each ray's composited samples
+//   render_fwd_generic_kernel  fallback forward
+//   render_bwd_kernel          trace_ray_backward: replays recorded samples (or marches),
+//                              stages gradient rows in LDS, flushes them as shaped atomics
+//   render_bwd_generic_kernel  fallback backward (reference-style per-lane atomics)
+//   opacity_fwd_kernel, depth_kernel, count_fwd_kernel
+//   query_fwd_kernel, query_bwd_kernel
+//   compact_rows_kernel, accel_build_kernel
+// The design rationale and the measurements behind each choice are in DESIGN.md 5.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
 
