@@ -14,7 +14,8 @@
 //   render_fwd_generic_kernel  fallback forward
 //   render_bwd_kernel          trace_ray_backward: replays recorded samples (or marches),
 //                              stages gradient rows in LDS, flushes them as shaped atomics
-//   render_bwd_generic_kernel  fallback backward (reference-style per-lane atomics)
+//   render_bwd_generic_kernel  fallback backward, per-lane atomics (opacity backward, K > 64)
+//   render_bwd_generic_staged_kernel  fallback backward with LDS-staged, shaped atomics
 //   opacity_fwd_kernel, depth_kernel, count_fwd_kernel
 //   query_fwd_kernel, query_bwd_kernel
 //   compact_rows_kernel, accel_build_kernel
@@ -584,6 +585,143 @@ render_bwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
     }
 }
 
+// Generic backward with shaped atomics: the same two steps as the specialised
+// kernel -- a first march that only builds `accum`, a wave-synchronous second
+// march that stages each sample's K gradient values in LDS and flushes rows
+// cooperatively -- for any K <= 61, any format, component sub-range and per-leaf
+// view rotation.  Staging lives in dynamic LDS: (kBlock/64) * 64 * (K|1) floats
+// + kBlock row indices.
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+render_bwd_generic_staged_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
+                                 const float* __restrict__ grad_out, float* __restrict__ grad, int gstride) {
+    extern __shared__ float dyn_lds[];
+    const int K = tr.K;
+    const int KS = K | 1;
+    const int lane = threadIdx.x & 63;
+    float* stage = dyn_lds + (threadIdx.x >> 6) * (64 * KS);
+    int32_t* sidx = reinterpret_cast<int32_t*>(dyn_lds + (kBlock / 64) * 64 * KS) + (threadIdx.x >> 6) * 64;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+    Ray r;
+    bool alive = q < rays.Q;
+    if (alive) alive = setup_ray(tr, rays, q, r);
+    if (!__any(alive)) return;
+    const float* g = grad_out + (alive ? q : 0) * (C + 1);
+    const float* vd = rays.vdirs + 3 * (alive ? q : 0);
+    const bool rgba = opt.format == FMT_RGBA;
+    float basis[25];       // basis of the current sample (re-evaluated per sample with view rotations)
+    float basis2[25];      // basis pass 2 of the reference sees: the one pass 1 ended with
+    float accum = 0.f, light_ray = 1.f;
+    if (alive) {
+        precalc_basis<0>(opt.format, opt.basis_dim, tr, vd[0], vd[1], vd[2], basis);
+        float light = 1.f, t = r.tmin;
+        while (t < r.tmax) {                               // march 1 (rt_kernel.cu:365-437 minus the atomics)
+            Sample s;
+            march_step<N2>(tr, r, opt.step_size, t, s);
+            if (s.valid) {
+                const float* row = tr.features + (int64_t)s.idx * K;
+                const float sigma = row[K - 1];
+                if (sigma > 0.f) {
+                    if (tr.xform != nullptr) rotated_basis(tr, opt.format, opt.basis_dim, s.idx, vd, basis);
+                    const float att = pexpf(-s.delta_t * sigma * r.delta_scale);
+                    const float weight = light * (1.f - att);
+                    float total_color = 0.f;
+                    for (int c = 0; c < C; ++c) {
+                        float x;
+                        if (rgba) {
+                            x = row[c];
+                        } else {
+                            x = 0.f;
+                            for (int i = opt.min_comp; i <= opt.max_comp; ++i) x += basis[i] * row[c * opt.basis_dim + i];
+                        }
+                        total_color += (float)(1.0 / (1.0 + (double)pexpf(-x))) * g[c];
+                    }
+                    light *= att;
+                    accum += weight * total_color;
+                }
+            }
+            t = march_advance(t, s.delta_t);
+        }
+        float total_grad = 0.f;
+        for (int j = 0; j < C; ++j) total_grad += g[j];
+        accum += light * opt.background_brightness * total_grad;
+        light_ray = light;
+        for (int i = 0; i < 25; ++i) basis2[i] = basis[i];
+    }
+    // march 2, wave-synchronous (rt_kernel.cu:439-494 plus the colour terms of :408-425)
+    float light = 1.f;
+    float t = alive ? r.tmin : 0.f;
+    const float tmax = alive ? r.tmax : -1.f;
+    const int ROWS = (K <= 32) ? 2 : 1;
+    const int LPR = 64 / ROWS;
+    while (__any(t < tmax)) {
+        bool active = false;
+        int32_t idx = -1;
+        Sample s;
+        const float* row = nullptr;
+        if (t < tmax) {
+            march_step<N2>(tr, r, opt.step_size, t, s);
+            t = march_advance(t, s.delta_t);
+            if (s.valid) {
+                row = tr.features + (int64_t)s.idx * K;
+                if (row[K - 1] > 0.f) { active = true; idx = s.idx; }
+            }
+        }
+        const unsigned long long amask = __ballot(active);
+        if (amask == 0ull) continue;
+        const int n = __popcll(amask);
+        if (active) {
+            const int slot = __popcll(amask & lane_lt);
+            sidx[slot] = idx;
+            float* st = stage + slot * KS;
+            for (int j = 0; j < K - 1; ++j) st[j] = 0.f;       // columns outside the component range stay 0
+            const float sigma = row[K - 1];
+            if (tr.xform != nullptr) rotated_basis(tr, opt.format, opt.basis_dim, idx, vd, basis);
+            const float att = pexpf(-s.delta_t * sigma * r.delta_scale);
+            const float weight = light * (1.f - att);
+            float total_color = 0.f;
+            for (int c = 0; c < C; ++c) {
+                if (rgba) {
+                    const double sd = 1.0 / (1.0 + (double)pexpf(-row[c]));
+                    const float sig = (float)sd;
+                    st[c] = weight * sig * (1.f - sig) * g[c];
+                    total_color = (float)((double)total_color + sd * (double)g[c]);
+                } else {
+                    const int off = c * opt.basis_dim;
+                    float x = 0.f, x2 = 0.f;
+                    for (int i = opt.min_comp; i <= opt.max_comp; ++i) {
+                        x += basis[i] * row[off + i];
+                        x2 += basis2[i] * row[off + i];
+                    }
+                    const float sig = (float)(1.0 / (1.0 + (double)pexpf(-x)));
+                    const float gsig = (float)((double)sig * (1.0 - (double)sig));
+                    for (int i = opt.min_comp; i <= opt.max_comp; ++i) st[off + i] = weight * basis[i] * gsig * g[c];
+                    total_color = (float)((double)total_color + 1.0 / (1.0 + (double)pexpf(-x2)) * (double)g[c]);
+                }
+            }
+            light *= att;
+            accum -= weight * total_color;
+            st[K - 1] = s.delta_t * r.delta_scale * (total_color * light - accum)
+                      + s.delta_t * r.delta_scale * g[C] * light_ray;
+        }
+        // cooperative flush: contiguous K-float segments per atomic instruction
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int half = (ROWS == 2) ? (lane >> 5) : 0;
+        const int j = (ROWS == 2) ? (lane & 31) : lane;
+        for (int base = 0; base < n; base += ROWS) {
+            const int rw = base + half;
+            if (rw < n) {
+                const int32_t ridx = sidx[rw];
+                for (int col = j; col < K; col += LPR)
+                    atomicAdd(grad + (int64_t)ridx * gstride + col, stage[rw * KS + col]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Opacity (rt_kernel.cu:500-560, :1110-1126) and depth (:782-834, :866-882)
 // ---------------------------------------------------------------------------
@@ -988,8 +1126,15 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
     }
     if (!done) {
         const unsigned nb = nblocks(rays->Q);
-        if (n2) hipLaunchKernelGGL((render_bwd_generic_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, grad_out, grad_features, gs);
-        else hipLaunchKernelGGL((render_bwd_generic_kernel<false>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, grad_out, grad_features, gs);
+        const size_t lds = (size_t)(kBlock / 64) * 64 * (tree->K | 1) * sizeof(float) + kBlock * sizeof(int32_t);
+        if (C > 0 && lds <= 65536) {      // shaped atomics through LDS staging (default dynamic-LDS limit: 64 KiB)
+            if (n2) hipLaunchKernelGGL((render_bwd_generic_staged_kernel<true>), dim3(nb), dim3(kBlock), lds, st, tr, rd, od, C, grad_out, grad_features, gs);
+            else hipLaunchKernelGGL((render_bwd_generic_staged_kernel<false>), dim3(nb), dim3(kBlock), lds, st, tr, rd, od, C, grad_out, grad_features, gs);
+        } else {
+            // C == 0 (opacity: one value per sample, nothing to shape) or rows too wide to stage
+            if (n2) hipLaunchKernelGGL((render_bwd_generic_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, grad_out, grad_features, gs);
+            else hipLaunchKernelGGL((render_bwd_generic_kernel<false>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, grad_out, grad_features, gs);
+        }
     }
     return check_launch(fn);
 }
