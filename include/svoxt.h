@@ -20,7 +20,8 @@
  * result-neutral (a caller that ignores them gets the same numbers, slower):
  *   svoxt_accel_build / svoxt_accel_bytes            cached prefix of the root descent
  *   svoxt_volume_render_fwd_record / _bwd_replay     backward without tree traversal
- *   svoxt_can_record, svoxt_bwd_workspace_bytes, svoxt_compact_rows, svoxt_count_fwd
+ *   svoxt_can_record, svoxt_bwd_workspace_bytes, svoxt_compact_rows, svoxt_count_fwd,
+ *   svoxt_query_leaves (the reference's mask compaction, made deterministic)
  *
  * Conventions
  *   - Every pointer marked "device" is HBM memory of the current HIP device;
@@ -211,6 +212,15 @@ int svoxt_render_depth(const svoxt_tree* tree, const svoxt_rays* rays,
 int svoxt_query_fwd(const svoxt_tree* tree, const float* points, int64_t Q,
                     float* values, int64_t* node_ids, int64_t* data_ids,
                     uint8_t* hit_mask, void* stream);
+
+/* Unique-leaf list of a query (the reference's leaf_node, svox_kernel.cu:240-269,
+ * 304-320): compacts hit_mask [n_slots] into leaf_node [U, 4] int64 rows
+ * (node, u, v, w) in increasing packed-id order and writes U to *count (device).
+ * leaf_node must have room for min(Q, n_slots) rows; workspace:
+ * svoxt_query_leaves_workspace_bytes(n_slots) device bytes. */
+int64_t svoxt_query_leaves_workspace_bytes(int64_t n_slots);
+int svoxt_query_leaves(const uint8_t* hit_mask, int64_t n_slots, int32_t N, int64_t* leaf_node,
+                       int64_t* count, void* workspace, void* stream);
 
 /* grad_out: device [Q, K]; grad_features: device [M, K], zeroed by this call. */
 int svoxt_query_bwd(const svoxt_tree* tree, const float* points, int64_t Q,

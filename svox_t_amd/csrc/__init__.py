@@ -95,6 +95,8 @@ EXPORTS = {
     "svoxt_bwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
     "svoxt_can_record": (ctypes.c_int, [_P(_CTree), _P(_COptions)]),
     "svoxt_compact_rows": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "svoxt_query_leaves_workspace_bytes": (ctypes.c_int64, [_i64]),
+    "svoxt_query_leaves": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "svoxt_volume_render_fwd_record": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _P(_CLists), _vp]),
     "svoxt_volume_render_bwd_replay": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _P(_CLists), _vp, _vp]),
     "svoxt_opacity_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
@@ -523,12 +525,13 @@ def query_vertical(tree: TreeSpec, indices: torch.Tensor):
         mask = torch.zeros((ct.n_internal * N * N * N,), dtype=torch.uint8, device=dev)
         _call("svoxt_query_fwd", ctypes.byref(ct), _ptr(indices), Q, _ptr(values), _ptr(node_ids),
               _ptr(data_ids), _ptr(mask), _stream(dev))
-        packed = torch.nonzero(mask).squeeze(1)          # host sync, like the reference's .item() (:312)
-        w = packed % N
-        v = (packed // N) % N
-        u = (packed // (N * N)) % N
-        node = packed // (N * N * N)
-        leaf_node = torch.stack((node, u, v, w), dim=-1)
+        n_slots = mask.numel()
+        cap = min(Q, n_slots)
+        leaf_buf = torch.empty((cap, 4), dtype=torch.int64, device=dev)
+        count = torch.empty((1,), dtype=torch.int64, device=dev)
+        ws = torch.empty((_lib.svoxt_query_leaves_workspace_bytes(n_slots),), dtype=torch.uint8, device=dev)
+        _call("svoxt_query_leaves", _ptr(mask), n_slots, N, _ptr(leaf_buf), _ptr(count), _ptr(ws), _stream(dev))
+        leaf_node = leaf_buf[:int(count.item())]         # host sync, like the reference's .item() (:312)
     return values, node_ids, data_ids, leaf_node
 
 

@@ -872,6 +872,81 @@ query_bwd_kernel(TreeDev tr, const float* __restrict__ points, int64_t Q,
 }
 
 // ---------------------------------------------------------------------------
+// Unique-leaf list of a point query: compaction of the hit mask into
+// leaf_node[U, 4] = (node, u, v, w), sorted by packed leaf id.  The reference
+// numbers the hits with a float atomic counter (svox_kernel.cu:260-269: order
+// undefined, exact only below 2^24 leaves); here a three-step integer prefix
+// sum gives a deterministic order: per-segment counts, scan of the counts,
+// ranked scatter.
+// ---------------------------------------------------------------------------
+
+constexpr int kSeg = 1024;     // mask entries per workgroup (4 per thread)
+
+__global__ void __launch_bounds__(kBlock)
+leaves_count_kernel(const uint8_t* __restrict__ mask, int64_t n, int32_t* __restrict__ seg_count) {
+    __shared__ int32_t wsum[kBlock / 64];
+    const int64_t base = (int64_t)blockIdx.x * kSeg;
+    int c = 0;
+    for (int i = threadIdx.x; i < kSeg; i += kBlock) c += (base + i < n && mask[base + i]) ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) seg_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of seg_count[0..nseg) in place; total -> *count (one workgroup)
+__global__ void __launch_bounds__(kBlock)
+leaves_scan_kernel(int32_t* __restrict__ seg_count, int nseg, int64_t* __restrict__ count) {
+    __shared__ int32_t part[kBlock];
+    const int per = (nseg + kBlock - 1) / kBlock;
+    const int lo = threadIdx.x * per, hi = min(lo + per, nseg);
+    int32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += seg_count[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t run = 0;
+        for (int i = 0; i < kBlock; ++i) { const int32_t v = part[i]; part[i] = run; run += v; }
+        *count = run;
+    }
+    __syncthreads();
+    int32_t run = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { const int32_t v = seg_count[i]; seg_count[i] = run; run += v; }
+}
+
+__global__ void __launch_bounds__(kBlock)
+leaves_scatter_kernel(const uint8_t* __restrict__ mask, int64_t n, int N, const int32_t* __restrict__ seg_offset,
+                      int64_t* __restrict__ leaf_node) {
+    __shared__ int32_t wbase[kBlock / 64];
+    const int64_t base = (int64_t)blockIdx.x * kSeg;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t running = seg_offset[blockIdx.x];
+    // 4 rounds of 256 consecutive entries keep the output in increasing slot order
+    for (int rd = 0; rd < kSeg / kBlock; ++rd) {
+        const int64_t i = base + rd * kBlock + threadIdx.x;
+        const bool hit = i < n && mask[i] != 0;
+        const unsigned long long b = __ballot(hit);
+        if (lane == 0) wbase[wave] = __popcll(b);
+        __syncthreads();
+        int32_t before = 0, total = 0;
+        for (int w = 0; w < kBlock / 64; ++w) { if (w < wave) before += wbase[w]; total += wbase[w]; }
+        if (hit) {
+            const int64_t dst = running + before + __popcll(b & ((1ull << lane) - 1ull));
+            int64_t tmp = i;
+            const int64_t w3 = tmp % N; tmp /= N;
+            const int64_t v3 = tmp % N; tmp /= N;
+            const int64_t u3 = tmp % N; tmp /= N;
+            leaf_node[4 * dst + 0] = tmp;
+            leaf_node[4 * dst + 1] = u3;
+            leaf_node[4 * dst + 2] = v3;
+            leaf_node[4 * dst + 3] = w3;
+        }
+        running += total;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
 // [M, stride] -> dense [M, K] (the backward accumulates into 64-byte-aligned rows)
 // ---------------------------------------------------------------------------
 
@@ -1352,6 +1427,32 @@ int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
 int64_t svoxt_bwd_workspace_bytes(int64_t Q, int32_t max_samples) {
     if (Q < 0 || max_samples < 0) return -1;
     return Q * (int64_t)max_samples * 8;
+}
+
+int64_t svoxt_query_leaves_workspace_bytes(int64_t n_slots) {
+    if (n_slots < 0) return -1;
+    return (int64_t)sizeof(int32_t) * ((n_slots + kSeg - 1) / kSeg + 1);
+}
+
+int svoxt_query_leaves(const uint8_t* hit_mask, int64_t n_slots, int32_t N, int64_t* leaf_node,
+                       int64_t* count, void* workspace, void* stream) {
+    const char* fn = "svoxt_query_leaves";
+    if (n_slots < 0 || N < 2) return fail(SVOXT_ERR_INVALID, "%s: bad extents", fn);
+    if (count == nullptr) return fail(SVOXT_ERR_INVALID, "%s: count is NULL", fn);
+    hipStream_t st = (hipStream_t)stream;
+    if (n_slots == 0) {
+        const hipError_t e = hipMemsetAsync(count, 0, sizeof(int64_t), st);
+        return e == hipSuccess ? SVOXT_OK : fail(SVOXT_ERR_HIP, "%s: %s", fn, hipGetErrorString(e));
+    }
+    if (hit_mask == nullptr || leaf_node == nullptr || workspace == nullptr)
+        return fail(SVOXT_ERR_INVALID, "%s: hit_mask / leaf_node / workspace is NULL", fn);
+    const int64_t nseg = (n_slots + kSeg - 1) / kSeg;
+    if (nseg > 2147483647LL) return fail(SVOXT_ERR_INVALID, "%s: mask too large", fn);
+    int32_t* seg = reinterpret_cast<int32_t*>(workspace);
+    hipLaunchKernelGGL(leaves_count_kernel, dim3((unsigned)nseg), dim3(kBlock), 0, st, hit_mask, n_slots, seg);
+    hipLaunchKernelGGL(leaves_scan_kernel, dim3(1), dim3(kBlock), 0, st, seg, (int)nseg, count);
+    hipLaunchKernelGGL(leaves_scatter_kernel, dim3((unsigned)nseg), dim3(kBlock), 0, st, hit_mask, n_slots, (int)N, seg, leaf_node);
+    return check_launch(fn);
 }
 
 int svoxt_compact_rows(const float* src, int64_t M, int32_t K, int32_t stride, float* dst, void* stream) {
