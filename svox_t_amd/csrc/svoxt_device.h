@@ -278,9 +278,9 @@ __device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float 
 
 struct Sample {
     Leaf leaf;
-    int32_t idx;       // feature row, valid iff (int64)idx < M (negative = empty too? no: see below)
-    float delta_t;
-    bool valid;
+    int32_t idx;       // data word of the leaf: the feature row when `valid`
+    float delta_t;     // chord of the leaf along the ray + step_size
+    bool valid;        // 0 <= idx < M (anything else marks an empty leaf)
 };
 
 // One leaf crossing: rt_kernel.cu:261-277.
