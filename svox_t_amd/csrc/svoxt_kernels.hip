@@ -1,7 +1,7 @@
 // svoxt_kernels.hip -- hand-written CDNA4 (gfx950) kernels for svox_t's
 // volume-render hot path and the C ABI declared in include/svoxt.h.
 //
-// Mapping: one ray per wavefront lane, 256-thread workgroups (4 waves); a
+// Mapping: one ray per wavefront lane, one wavefront per workgroup (kBlock); a
 // wavefront takes 64 consecutive rays, or an 8x8 pixel tile when the caller says
 // the batch is an image.  The per-ray output accumulators live in registers for
 // the specialised payloads (RGBA C=3 / C=31, SH with 1/4/9/16/25 basis functions
@@ -35,7 +35,10 @@
 
 namespace svoxt {
 
-constexpr int kBlock = 256;
+// One wavefront per workgroup: the finest scheduling granularity for kernels whose
+// wavefronts differ 10x in cost (measured: 64 -> 492, 128 -> 485, 256 -> 477,
+// 512 -> 466 Mrays/s on the headline workload).
+constexpr int kBlock = 64;
 
 // ---------------------------------------------------------------------------
 // Forward: trace_ray (rt_kernel.cu:222-328) + render_ray_kernel (:655-671)
@@ -891,7 +894,11 @@ leaves_count_kernel(const uint8_t* __restrict__ mask, int64_t n, int32_t* __rest
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) seg_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) {
+        int32_t tot = 0;
+        for (int w = 0; w < kBlock / 64; ++w) tot += wsum[w];
+        seg_count[blockIdx.x] = tot;
+    }
 }
 
 // exclusive scan of seg_count[0..nseg) in place; total -> *count (one workgroup)
