@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 7
+#define SVOXT_ABI_VERSION 8
 
 enum {
     SVOXT_OK = 0,
@@ -242,6 +242,46 @@ int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
  * svoxt_accel_build fills `cells` from tree->child / tree->data. */
 int64_t svoxt_accel_bytes(int32_t log2_res);
 int     svoxt_accel_build(const svoxt_tree* tree, int32_t log2_res, void* cells, void* stream);
+
+/* ---- Octree construction from a point cloud -------------
+ *
+ * The reference builds a frame's octree by repeating, depth-1 times,
+ * `tree[points].refine()` (helpers.py:101-109: a point query, svox_kernel.cu:45-94,
+ * its unique-leaf list, :240-324, then N3Tree.refine, svox.py:488-560) on a fresh
+ * N = 2 tree, and then `tree.construct_tree(points)` (svox.py:160-161,
+ * svox_kernel.cu:110-121: data[leaf of point i] = i).  The two calls below produce
+ * the same child / parent_depth / data tables in one pipeline, with one host
+ * read in the middle (the node count, to size the tables) instead of one per round:
+ * occupancy bitmaps per level instead of repeated descents, integer prefix sums
+ * for the node numbering (nodes of a level in increasing packed-parent order,
+ * i.e. the order refine() assigns when given the sorted unique-leaf list).
+ * Where several points share a finest leaf, the reference keeps whichever thread
+ * wrote last; here the smallest point index wins.
+ *
+ * points          : device [P, 3] fp32, world coordinates
+ * offset, scaling : device fp32[3] (as in svoxt_tree)
+ * depth           : D in [1, 10]; internal nodes at levels 0..D-1, finest leaf side 2^-D
+ * workspace       : svoxt_build_workspace_bytes(depth) device bytes, carried from
+ *                   _count to _emit unchanged
+ * n_internal      : _count writes the node count to this device int64; _emit takes
+ *                   the value the host read back, = rows of the three tables
+ * child, data     : device int32 [n_internal, 2, 2, 2]; parent_depth: [n_internal, 2];
+ *                   every row is written (no pre-initialisation needed)
+ * empty_index     : value for leaf slots that hold no point (any value >= P) */
+int64_t svoxt_build_workspace_bytes(int32_t depth);
+int svoxt_build_count(const float* points, int64_t P, const float* offset, const float* scaling,
+                      int32_t depth, void* workspace, int64_t workspace_bytes,
+                      int64_t* n_internal, void* stream);
+int svoxt_build_emit(const float* points, int64_t P, const float* offset, const float* scaling,
+                     int32_t depth, const void* workspace, int64_t workspace_bytes,
+                     int32_t* child, int32_t* data, int32_t* parent_depth,
+                     int64_t n_internal, int32_t empty_index, void* stream);
+
+/* construct_tree (svox.py:160-161, svox_kernel.cu:110-121, 341-352) on an existing
+ * tree of any N: data[leaf containing point i] = i; of several points in one
+ * leaf the smallest index is kept (the reference: whichever wrote last).
+ * tree->data is written; tree->features is not read. */
+int svoxt_construct_tree(const svoxt_tree* tree, const float* points, int64_t P, void* stream);
 
 #ifdef __cplusplus
 }

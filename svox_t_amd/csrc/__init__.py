@@ -43,7 +43,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -107,6 +107,10 @@ EXPORTS = {
     "svoxt_count_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
     "svoxt_accel_bytes": (ctypes.c_int64, [_i32]),
     "svoxt_accel_build": (ctypes.c_int, [_P(_CTree), _i32, _vp, _vp]),
+    "svoxt_build_workspace_bytes": (ctypes.c_int64, [_i32]),
+    "svoxt_build_count": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp]),
+    "svoxt_build_emit": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "svoxt_construct_tree": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp]),
 }
 for _name, (_res, _args) in EXPORTS.items():
     _fn = getattr(_lib, _name)       # AttributeError here = library/header mismatch
@@ -567,6 +571,60 @@ def count_forward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.T
     return counters
 
 
+def construct_tree(tree: TreeSpec, indices: torch.Tensor) -> None:
+    """svox_kernel.cu:341-352: data[leaf containing point i] = i, in place on
+    `tree.data`.  Where several points share a leaf the smallest index is kept
+    (the reference keeps whichever thread wrote last)."""
+    ct = _pack_tree(tree)
+    _check_indices(indices)
+    dev = indices.device
+    with torch.cuda.device(dev):
+        _call("svoxt_construct_tree", ctypes.byref(ct), _ptr(indices), indices.shape[0], _stream(dev))
+    # tree.data was written behind torch's back: tell the version counter (the
+    # acceleration-grid cache keys on it) and drop any grid built from the old words
+    torch.autograd.graph.increment_version(tree.data)
+    _ACCEL_CACHE.pop(id(tree.child), None)
+
+
+def build_octree(points: torch.Tensor, offset: torch.Tensor, scaling: torch.Tensor, depth: int,
+                 empty_index: int, reserve: int = 0):
+    """Octree of a point cloud in one pipeline (not an entry of the reference's
+    extension; it stands for `depth - 1` rounds of `tree[points].refine()` on a
+    fresh N = 2 tree followed by `construct_tree(points)`, include/svoxt.h).
+
+    Returns (child [n + reserve, 2, 2, 2] int32, data [n + reserve, 2, 2, 2, 1] int32,
+    parent_depth [n + reserve, 2] int32, n): the first n rows are the tree, the
+    `reserve` rows after them are initialised like unused rows of an N3Tree."""
+    _check_indices(points)
+    for name, x in (("offset", offset), ("scaling", scaling)):
+        _check_input(x, name)
+        if x.dtype != torch.float32 or x.numel() != 3:
+            raise RuntimeError(f"{name} must be float32 [3]")
+    dev = points.device
+    P = points.shape[0]
+    with torch.cuda.device(dev):
+        nbytes = _lib.svoxt_build_workspace_bytes(int(depth))
+        if nbytes < 0:
+            raise RuntimeError("build_octree: depth must be in [1, 10]")
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        count = torch.empty((1,), dtype=torch.int64, device=dev)
+        _call("svoxt_build_count", _ptr(points), P, _ptr(offset), _ptr(scaling), int(depth),
+              _ptr(ws), nbytes, _ptr(count), _stream(dev))
+        n = int(count.item())                 # the one host read: sizes the tables
+        rows = n + int(reserve)
+        child = torch.empty((rows, 2, 2, 2), dtype=torch.int32, device=dev)
+        data = torch.empty((rows, 2, 2, 2, 1), dtype=torch.int32, device=dev)
+        parent_depth = torch.empty((rows, 2), dtype=torch.int32, device=dev)
+        if reserve > 0:
+            child[n:].zero_()
+            data[n:].fill_(int(empty_index))
+            parent_depth[n:].zero_()
+        _call("svoxt_build_emit", _ptr(points), P, _ptr(offset), _ptr(scaling), int(depth),
+              _ptr(ws), nbytes, _ptr(child), _ptr(data), _ptr(parent_depth), n, int(empty_index),
+              _stream(dev))
+    return child, data, parent_depth, n
+
+
 # ---------------------------------------------------------------------------
 # Entry points of svox_t.csrc that are outside this project's hot path
 # (SURVEY.md section 2).  They exist so a caller gets a clear error, not an
@@ -577,12 +635,12 @@ def _out_of_scope(name):
     def fn(*_a, **_k):
         raise NotImplementedError(
             f"svox_t_amd.csrc.{name}: outside the accelerated hot path "
-            "(volume_render / opacity / depth / query); see SURVEY.md section 2")
+            "(volume_render / opacity / depth / query / construct_tree); see SURVEY.md section 2")
     fn.__name__ = name
     return fn
 
 
-for _n in ("assign_vertical", "construct_tree", "warp_vertices", "warp_vertices_backward",
+for _n in ("assign_vertical", "warp_vertices", "warp_vertices_backward",
            "p2v", "p2v_backward", "volume_render_image", "volume_render_image_backward",
            "motion_render", "motion_feature_render", "motion_feature_render_backward",
            "calc_corners", "grid_weight_render", "quantize_median_cut"):

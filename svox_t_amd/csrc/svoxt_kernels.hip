@@ -30,6 +30,7 @@
 
 #include "../../include/svoxt.h"
 #include "svoxt_device.h"
+#include "svoxt_host.h"
 
 #pragma clang fp contract(off)
 
@@ -1002,18 +1003,28 @@ accel_build_kernel(TreeDev tr, int G, uint2* __restrict__ cells) {
 using namespace svoxt;
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
-int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
+namespace svoxt {
+
+int set_error(int code, const char* fmt, const char* a, const char* b) {
     snprintf(g_err, sizeof(g_err), fmt, a, b);
     return code;
 }
 
 int check_launch(const char* what) {
     const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(SVOXT_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    if (e != hipSuccess) return set_error(SVOXT_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     return SVOXT_OK;
+}
+
+}  // namespace svoxt
+
+namespace {
+
+int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
+    return svoxt::set_error(code, fmt, a, b);
 }
 
 int check_tree(const svoxt_tree* t, const char* fn) {

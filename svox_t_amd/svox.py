@@ -107,12 +107,37 @@ class N3Tree(nn.Module):
 
     def construct_tree(self, indices):
         """data[leaf containing point i] = i (svox.py:160-161 -> construct_tree_kernel,
-        svox_kernel.cu:110-121).  One-off setup; done with the point query plus a
-        torch scatter rather than a dedicated kernel."""
+        svox_kernel.cu:110-121); the smallest index where points share a leaf."""
+        _C.construct_tree(self._spec(self.features), indices.to(self.data.device))
+        self._invalidate()
+
+    def build_from_points(self, points, depth, reserve=0):
+        """Replace the topology with the octree of a point cloud: what
+
+            for _ in range(depth - 1): tree[points].refine()
+            tree.construct_tree(points)
+
+        leaves behind on a fresh tree (helpers.py:101-109, svox.py:488-560, 160-161),
+        computed by one HIP pipeline (csrc/svoxt_build.hip) with a single host read
+        instead of one query + a dozen tensor ops + a sync per level.  N = 2 only;
+        `points` are world coordinates, float32 [P, 3], row i of `features` belongs
+        to point i.  `reserve` extra rows are kept free for later refine() calls.
+        :return: n_internal"""
+        if self._lock_tree_structure:
+            raise RuntimeError("Tree locked")
+        if self.N != 2:
+            raise RuntimeError("build_from_points: N = 2 only; use refine() / construct_tree() for other N")
+        if not self.data.is_cuda:
+            raise RuntimeError("build_from_points: only the GPU (HIP) path exists; move the tree to a GPU")
         with torch.no_grad():
-            _, packed = self.forward(self.features, indices, want_node_ids=True)[:2]
-            self.data.view(-1)[packed] = torch.arange(indices.shape[0], dtype=torch.int32,
-                                                      device=self.data.device)
+            points = points.to(device=self.data.device, dtype=torch.float32).contiguous()
+            child, data, parent_depth, n = _C.build_octree(points, self.offset, self.invradius, depth,
+                                                           EMPTY_INDEX, reserve)
+            self.child, self.data, self.parent_depth = child, data, parent_depth
+            self._n_internal.fill_(n)
+            self.filled = n
+            self._invalidate()
+        return n
 
     # ------------------------------------------------------------------ query
     def forward(self, features, indices, cuda=True, want_node_ids=False, world=True,

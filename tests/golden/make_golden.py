@@ -13,6 +13,11 @@ code, SH polynomials and small helpers run on CPU.  The fixtures hold only data
                    reference's N3Tree.refine -- full refinement and selective
                    (shell) refinement driven through refine(sel=..., leaf_node=...)
                    -- plus leaf corners / depths from its CPU _calc_corners
+  topology_points_*.npz   the same tables for the reference's per-frame build loop
+                   `tree[points].refine()` x (depth-1) (helpers.py:101-109): the
+                   reference's refine() driven with the sorted unique-leaf list of a
+                   seeded point cloud (its own point query needs the CUDA extension,
+                   so the leaves are located by oracle/builder.py's restatement)
   sh_bases.npz     sh.eval_sh_bases(deg, dirs) in float64 for deg 0..4, and
                    sh.eval_sh(deg, coeffs, dirs) (pins the channel-major layout)
   helpers.json     DataFormat parse table, offset / invradius / world2tree for a
@@ -37,6 +42,7 @@ from svox_t import sh as ref_sh            # noqa: E402
 from svox_t.helpers import DataFormat as RefDataFormat   # noqa: E402
 
 from svox_t_amd import synth               # noqa: E402  (only for the shell predicate)
+from oracle import builder as ob           # noqa: E402  (point -> leaf location for topology_points_*)
 
 
 def ref_tree_arrays(t):
@@ -76,8 +82,40 @@ def shell_tree_via_reference(depth):
     return out
 
 
+def point_cloud(n, seed, radius, center):
+    """Seeded cloud: a noisy sphere surface inside the cube, a few points outside it, duplicates."""
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = 0.62 + 0.05 * rng.normal(size=(n, 1))
+    pts = (np.asarray(center) + np.asarray(radius) * r * d).astype(np.float32)
+    pts[: n // 50] *= 3.0                       # outside the cube: clamped to its faces
+    pts[n // 2: n // 2 + n // 20] = pts[: n // 20]   # exact duplicates
+    return pts
+
+
+def points_tree_via_reference(points, depth, radius, center):
+    """The reference's N3TreeView.refine loop (helpers.py:101-109) on the CPU."""
+    t = ref.N3Tree(N=2, data_dim=4, init_reserve=400000, radius=radius, center=center, data_format="RGBA")
+    offset, scaling = t.offset.numpy(), t.invradius.numpy()
+    for _ in range(depth - 1):
+        topo = ob.Topology(N=2)
+        n = t.n_internal
+        topo.child, topo.n = t.child[:n].numpy(), n
+        leaf_node = torch.from_numpy(ob.unique_leaves(topo, ob.descend(topo, points, offset, scaling)))
+        t.refine(1, sel=(*leaf_node.T,), leaf_node=leaf_node)
+    out = ref_tree_arrays(t)
+    out.update(points=points, radius=np.asarray(radius, np.float32), center=np.asarray(center, np.float32),
+               depth=np.int64(depth), offset=offset, scaling=scaling)
+    return out
+
+
 def main():
     # ---- topology ---------------------------------------------------------
+    for name, n, depth, radius, center in (("a", 400, 4, [0.5] * 3, [0.5] * 3),
+                                           ("b", 3000, 6, [1.0, 1.2, 0.8], [0.1, -0.2, 0.3])):
+        np.savez_compressed(os.path.join(HERE, f"topology_points_{name}.npz"),
+                            **points_tree_via_reference(point_cloud(n, 11, radius, center), depth, radius, center))
     np.savez_compressed(os.path.join(HERE, "topology_full_n2_l3.npz"), **ref_tree_arrays(full_tree(2, 3)))
     np.savez_compressed(os.path.join(HERE, "topology_full_n3_l2.npz"), **ref_tree_arrays(full_tree(3, 2)))
     for d in (3, 4, 5):
