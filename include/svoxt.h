@@ -88,7 +88,9 @@ typedef struct svoxt_tree {
     int32_t        accel_log2;   /* log2 of the grid resolution per axis the grid was built with */
 } svoxt_tree;
 
-/* RaysSpec (data_spec.hpp:52-65) */
+/* RaysSpec (data_spec.hpp:52-65); with c2w set, CameraSpec (data_spec.hpp:113-126):
+ * the image-mode entry points volume_render_image / volume_render_image_backward
+ * (rt_kernel.cu:1382-1399, 1428-1452) are every render call below given a camera. */
 typedef struct svoxt_rays {
     const float* origins;        /* device [Q, 3] */
     const float* dirs;           /* device [Q, 3] */
@@ -97,6 +99,14 @@ typedef struct svoxt_rays {
     int32_t      image_width;    /* optional hint (no counterpart in the reference): if the batch is a   */
     int32_t      image_height;   /* row-major W x H image (Q == W*H, both multiples of 8) the kernels walk
                                     it in 8x8 pixel tiles; 0 = no hint.  Results do not depend on it. */
+    const float* c2w;            /* camera mode when non-NULL: device camera-to-world matrix, rows of 4 floats
+                                    ([3,4] or [4,4] contiguous).  Ray q is then pixel (q % image_width,
+                                    q / image_width) of a pinhole camera, generated inside the kernels as
+                                    cam2world_ray + maybe_world2ndc do (rt_kernel.cu:1153-1190; the NDC warp
+                                    applies iff options.ndc_width >= 0, and the view direction is the one
+                                    before the warp, :1203); origins / dirs / vdirs are ignored, Q must be
+                                    image_width * image_height, outputs are the [H, W, C+1] image. */
+    float        fx, fy;         /* focal lengths in pixels (camera mode) */
 } svoxt_rays;
 
 /* RenderOptions (data_spec.hpp:129-145), same fields in the same order. */

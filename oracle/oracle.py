@@ -236,6 +236,21 @@ def query_backward(tree: Tree, points, grad_output):
     return grad
 
 
+def camera_rays(c2w, fx, fy, width, height, ndc=None):
+    """(origins, dirs, vdirs) float32 [H*W, 3] of a pinhole camera, row-major:
+    cam2world_ray + maybe_world2ndc (rt_kernel.cu:1153-1190).  c2w: [3,4] or [4,4];
+    ndc: None or (ndc_width, ndc_height, ndc_focal)."""
+    c = np.ascontiguousarray(np.asarray(c2w, dtype=np.float32)[:3, :4])
+    n = int(width) * int(height)
+    o = np.empty((n, 3), np.float32)
+    d = np.empty((n, 3), np.float32)
+    v = np.empty((n, 3), np.float32)
+    nw, nh, nf = (-1, -1, 0.0) if ndc is None else ndc
+    lib().svoxt_oracle_camera_rays(_p(c), ctypes.c_float(fx), ctypes.c_float(fy), int(width), int(height),
+                                   int(nw), int(nh), ctypes.c_float(nf), _p(o), _p(d), _p(v))
+    return o, d, v
+
+
 def basis(format: int, basis_dim: int, dirs, extra=None):
     d = _c(dirs, np.float32)
     out = np.zeros((d.shape[0], basis_dim), dtype=np.float32)

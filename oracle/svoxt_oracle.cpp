@@ -664,6 +664,46 @@ void svoxt_oracle_set_num_threads(int n) {
 #endif
 }
 
+// cam2world_ray (rt_kernel.cu:1153-1166) + maybe_world2ndc (:1170-1190) as
+// render_image_kernel (:1193-1211) applies them, for every pixel of a W x H image,
+// row-major.  scalar_t = float; the double sub-expressions are the reference's
+// (`0.5 * cam.width`, `+ 1.0`).  c2w: row-major, 4 floats per row, first 3 rows used.
+// vdirs = the directions before the NDC warp (:1203).
+void svoxt_oracle_camera_rays(const float* c2w, float fx, float fy, int W, int H,
+                              int ndc_width, int ndc_height, float ndc_focal,
+                              float* origins, float* dirs, float* vdirs) {
+    for (int iy = 0; iy < H; ++iy)
+        for (int ix = 0; ix < W; ++ix) {
+            float x = (float)((ix - 0.5 * W) / fx);
+            float y = (float)(-(iy - 0.5 * H) / fy);
+            float z = sqrtf((float)(x * x + y * y + 1.0));
+            x /= z; y /= z; z = -1.0f / z;
+            float dir[3], cen[3];
+            for (int i = 0; i < 3; ++i) {
+                dir[i] = c2w[4 * i + 0] * x + c2w[4 * i + 1] * y + c2w[4 * i + 2] * z;
+                cen[i] = c2w[4 * i + 3];
+            }
+            float* vo = vdirs + 3 * ((int64_t)iy * W + ix);
+            vo[0] = dir[0]; vo[1] = dir[1]; vo[2] = dir[2];
+            if (ndc_width >= 0) {                       // `if (opt.ndc_width < 0) return;`
+                const float near = 1.f;
+                const float t = -(near + cen[2]) / dir[2];
+                for (int i = 0; i < 3; ++i) cen[i] = cen[i] + t * dir[i];
+                dir[0] = -((2 * ndc_focal) / ndc_width) * (dir[0] / dir[2] - cen[0] / cen[2]);
+                dir[1] = -((2 * ndc_focal) / ndc_height) * (dir[1] / dir[2] - cen[1] / cen[2]);
+                dir[2] = -2 * near / cen[2];
+                cen[0] = -((2 * ndc_focal) / ndc_width) * (cen[0] / cen[2]);
+                cen[1] = -((2 * ndc_focal) / ndc_height) * (cen[1] / cen[2]);
+                cen[2] = 1 + 2 * near / cen[2];
+                const float norm = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+                dir[0] /= norm; dir[1] /= norm; dir[2] /= norm;
+            }
+            float* oo = origins + 3 * ((int64_t)iy * W + ix);
+            float* od = dirs + 3 * ((int64_t)iy * W + ix);
+            for (int i = 0; i < 3; ++i) { oo[i] = cen[i]; od[i] = dir[i]; }
+        }
+}
+
 // volume_render (rt_kernel.cu:1362-1379).  out is [Q, C+1].
 void svoxt_oracle_volume_render_f32(
     const float* features, int64_t M, int K, const int32_t* data, const int32_t* child, int N,

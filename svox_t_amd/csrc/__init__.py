@@ -64,7 +64,8 @@ class _CTree(ctypes.Structure):          # struct svoxt_tree
 class _CRays(ctypes.Structure):          # struct svoxt_rays
     _fields_ = [("origins", ctypes.c_void_p), ("dirs", ctypes.c_void_p),
                 ("vdirs", ctypes.c_void_p), ("Q", ctypes.c_int64),
-                ("image_width", ctypes.c_int32), ("image_height", ctypes.c_int32)]
+                ("image_width", ctypes.c_int32), ("image_height", ctypes.c_int32),
+                ("c2w", ctypes.c_void_p), ("fx", ctypes.c_float), ("fy", ctypes.c_float)]
 
 
 class _COptions(ctypes.Structure):       # struct svoxt_options
@@ -317,8 +318,28 @@ def _pack_tree_accel(tree: TreeSpec) -> _CTree:
     return ct
 
 
-def _pack_rays(rays: RaysSpec) -> _CRays:
-    """RaysSpec.check() (data_spec.hpp:57-64)."""
+def _pack_camera(cam: "CameraSpec") -> _CRays:
+    """CameraSpec.check() (data_spec.hpp:120-125): the ray batch is the image of a
+    pinhole camera; the kernels generate the rays themselves."""
+    _check_input(cam.c2w, "c2w")
+    if not cam.c2w.is_floating_point() or cam.c2w.dim() != 2 or cam.c2w.shape[1] != 4:
+        raise RuntimeError("c2w must be a floating point [3 or 4, 4] matrix")
+    if cam.c2w.dtype != torch.float32 or cam.c2w.shape[0] < 3:
+        raise RuntimeError("c2w must be float32 with at least 3 rows")
+    w, h = int(cam.width), int(cam.height)
+    if w < 1 or h < 1:
+        raise RuntimeError("camera width / height must be positive")
+    c = _CRays()
+    c.Q = w * h
+    c.image_width, c.image_height = w, h
+    c.c2w, c.fx, c.fy = cam.c2w.data_ptr(), float(cam.fx), float(cam.fy)
+    return c
+
+
+def _pack_rays(rays) -> _CRays:
+    """RaysSpec.check() (data_spec.hpp:57-64); a CameraSpec selects camera mode."""
+    if isinstance(rays, CameraSpec):
+        return _pack_camera(rays)
     for nm in ("origins", "dirs", "vdirs"):
         t = getattr(rays, nm)
         _check_input(t, nm)
@@ -462,6 +483,29 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
             grad = torch.empty((M, K), dtype=torch.float32, device=dev)
             _call("svoxt_compact_rows", _ptr(buf), M, K, stride, _ptr(grad), _stream(dev))
     return grad
+
+
+def volume_render_image(tree: TreeSpec, cam: CameraSpec, opt: RenderOptions, record: bool = False):
+    """rt_kernel.cu:1382-1399: [height, width, C+1] image of a pinhole camera; the
+    rays (cam2world_ray, and maybe_world2ndc when opt.ndc_width >= 0) are generated
+    inside the kernels.  (The reference's version cannot run: it allocates and
+    dispatches on the int32 index tensor, :1390-1393.)"""
+    res = volume_render(tree, cam, opt, record=record)
+    out = res[0] if record else res
+    out = out.view(int(cam.height), int(cam.width), -1)
+    return (out, res[1]) if record else out
+
+
+def volume_render_image_backward(tree: TreeSpec, cam: CameraSpec, opt: RenderOptions,
+                                 grad_output: torch.Tensor, lists: SampleLists = None,
+                                 fwd_output: torch.Tensor = None) -> torch.Tensor:
+    """rt_kernel.cu:1428-1452; grad_output [height, width, C+1]."""
+    _check_input(grad_output, "grad_output")
+    if grad_output.dim() != 3 or grad_output.shape[0] != cam.height or grad_output.shape[1] != cam.width:
+        raise RuntimeError("grad_output must be float32 [height, width, C+1]")
+    flat = grad_output.view(-1, grad_output.shape[2])
+    fo = None if fwd_output is None else fwd_output.view(-1, grad_output.shape[2])
+    return volume_render_backward(tree, cam, opt, flat, lists=lists, fwd_output=fo)
 
 
 def render_depth(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
@@ -641,7 +685,7 @@ def _out_of_scope(name):
 
 
 for _n in ("assign_vertical", "warp_vertices", "warp_vertices_backward",
-           "p2v", "p2v_backward", "volume_render_image", "volume_render_image_backward",
+           "p2v", "p2v_backward",
            "motion_render", "motion_feature_render", "motion_feature_render_backward",
            "calc_corners", "grid_weight_render", "quantize_median_cut"):
     globals()[_n] = _out_of_scope(_n)

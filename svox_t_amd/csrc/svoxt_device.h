@@ -51,6 +51,11 @@ struct RaysDev {
     const float* __restrict__ vdirs;
     int64_t Q;
     int tiles_per_row;   // > 0: rays are a row-major W x H image (W = 8 * tiles_per_row), walk it in 8x8 tiles
+    // camera mode (c2w != null): ray q is pixel (q % width, q / width) of a pinhole
+    // camera, generated in the kernel; origins / dirs / vdirs are not read
+    const float* __restrict__ c2w;   // camera-to-world, rows of 4 floats, 3 rows used
+    float fx, fy;
+    int width, height;
 };
 
 // Which ray a thread works on.  By default thread i takes ray i (a wavefront =
@@ -114,15 +119,65 @@ __device__ __forceinline__ void dda_unit(float cx, float cy, float cz,
     tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
 }
 
+// cam2world_ray (rt_kernel.cu:1153-1166): unit world-space direction of pixel q,
+// with the reference's mixed arithmetic (pixel offset and focal division in
+// double, `x*x + y*y` in float, `+ 1.0` in double, sqrtf of the float).
+__device__ __forceinline__ void camera_dir(const RaysDev& rays, int64_t q, float d[3]) {
+    const int iy = (int)(q / rays.width), ix = (int)(q - (int64_t)iy * rays.width);
+    float x = (float)(((double)ix - 0.5 * (double)rays.width) / (double)rays.fx);
+    float y = (float)(-((double)iy - 0.5 * (double)rays.height) / (double)rays.fy);
+    float z = sqrtf((float)((double)(x * x + y * y) + 1.0));
+    x /= z; y /= z; z = -1.0f / z;
+    const float* c = rays.c2w;
+    d[0] = c[0] * x + c[1] * y + c[2] * z;
+    d[1] = c[4] * x + c[5] * y + c[6] * z;
+    d[2] = c[8] * x + c[9] * y + c[10] * z;
+}
+
+// The direction the view-dependent basis is evaluated for: rays.vdirs[q], or
+// in camera mode the pixel's direction before the NDC warp (rt_kernel.cu:1203).
+__device__ __forceinline__ void load_vdir(const RaysDev& rays, int64_t q, float vd[3]) {
+    if (rays.c2w == nullptr) {
+        const float* v = rays.vdirs + 3 * q;
+        vd[0] = v[0]; vd[1] = v[1]; vd[2] = v[2];
+    } else {
+        camera_dir(rays, q, vd);
+    }
+}
+
 // Ray preamble: render_ray_kernel's transform (rt_kernel.cu:663-665,
 // common.cuh:45-51), _get_delta_scale (:188-199), invdir (:237, double) and
 // the cube slab test (:239-241).  Returns false when the ray misses the cube.
-__device__ __forceinline__ bool setup_ray(const TreeDev& tr, const RaysDev& rays,
+// Camera mode: the ray comes from cam2world_ray + maybe_world2ndc (:1170-1190)
+// as in render_image_kernel (:1193-1211).
+__device__ __forceinline__ bool setup_ray(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
                                           int64_t q, Ray& r) {
     const float s0 = tr.scaling[0], s1 = tr.scaling[1], s2 = tr.scaling[2];
     const float f0 = tr.offset[0], f1 = tr.offset[1], f2 = tr.offset[2];
-    const float* o = rays.origins + 3 * q;
-    const float* d = rays.dirs + 3 * q;
+    float o[3], d[3];
+    if (rays.c2w == nullptr) {
+        const float* po = rays.origins + 3 * q;
+        const float* pd = rays.dirs + 3 * q;
+        o[0] = po[0]; o[1] = po[1]; o[2] = po[2];
+        d[0] = pd[0]; d[1] = pd[1]; d[2] = pd[2];
+    } else {
+        camera_dir(rays, q, d);
+        o[0] = rays.c2w[3]; o[1] = rays.c2w[7]; o[2] = rays.c2w[11];
+        if (opt.ndc_width >= 0) {            // `if (opt.ndc_width < 0) return;` (:1174)
+            const float near = 1.f;
+            const float t = -(near + o[2]) / d[2];
+            o[0] = o[0] + t * d[0]; o[1] = o[1] + t * d[1]; o[2] = o[2] + t * d[2];
+            const float kx = (2 * opt.ndc_focal) / opt.ndc_width, ky = (2 * opt.ndc_focal) / opt.ndc_height;
+            const float n0 = -kx * (d[0] / d[2] - o[0] / o[2]);
+            const float n1 = -ky * (d[1] / d[2] - o[1] / o[2]);
+            const float n2 = -2 * near / o[2];
+            o[0] = -kx * (o[0] / o[2]);
+            o[1] = -ky * (o[1] / o[2]);
+            o[2] = 1 + 2 * near / o[2];
+            const float norm = sqrtf(n0 * n0 + n1 * n1 + n2 * n2);
+            d[0] = n0 / norm; d[1] = n1 / norm; d[2] = n2 / norm;
+        }
+    }
     r.ox = f0 + s0 * o[0];
     r.oy = f1 + s1 * o[1];
     r.oz = f2 + s2 * o[2];

@@ -77,7 +77,7 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
     float* o = out + q * (C + 1);
 
     Ray r;
-    if (!setup_ray(tr, rays, q, r)) {
+    if (!setup_ray(tr, rays, opt, q, r)) {
 #pragma unroll
         for (int j = 0; j < C; ++j) o[j] = opt.background_brightness;
         o[C] = 0.f;
@@ -89,7 +89,8 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
     float t_resume = 0.f;
     float basis[BD > 0 ? BD : 1];
     if constexpr (FMT == FMT_SH) {
-        const float* vd = rays.vdirs + 3 * q;
+        float vd[3];
+        load_vdir(rays, q, vd);
         precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
     }
     float acc[C];
@@ -167,17 +168,16 @@ render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __re
     const int K = tr.K;
 
     Ray r;
-    if (!setup_ray(tr, rays, q, r)) {
+    if (!setup_ray(tr, rays, opt, q, r)) {
         for (int j = 0; j < C; ++j) o[j] = opt.background_brightness;
         o[C] = 0.f;
         return;
     }
     for (int j = 0; j < C; ++j) o[j] = 0.f;
     float basis[25];
-    {
-        const float* vd = rays.vdirs + 3 * q;
-        precalc_basis<0>(opt.format, opt.basis_dim, tr, vd[0], vd[1], vd[2], basis);
-    }
+    float vd[3];
+    load_vdir(rays, q, vd);
+    precalc_basis<0>(opt.format, opt.basis_dim, tr, vd[0], vd[1], vd[2], basis);
     float light = 1.f;
     float t = r.tmin;
     while (t < r.tmax) {
@@ -189,7 +189,7 @@ render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __re
             if (sigma > opt.sigma_thresh) {
                 const float att = pexpf(-s.delta_t * r.delta_scale * sigma);
                 const float weight = light * (1.f - att);
-                if (tr.xform != nullptr) rotated_basis(tr, opt.format, opt.basis_dim, s.idx, rays.vdirs + 3 * q, basis);
+                if (tr.xform != nullptr) rotated_basis(tr, opt.format, opt.basis_dim, s.idx, vd, basis);
                 if (opt.format != FMT_RGBA) {
                     for (int c = 0; c < C; ++c) {
                         const int off = c * opt.basis_dim;
@@ -369,14 +369,15 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     Ray r;
     bool alive = q < rays.Q;
-    if (alive) alive = setup_ray(tr, rays, q, r);
+    if (alive) alive = setup_ray(tr, rays, opt, q, r);
     if (!__any(alive)) return;
 
     float basis[BD > 0 ? BD : 1];
     float g[C + 1];
     if (alive) {
         if constexpr (FMT == FMT_SH) {
-            const float* vd = rays.vdirs + 3 * q;
+            float vd[3];
+        load_vdir(rays, q, vd);
             precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
         }
 #pragma unroll
@@ -500,14 +501,13 @@ render_bwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     if (q >= rays.Q) return;
     Ray r;
-    if (!setup_ray(tr, rays, q, r)) return;
+    if (!setup_ray(tr, rays, opt, q, r)) return;
     const int K = tr.K;
     const float* g = grad_out + q * (C + 1);
     float basis[25];
-    {
-        const float* vd = rays.vdirs + 3 * q;
-        precalc_basis<0>(opt.format, opt.basis_dim, tr, vd[0], vd[1], vd[2], basis);
-    }
+    float vd[3];
+    load_vdir(rays, q, vd);
+    precalc_basis<0>(opt.format, opt.basis_dim, tr, vd[0], vd[1], vd[2], basis);
     float accum = 0.f;
     float light_ray;
     {   // pass 1
@@ -521,7 +521,7 @@ render_bwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
                 if (sigma > 0.f) {
                     float* grow = grad + (int64_t)s.idx * gstride;
                     // pass 1 re-evaluates the rotated basis; pass 2 keeps the last one
-                    if (tr.xform != nullptr) rotated_basis(tr, opt.format, opt.basis_dim, s.idx, rays.vdirs + 3 * q, basis);
+                    if (tr.xform != nullptr) rotated_basis(tr, opt.format, opt.basis_dim, s.idx, vd, basis);
                     const float att = pexpf(-s.delta_t * sigma * r.delta_scale);
                     const float weight = light * (1.f - att);
                     float total_color = 0.f;
@@ -609,10 +609,11 @@ render_bwd_generic_staged_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     Ray r;
     bool alive = q < rays.Q;
-    if (alive) alive = setup_ray(tr, rays, q, r);
+    if (alive) alive = setup_ray(tr, rays, opt, q, r);
     if (!__any(alive)) return;
     const float* g = grad_out + (alive ? q : 0) * (C + 1);
-    const float* vd = rays.vdirs + 3 * (alive ? q : 0);
+    float vd[3];
+    load_vdir(rays, alive ? q : 0, vd);
     const bool rgba = opt.format == FMT_RGBA;
     float basis[25];       // basis of the current sample (re-evaluated per sample with view rotations)
     float basis2[25];      // basis pass 2 of the reference sees: the one pass 1 ended with
@@ -736,7 +737,7 @@ opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) 
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     if (q >= rays.Q) return;
     Ray r;
-    if (!setup_ray(tr, rays, q, r)) { out[q] = 0.f; return; }
+    if (!setup_ray(tr, rays, opt, q, r)) { out[q] = 0.f; return; }
     const int K = tr.K;
     float light = 1.f, t = r.tmin;
     while (t < r.tmax) {
@@ -761,7 +762,7 @@ depth_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ depth) {
     if (q >= rays.Q) return;
     Ray r;
     float d = 0.f;
-    if (setup_ray(tr, rays, q, r)) {
+    if (setup_ray(tr, rays, opt, q, r)) {
         const int K = tr.K;
         float t = r.tmin;
         while (t < r.tmax) {
@@ -793,7 +794,7 @@ count_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, unsigned long long* __restr
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     unsigned long long hit = 0, steps = 0, levels = 0, valid = 0, active = 0;
     Ray r;
-    if (q < rays.Q && setup_ray(tr, rays, q, r)) {
+    if (q < rays.Q && setup_ray(tr, rays, opt, q, r)) {
         hit = 1;
         const int K = tr.K;
         float light = 1.f, t = r.tmin;
@@ -1045,8 +1046,13 @@ int check_tree(const svoxt_tree* t, const char* fn) {
 int check_rays(const svoxt_rays* r, const char* fn) {
     if (r == nullptr) return fail(SVOXT_ERR_INVALID, "%s: rays is NULL", fn);
     if (r->Q < 0) return fail(SVOXT_ERR_INVALID, "%s: negative ray count", fn);
-    if (r->Q > 0 && (r->origins == nullptr || r->dirs == nullptr || r->vdirs == nullptr))
+    if (r->c2w != nullptr) {
+        if (r->image_width < 1 || r->image_height < 1 || (int64_t)r->image_width * r->image_height != r->Q)
+            return fail(SVOXT_ERR_INVALID, "%s: camera mode needs Q == image_width * image_height", fn);
+        if (!(r->fx != 0.f) || !(r->fy != 0.f)) return fail(SVOXT_ERR_INVALID, "%s: camera focal lengths must be non-zero", fn);
+    } else if (r->Q > 0 && (r->origins == nullptr || r->dirs == nullptr || r->vdirs == nullptr)) {
         return fail(SVOXT_ERR_INVALID, "%s: rays.origins / dirs / vdirs is NULL", fn);
+    }
     if (r->Q >= (int64_t)kBlock * 2147483647LL) return fail(SVOXT_ERR_INVALID, "%s: too many rays", fn);
     if (r->image_width < 0 || r->image_height < 0) return fail(SVOXT_ERR_INVALID, "%s: negative image extent", fn);
     return SVOXT_OK;
@@ -1093,6 +1099,8 @@ RaysDev to_dev(const svoxt_rays* r) {
     const bool tiled = r->image_width > 0 && r->image_height > 0 && r->image_width % 8 == 0 &&
                        r->image_height % 8 == 0 && (int64_t)r->image_width * r->image_height == r->Q;
     d.tiles_per_row = tiled ? r->image_width / 8 : 0;
+    d.c2w = r->c2w; d.fx = r->fx; d.fy = r->fy;
+    d.width = r->image_width; d.height = r->image_height;
     return d;
 }
 

@@ -36,6 +36,17 @@ def _rays_spec_from_rays(rays, image_shape=None):
     return spec
 
 
+def _make_camera_spec(c2w, width, height, fx, fy):
+    """svox_t/renderer.py:51-58."""
+    spec = _C.CameraSpec()
+    spec.c2w = c2w
+    spec.width = width
+    spec.height = height
+    spec.fx = fx
+    spec.fy = fy
+    return spec
+
+
 def pinhole_rays(c2w, width, height, fx, fy, ndc: NDCConfig = None, near=1.0):
     """Row-major [H*W, 3] float32 (origins, dirs, viewdirs) of a pinhole camera.
 
@@ -101,6 +112,32 @@ class _VolumeRenderFunction(autograd.Function):
             fwd_out = ctx.saved_tensors[0] if ctx.lists is not None else None
             return _C.volume_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out.contiguous(),
                                              lists=ctx.lists, fwd_output=fwd_out), None, None, None
+        return None, None, None, None
+
+
+class _VolumeRenderImageFunction(autograd.Function):
+    """svox_t/renderer.py:79-94; as _VolumeRenderFunction, the forward records the
+    sample lists when a backward will follow."""
+
+    @staticmethod
+    def forward(ctx, data, tree, cam, opt):
+        if ctx.needs_input_grad[0]:
+            out, ctx.lists = _C.volume_render_image(tree, cam, opt, record=True)
+        else:
+            out, ctx.lists = _C.volume_render_image(tree, cam, opt), None
+        ctx.tree = tree
+        ctx.cam = cam
+        ctx.opt = opt
+        if ctx.lists is not None:
+            ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if ctx.needs_input_grad[0]:
+            fwd_out = ctx.saved_tensors[0] if ctx.lists is not None else None
+            return _C.volume_render_image_backward(ctx.tree, ctx.cam, ctx.opt, grad_out.contiguous(),
+                                                   lists=ctx.lists, fwd_output=fwd_out), None, None, None
         return None, None, None, None
 
 
@@ -180,13 +217,14 @@ class VolumeRenderer(nn.Module):
                      cuda=True, fast=False):
         """Render a perspective image; differentiable wrt `features`.
 
-        Same signature as the reference (svox_t/renderer.py:310-366), whose CUDA
-        route for it cannot run (it allocates and dispatches on the int32 index
-        tensor, svox_t/csrc/rt_kernel.cu:1390-1393).  Here the pinhole rays of
+        Same signature and route as the reference (svox_t/renderer.py:310-366:
+        _VolumeRenderImageFunction -> volume_render_image with a CameraSpec), whose
+        CUDA side cannot run (it allocates and dispatches on the int32 index
+        tensor, svox_t/csrc/rt_kernel.cu:1390-1393).  The pinhole rays of
         `cam2world_ray` (:1153-1166) -- and the NDC warp of `maybe_world2ndc`
-        (:1170-1190) when the renderer has an `ndc` config -- are generated on
-        the GPU with torch ops and fed to the ray-batch kernels, walked in 8x8
-        pixel tiles.
+        (:1170-1190) when the renderer has an `ndc` config -- are generated inside
+        the HIP kernels, which walk the image in 8x8 pixel tiles: no ray tensors
+        exist in memory.
 
         :param c2w: (3, 4) or (4, 4) camera-to-world matrix (OpenGL axes: -z forward)
         :return: (height, width, C+1)
@@ -194,10 +232,10 @@ class VolumeRenderer(nn.Module):
         self._require_gpu(cuda, "render_persp")
         if fy is None:
             fy = fx
-        origins, dirs, vdirs = pinhole_rays(c2w.to(device=self.tree.data.device, dtype=torch.float32),
-                                            width, height, fx, fy, self.ndc_config)
-        out = self.forward(features, Rays(origins, dirs, vdirs), fast=fast, image_shape=(height, width))
-        return out.reshape(height, width, -1)
+        c2w = c2w.to(device=self.tree.data.device, dtype=torch.float32).contiguous()
+        return _VolumeRenderImageFunction.apply(
+            features, self.tree._spec(features), _make_camera_spec(c2w, width, height, fx, fy),
+            self._get_options(fast))
 
     def render_depth(self, features, rays: Rays, cuda=True, fast=False, image_shape=None):
         """[Q, 1] distance to the first sample with sigma > sigma_thresh (0 if none)."""

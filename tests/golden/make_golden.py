@@ -20,6 +20,8 @@ code, SH polynomials and small helpers run on CPU.  The fixtures hold only data
                    so the leaves are located by oracle/builder.py's restatement)
   sh_bases.npz     sh.eval_sh_bases(deg, dirs) in float64 for deg 0..4, and
                    sh.eval_sh(deg, coeffs, dirs) (pins the channel-major layout)
+  ndc.npz          renderer.convert_to_ndc (renderer.py:140-160) applied in float64 to the
+                   pinhole rays of a forward-facing camera (pins maybe_world2ndc)
   helpers.json     DataFormat parse table, offset / invradius / world2tree for a
                    non-unit radius and centre, _pack_index / _unpack_index
 """
@@ -43,6 +45,7 @@ from svox_t.helpers import DataFormat as RefDataFormat   # noqa: E402
 
 from svox_t_amd import synth               # noqa: E402  (only for the shell predicate)
 from oracle import builder as ob           # noqa: E402  (point -> leaf location for topology_points_*)
+from oracle import oracle as O             # noqa: E402  (pinhole rays fed to the reference's convert_to_ndc)
 
 
 def ref_tree_arrays(t):
@@ -135,6 +138,17 @@ def main():
     out["coeffs_deg2"] = coeffs.numpy()
     out["eval_sh_deg2"] = ref_sh.eval_sh(2, coeffs, dirs).numpy()
     np.savez_compressed(os.path.join(HERE, "sh_bases.npz"), **out)
+
+    # ---- NDC ----------------------------------------------------------------
+    from svox_t.renderer import convert_to_ndc
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = [[0.9986295, 0.0, 0.0523360], [0.0027390, 0.9986295, -0.0522642], [-0.0522642, 0.0523360, 0.9972609]]
+    pose[:3, 3] = [0.3, -0.2, 2.5]
+    W, H, fx, fy, focal = 24, 16, 30.0, 33.0, 31.0
+    o, d, _ = O.camera_rays(pose, fx, fy, W, H)
+    ro, rd = convert_to_ndc(torch.from_numpy(o).double(), torch.from_numpy(d).double(), focal, W, H)
+    np.savez_compressed(os.path.join(HERE, "ndc.npz"), pose=pose, W=W, H=H, fx=fx, fy=fy, focal=focal,
+                        origins=o, dirs=d, ndc_origins=ro.numpy(), ndc_dirs=rd.numpy())
 
     # ---- helpers ------------------------------------------------------------
     fmt = {}

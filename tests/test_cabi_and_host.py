@@ -31,11 +31,20 @@ def test_library_exports_every_declared_symbol():
     assert lib.svoxt_abi_version() == _C.ABI_VERSION == 8
 
 
-def test_struct_layouts_match_header():
-    # sizes the C compiler gives the three structs (x86-64 SysV): 14 fields / 4 / 11
-    assert ctypes.sizeof(_C._COptions) == 44
-    assert ctypes.sizeof(_C._CRays) == 40
-    assert ctypes.sizeof(_C._CTree) == 112
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors have the sizes and field offsets gcc gives the structs of include/svoxt.h."""
+    import subprocess
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "svoxt.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(svoxt_options), sizeof(svoxt_rays),'
+                   ' sizeof(svoxt_tree), sizeof(svoxt_sample_lists), offsetof(svoxt_rays, c2w), offsetof(svoxt_rays, fy),'
+                   ' offsetof(svoxt_tree, accel_log2)); return 0;}\n')
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got == [ctypes.sizeof(_C._COptions), ctypes.sizeof(_C._CRays), ctypes.sizeof(_C._CTree),
+                   ctypes.sizeof(_C._CLists), _C._CRays.c2w.offset, _C._CRays.fy.offset, _C._CTree.accel_log2.offset]
+    assert got[:3] == [44, 56, 112]
 
 
 def test_out_data_dim():
@@ -92,7 +101,7 @@ def test_operator_layer_rejects_cpu_and_noncontiguous_tensors():
     with pytest.raises(RuntimeError, match="GPU"):
         tree(tree.features, torch.zeros(2, 3))
     with pytest.raises(NotImplementedError):
-        _C.volume_render_image(None, None, None)
+        _C.motion_feature_render(None, None, None)
 
 
 def test_spec_and_options_field_mapping():

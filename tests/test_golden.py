@@ -133,3 +133,23 @@ def test_shell_tree_sizes_of_the_benchmark_configs():
     np.testing.assert_array_equal(occ, np.arange(s.n_features))
     # only finest-level slots are occupied and none of them has a child
     assert not s.child.reshape(-1)[idx != synth.EMPTY_SENTINEL].any()
+
+
+# ---------------------------------------------------------------- camera rays
+def test_ndc_warp_matches_reference_convert_to_ndc():
+    """The oracle's maybe_world2ndc (rt_kernel.cu:1170-1190) == renderer.convert_to_ndc
+    (renderer.py:140-160, float64) followed by the normalisation the kernel adds."""
+    g = load("ndc.npz")
+    W, H = int(g["W"]), int(g["H"])
+    o, d, v = O.camera_rays(g["pose"], float(g["fx"]), float(g["fy"]), W, H, ndc=(W, H, float(g["focal"])))
+    np.testing.assert_array_equal(v, g["dirs"])                        # view dirs: before the warp
+    np.testing.assert_allclose(o, g["ndc_origins"], rtol=0, atol=2e-6)
+    want_d = g["ndc_dirs"] / np.linalg.norm(g["ndc_dirs"], axis=-1, keepdims=True)
+    np.testing.assert_allclose(d, want_d, rtol=0, atol=2e-6)
+    # without NDC: unit directions, origin = camera position, centre pixel looks down -z of the camera
+    o0, d0, v0 = O.camera_rays(g["pose"], float(g["fx"]), float(g["fy"]), W, H)
+    np.testing.assert_array_equal(o0, np.broadcast_to(g["pose"][:3, 3], o0.shape))
+    np.testing.assert_allclose(np.linalg.norm(d0, axis=-1), 1.0, atol=1e-6)
+    np.testing.assert_array_equal(d0, v0)
+    centre = d0.reshape(H, W, 3)[H // 2, W // 2]
+    np.testing.assert_allclose(centre, -g["pose"][:3, 2], atol=1e-6)

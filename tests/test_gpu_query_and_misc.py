@@ -246,33 +246,87 @@ def test_config4_depth9_features32_and_depth(gpu):
     assert dn.max() < 1.6 + 0.9
 
 
-def test_render_persp_matches_ray_batch_render(gpu):
-    """render_persp = pinhole ray generation (cam2world_ray) + the ray-batch
-    render; checked against the oracle fed with rays generated independently
-    (synth.pinhole_rays, float64 -> float32) and against the explicit ray path."""
-    c = Case(depth=5, K=28, data_format="SH9", width=64, height=48)
+@pytest.mark.parametrize("width,height,ndc", [(64, 48, False), (50, 37, False), (64, 48, True), (33, 40, True)])
+def test_render_persp_generates_the_reference_rays_in_kernel(gpu, width, height, ndc):
+    """render_persp -> volume_render_image with a CameraSpec: the kernels generate
+    cam2world_ray (+ maybe_world2ndc) rays themselves.  Bit-exact against the oracle
+    rendering the rays of its own restatement of rt_kernel.cu:1153-1190, forward
+    and (to the gradient tolerance) backward; and equal to the ray-batch render of
+    the same rays."""
+    c = Case(depth=5, K=28, data_format="SH9", width=8, height=8)
+    tree = c.tree(gpu)
+    fx = 1111.111 * width / 800.0
+    fy = fx * 1.1
+    cfg = svox.NDCConfig(width, height, fx) if ndc else None
+    r = svox.VolumeRenderer(tree, ndc=cfg)
+    if ndc:      # a forward-facing camera in front of the near plane, as NDC scenes have
+        pose = np.eye(4, dtype=np.float32)
+        pose[:3, 3] = [0.45, 0.55, 2.2]
+    else:
+        pose = synth.camera_pose(azimuth_deg=70.0, elevation_deg=-15.0).astype(np.float32)
+    c2w = torch.from_numpy(pose)
+    feats = tree.features.detach().clone().requires_grad_(True)
+    img = r.render_persp(feats, c2w.to(gpu), width=width, height=height, fx=fx, fy=fy)
+    assert img.shape == (height, width, 4)
+    o, d, v = O.camera_rays(pose, fx, fy, width, height, ndc=(width, height, fx) if ndc else None)
+    opt = c.oracle_opts()
+    if ndc:
+        opt.ndc_width, opt.ndc_height, opt.ndc_focal = width, height, fx
+    want = O.volume_render(c.oracle_tree(), o, d, v, opt)
+    assert (want[:, 3] > 0.05).mean() > 0.05                      # the camera does see the shell
+    np.testing.assert_array_equal(img.detach().reshape(-1, 4).cpu().numpy(), want)
+    # the same rays through the ray-batch entry give the same image
+    with torch.no_grad():
+        batch = svox.VolumeRenderer(tree)(feats, svox.Rays(*(torch.from_numpy(a).to(gpu) for a in (o, d, v))))
+    assert torch.equal(batch, img.detach().reshape(-1, 4))
+    # backward
+    g = torch.Generator().manual_seed(4)
+    gout = torch.randn(height, width, 4, generator=g)
+    img.backward(gout.to(gpu))
+    wg, wabs = O.volume_render_backward(c.oracle_tree(), o, d, v, opt, gout.reshape(-1, 4).numpy(), want_abs=True)
+    assert_grads_close(feats.grad.cpu().numpy(), wg, wabs)
+    # depth / opacity operators accept the camera too
+    cam = _C.CameraSpec()
+    cam.c2w, cam.fx, cam.fy, cam.width, cam.height = c2w.to(gpu), fx, fy, width, height
+    spec = tree._spec(tree.features)
+    np.testing.assert_array_equal(_C.render_depth(spec, cam, r._get_options()).cpu().numpy(),
+                                  O.render_depth(c.oracle_tree(), o, d, v, opt))
+    np.testing.assert_array_equal(_C.opacity_render(spec, cam, r._get_options()).cpu().numpy(),
+                                  O.opacity_render(c.oracle_tree(), o, d, v, opt))
+
+
+def test_torch_ray_generator_matches_the_oracle_camera(gpu):
+    """renderer.pinhole_rays (a torch utility for callers that want the ray tensors)
+    == the oracle's cam2world_ray / maybe_world2ndc restatement."""
+    from svox_t_amd.renderer import pinhole_rays
+    pose = synth.camera_pose(azimuth_deg=10.0, elevation_deg=35.0).astype(np.float32)
+    fx = 91.0
+    o, d, v = pinhole_rays(torch.from_numpy(pose).to(gpu), 40, 24, fx, fx)
+    wo, wd, wv = O.camera_rays(pose, fx, fx, 40, 24)
+    np.testing.assert_array_equal(o.cpu().numpy(), wo)
+    np.testing.assert_array_equal(d.cpu().numpy(), wd)
+    np.testing.assert_array_equal(v.cpu().numpy(), wv)
+    # against the float64 construction used for the benchmark inputs
+    _, d2, _ = synth.pinhole_rays(40, 24, c2w=pose.astype(np.float64), fx=fx)
+    np.testing.assert_allclose(wd, d2.numpy(), atol=3e-7)
+
+
+def test_camera_argument_errors(gpu):
+    c = Case(depth=3, K=4, data_format="RGBA", width=8, height=8)
     tree = c.tree(gpu)
     r = svox.VolumeRenderer(tree)
-    pose = synth.camera_pose(azimuth_deg=70.0, elevation_deg=-15.0)
-    c2w = torch.from_numpy(pose).float()
-    fx = 1111.111 * 64 / 800.0
-    img = r.render_persp(tree.features, c2w.to(gpu), width=64, height=48, fx=fx)
-    assert img.shape == (48, 64, 4)
-    from svox_t_amd.renderer import pinhole_rays
-    o, d, v = pinhole_rays(c2w.to(gpu), 64, 48, fx, fx)
-    want = O.volume_render(c.oracle_tree(), o.cpu().numpy(), d.cpu().numpy(), v.cpu().numpy(), c.oracle_opts())
-    np.testing.assert_array_equal(img.detach().reshape(-1, 4).cpu().numpy(), want)
-    # the generated rays agree with the float64 construction used for the benchmark inputs
-    o2, d2, _ = synth.pinhole_rays(64, 48, c2w=pose, fx=fx)
-    np.testing.assert_allclose(d.cpu().numpy(), d2.numpy(), atol=3e-7)
-    np.testing.assert_array_equal(o.cpu().numpy(), o2.numpy())
-    img.sum().backward()
-    assert tree.features.grad.abs().sum() > 0
-    # NDC config: runs, finite, differentiable (no reference behaviour to compare with)
-    rn = svox.VolumeRenderer(tree, ndc=svox.NDCConfig(64, 48, fx))
-    with torch.no_grad():
-        imgn = rn.render_persp(tree.features, c2w.to(gpu), width=64, height=48, fx=fx)
-    assert torch.isfinite(imgn).all()
+    with pytest.raises(RuntimeError):
+        r.render_persp(tree.features, torch.eye(4), width=0, height=8)
+    cam = _C.CameraSpec()
+    cam.c2w, cam.fx, cam.fy, cam.width, cam.height = torch.eye(4), 10.0, 10.0, 8, 8     # not on the GPU
+    with pytest.raises(RuntimeError):
+        _C.volume_render_image(tree._spec(tree.features), cam, r._get_options())
+    cam.c2w = torch.eye(3, device=gpu)                                                   # not [*, 4]
+    with pytest.raises(RuntimeError):
+        _C.volume_render_image(tree._spec(tree.features), cam, r._get_options())
+    cam.c2w, cam.fx = torch.eye(4, device=gpu), 0.0
+    with pytest.raises(RuntimeError):
+        _C.volume_render_image(tree._spec(tree.features), cam, r._get_options())
 
 
 def test_acceleration_grid_never_goes_stale(gpu):
