@@ -293,6 +293,45 @@ int svoxt_build_emit(const float* points, int64_t P, const float* offset, const 
  * tree->data is written; tree->features is not read. */
 int svoxt_construct_tree(const svoxt_tree* tree, const float* points, int64_t P, void* stream);
 
+/* ---- Motion variants of the march --------------------------
+ *
+ * svoxt_motion_render: motion_render (rt_kernel.cu:698-778, 1480-1504).  For each ray,
+ * the first sample with sigma > sigma_thresh gives
+ *   out       device [Q, J]  distance from the hit point to each of the J = extra_rows
+ *                            joint positions extra_data[j][0:3]
+ *   depth     device [Q]     t * delta_scale
+ *   hit_point device [Q, 3]  (as the reference computes it: transform_coord_world of
+ *                            the LEAF-LOCAL coordinates, rt_kernel.cu:745,757)
+ *   data_idx  device [Q] int64  feature row of the hit leaf
+ * and zeros in all four when nothing is hit. */
+int svoxt_motion_render(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
+                        float* out, float* depth, float* hit_point, int64_t* data_idx, void* stream);
+
+/* TreeSpec.joint_features / skinning_weights / joint_index (data_spec.hpp:66-110) */
+typedef struct svoxt_motion {
+    const float*   joint_features;    /* device [n_joints, feature_dim] */
+    int32_t        n_joints;
+    int32_t        feature_dim;       /* 1..32 (the reference's fixed tmp_data_dim, rt_kernel.cu:904) */
+    const float*   skinning_weights;  /* device [M, n_bind]: weight of each bound joint per feature row */
+    const int32_t* joint_index;       /* device [M, n_bind]: which joints; entries outside [0, n_joints) are skipped */
+    int32_t        n_bind;
+} svoxt_motion;
+
+/* motion_feature_render (rt_kernel.cu:886-981, 1525-1543): out device [Q, feature_dim] =
+ * sum_samples weight * sigmoid(sum_j skinning_weight_j * joint_features[joint_index_j]) + T * background
+ * (zeros for a ray that misses the cube, :913-919); early stop as volume_render. */
+int svoxt_motion_feature_render_fwd(const svoxt_tree* tree, const svoxt_motion* motion, const svoxt_rays* rays,
+                                    const svoxt_options* opt, float* out, void* stream);
+
+/* Gradient of the above wrt joint_features: grad_joint_features device
+ * [n_joints, feature_dim], zeroed by this call.  This is the derivative of the forward
+ * (thresholds ignored, as in every backward of the reference); the reference's own
+ * motion_feature_render_backward (rt_kernel.cu:983-1061) accumulates into an
+ * uninitialised local indexed by bone, so it defines no result to reproduce. */
+int svoxt_motion_feature_render_bwd(const svoxt_tree* tree, const svoxt_motion* motion, const svoxt_rays* rays,
+                                    const svoxt_options* opt, const float* grad_out,
+                                    float* grad_joint_features, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,6 +214,72 @@ def render_depth(tree: Tree, origins, dirs, vdirs, opt: RenderOptions, count=Fal
     return (out, Counters(*cnt.tolist())) if count else out
 
 
+def motion_render(tree: Tree, origins, dirs, vdirs, opt: RenderOptions):
+    """motion_render (rt_kernel.cu:698-778, 1480-1504), float32 only.  Returns
+    (joint distances [Q, J], depth [Q, 1], hit_point [Q, 3], data_idx [Q, 1] int64);
+    tree.extra = joint positions [J, >=3]."""
+    assert tree.dtype == np.float32 and tree.extra is not None and tree.extra.shape[1] >= 3
+    o, d, v = _rays(tree, origins, dirs, vdirs)
+    Q, J = o.shape[0], tree.extra.shape[0]
+    out = np.zeros((Q, J), np.float32)
+    depth = np.zeros((Q, 1), np.float32)
+    hit = np.zeros((Q, 3), np.float32)
+    idx = np.zeros((Q, 1), np.int64)
+    lib().svoxt_oracle_motion_render_f32(*tree._args(), _p(o), _p(d), _p(v), ctypes.c_int64(Q),
+                                         ctypes.byref(opt), _p(out), _p(depth), _p(hit), _p(idx))
+    return out, depth, hit, idx
+
+
+class Motion:
+    """joint_features [n_joints, F], skinning_weights [M, B], joint_index [M, B] (TreeSpec fields)."""
+
+    def __init__(self, joint_features, skinning_weights, joint_index, dtype=np.float32):
+        self.jf = _c(joint_features, dtype)
+        self.sw = _c(skinning_weights, dtype)
+        self.ji = _c(joint_index, np.int32)
+        assert self.sw.shape == self.ji.shape and self.jf.shape[1] <= 32
+        assert self.ji.min() >= 0 and self.ji.max() < self.jf.shape[0]
+
+    def astype(self, dtype):
+        return Motion(self.jf, self.sw, self.ji, dtype)
+
+    def _args(self):
+        return [_p(self.jf), ctypes.c_int(self.jf.shape[0]), ctypes.c_int(self.jf.shape[1]),
+                _p(self.sw), _p(self.ji), ctypes.c_int(self.ji.shape[1])]
+
+
+def motion_feature_render(tree: Tree, motion: Motion, origins, dirs, vdirs, opt: RenderOptions):
+    """motion_feature_render (rt_kernel.cu:886-981, 1525-1543): [Q, F]."""
+    assert motion.jf.dtype == tree.dtype and motion.sw.shape[0] == tree.M
+    o, d, v = _rays(tree, origins, dirs, vdirs)
+    Q = o.shape[0]
+    out = np.zeros((Q, motion.jf.shape[1]), tree.dtype)
+    fn = lib().svoxt_oracle_motion_feature_render_f32 if tree.dtype == np.float32 \
+        else lib().svoxt_oracle_motion_feature_render_f64
+    fn(*tree._args(with_extra=False), *motion._args(), _p(o), _p(d), _p(v), ctypes.c_int64(Q),
+       ctypes.byref(opt), _p(out))
+    return out
+
+
+def motion_feature_render_backward(tree: Tree, motion: Motion, origins, dirs, vdirs, opt: RenderOptions,
+                                   grad_output, want_abs=False):
+    """d/d joint_features of motion_feature_render: grad [n_joints, F] float64
+    (see svoxt_oracle.cpp: the derivative of the forward; the reference's own
+    backward, rt_kernel.cu:983-1061, reads an uninitialised local)."""
+    assert motion.jf.dtype == tree.dtype and motion.sw.shape[0] == tree.M
+    o, d, v = _rays(tree, origins, dirs, vdirs)
+    g = _c(grad_output, tree.dtype)
+    Q = o.shape[0]
+    assert g.shape == (Q, motion.jf.shape[1])
+    grad = np.zeros(motion.jf.shape, np.float64)
+    absum = np.zeros(motion.jf.shape, np.float64) if want_abs else None
+    fn = lib().svoxt_oracle_motion_feature_render_backward_f32 if tree.dtype == np.float32 \
+        else lib().svoxt_oracle_motion_feature_render_backward_f64
+    fn(*tree._args(with_extra=False), *motion._args(), _p(o), _p(d), _p(v), ctypes.c_int64(Q),
+       ctypes.byref(opt), _p(g), _p(grad), _p(absum))
+    return (grad, absum) if want_abs else grad
+
+
 def query(tree: Tree, points):
     p = _c(points, np.float32)
     Q = p.shape[0]

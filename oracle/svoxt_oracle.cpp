@@ -568,6 +568,165 @@ void depth_trace_ray(const Tree<T>& tree, const RaySetup<T>& r, const RenderOpti
     }
 }
 
+// ---------------------------------------------------------------------------
+// Motion variants
+// ---------------------------------------------------------------------------
+
+// One leaf crossing that also hands back the leaf-local coordinates the
+// reference's in/out `pos` holds after query_single_from_root.
+template <typename T>
+inline Step<T> march_step_local(const Tree<T>& tree, const RaySetup<T>& r, const RenderOptions& opt, T t, T* pos) {
+    Step<T> s;
+    for (int j = 0; j < 3; ++j) pos[j] = r.origin[j] + t * r.dir[j];
+    T cube_sz;
+    s.slot = query_from_root<T>(tree, pos, &cube_sz, &s.levels);
+    s.idx = tree.data[s.slot];
+    s.row = (s.idx < 0 || (int64_t)s.idx >= tree.M) ? nullptr : tree.features + (int64_t)s.idx * tree.K;
+    T sub_tmin, sub_tmax;
+    dda_unit<T>(pos, r.invdir, &sub_tmin, &sub_tmax);
+    s.delta_t = (sub_tmax - sub_tmin) / cube_sz + opt.step_size;
+    s.sigma = s.row != nullptr ? s.row[tree.K - 1] : 0.0;
+    return s;
+}
+
+// motion_trace_ray (rt_kernel.cu:698-778): first sample with sigma > sigma_thresh ->
+// distances from the "hit point" to the J joint positions in extra_data[:, 0:3], the
+// depth, the hit point, the feature row index.  The hit point is
+// transform_coord_world (common.cuh:54-60) of `pos`, which at that line holds the
+// LEAF-LOCAL coordinates (query_single_from_root rewrote it, :745) -- reproduced as is.
+// All outputs are zero when nothing is hit (torch::zeros, :1489-1492).
+template <typename T>
+void motion_trace_ray(const Tree<T>& tree, const RaySetup<T>& r, const RenderOptions& opt, int J,
+                      T* out, T* depth_out, T* hit_point_out, int64_t* data_idx_out) {
+    for (int j = 0; j < J; ++j) out[j] = 0.f;
+    depth_out[0] = 0.f;
+    hit_point_out[0] = hit_point_out[1] = hit_point_out[2] = 0.f;
+    data_idx_out[0] = 0;
+    if (!r.hit) return;
+    T t = r.tmin;
+    while (t < r.tmax) {
+        T pos[3];
+        const Step<T> s = march_step_local<T>(tree, r, opt, t, pos);
+        if (s.sigma > opt.sigma_thresh) {
+            for (int i = 0; i < 3; ++i) pos[i] = (pos[i] - tree.offset[i]) / tree.scaling[i];
+            for (int i = 0; i < 3; ++i) hit_point_out[i] = pos[i];
+            depth_out[0] = t * r.delta_scale;
+            for (int i = 0; i < J; ++i) {
+                T dis[3];
+                for (int k = 0; k < 3; ++k) dis[k] = pos[k] - tree.extra[(int64_t)i * tree.extra_cols + k];
+                out[i] = norm3<T>(dis);
+            }
+            data_idx_out[0] = s.idx;
+            return;
+        }
+        t += s.delta_t;
+    }
+}
+
+template <typename T>
+struct Motion {
+    const T* joint_features;       // [n_joints, F]
+    int n_joints, F;
+    const T* skinning_weights;     // [M, B]
+    const int32_t* joint_index;    // [M, B]
+    int B;
+};
+
+// pos_joint_feature (rt_kernel.cu:946-952)
+template <typename T>
+inline void blend_joint_features(const Motion<T>& mo, int32_t idx, T* pjf) {
+    for (int k = 0; k < mo.F; ++k) pjf[k] = 0.f;
+    const T* sw = mo.skinning_weights + (int64_t)idx * mo.B;
+    const int32_t* ji = mo.joint_index + (int64_t)idx * mo.B;
+    for (int j = 0; j < mo.B; ++j)
+        if (sw[j] > 0)
+            for (int k = 0; k < mo.F; ++k) pjf[k] += sw[j] * mo.joint_features[(int64_t)ji[j] * mo.F + k];
+}
+
+// motion_feature_trace_ray (rt_kernel.cu:886-981)
+template <typename T>
+void motion_feature_trace_ray(const Tree<T>& tree, const Motion<T>& mo, const RaySetup<T>& r,
+                              const RenderOptions& opt, T* out) {
+    const int F = mo.F;
+    for (int j = 0; j < F; ++j) out[j] = 0.f;
+    if (!r.hit) return;                                   // :913-919: zeros, not the background
+    T light_intensity = 1.f;
+    T t = r.tmin;
+    T pjf[32];
+    while (t < r.tmax) {
+        const Step<T> s = march_step<T>(tree, r, opt, t);
+        if (s.sigma > opt.sigma_thresh) {
+            const T att = exp_T<T>(-s.delta_t * r.delta_scale * s.sigma);
+            const T weight = light_intensity * (1.f - att);
+            blend_joint_features<T>(mo, s.idx, pjf);
+            for (int j = 0; j < F; ++j) out[j] += weight / (1.0 + exp_T<T>(-pjf[j]));
+            light_intensity *= att;
+            if (light_intensity <= opt.stop_thresh) {
+                T scale = 1.0 / (1.0 - light_intensity);
+                for (int j = 0; j != F; ++j) out[j] *= scale;
+                return;
+            }
+        }
+        t += s.delta_t;
+    }
+    for (int j = 0; j < F; ++j) out[j] += light_intensity * opt.background_brightness;
+}
+
+// Gradient of the above wrt joint_features, as motion_feature_trace_ray_backward
+// (rt_kernel.cu:983-1061) sets out to compute: per sample with sigma > 0,
+//   toadd_k = weight * sigmoid_k * (1 - sigmoid_k) * grad_output_k,
+//   grad[joint_index_j][k] += skinning_weight_j * toadd_k.
+// The reference's own loop adds into an uninitialised local and indexes it by bone
+// instead of channel (:1043, :1048), so its result is undefined;
+// this is the derivative of the forward.  Exponent associated as the reference's
+// backward does (:1031); thresholds ignored as there.  `grad` / `abs_sum` double.
+template <typename T>
+void motion_feature_trace_ray_backward(const Tree<T>& tree, const Motion<T>& mo, const RaySetup<T>& r,
+                                       const RenderOptions& opt, const T* grad_output,
+                                       double* grad, double* abs_sum, bool atomic) {
+    if (!r.hit) return;
+    const int F = mo.F;
+    T light_intensity = 1.f, t = r.tmin;
+    T pjf[32];
+    while (t < r.tmax) {
+        const Step<T> s = march_step<T>(tree, r, opt, t);
+        if (s.sigma > 0.0) {
+            const T att = exp_T<T>(-s.delta_t * s.sigma * r.delta_scale);
+            const T weight = light_intensity * (1.f - att);
+            blend_joint_features<T>(mo, s.idx, pjf);
+            const T* sw = mo.skinning_weights + (int64_t)s.idx * mo.B;
+            const int32_t* ji = mo.joint_index + (int64_t)s.idx * mo.B;
+            for (int k = 0; k < F; ++k) {
+                const T sigmoid = 1.0 / (1.0 + exp_T<T>(-pjf[k]));
+                const T toadd = weight * sigmoid * (1.f - sigmoid) * grad_output[k];
+                for (int j = 0; j < mo.B; ++j) {
+                    if (!(sw[j] > 0)) continue;
+                    const T v = sw[j] * toadd;
+                    double* g = grad + (int64_t)ji[j] * F + k;
+                    if (atomic) {
+#pragma omp atomic
+                        *g += (double)v;
+                    } else {
+                        *g += (double)v;
+                    }
+                    if (abs_sum) {
+                        double* a = abs_sum + (int64_t)ji[j] * F + k;
+                        const double av = std::fabs((double)v);
+                        if (atomic) {
+#pragma omp atomic
+                            *a += av;
+                        } else {
+                            *a += av;
+                        }
+                    }
+                }
+            }
+            light_intensity *= att;
+        }
+        t += s.delta_t;
+    }
+}
+
 // transformation_matrices for the next f32 render / backward calls (test hook)
 static const float* g_xform_f32 = nullptr;
 template <typename T> inline const T* current_xform() { return nullptr; }
@@ -703,6 +862,53 @@ void svoxt_oracle_camera_rays(const float* c2w, float fx, float fy, int W, int H
             for (int i = 0; i < 3; ++i) { oo[i] = cen[i]; od[i] = dir[i]; }
         }
 }
+
+// motion_render (rt_kernel.cu:1480-1504).  out [Q, J], depth [Q], hit_point [Q, 3], data_idx [Q].
+void svoxt_oracle_motion_render_f32(
+    const float* features, int64_t M, int K, const int32_t* data, const int32_t* child, int N,
+    const float* offset, const float* scaling, const float* extra, int er, int ec,
+    const float* origins, const float* dirs, const float* vdirs, int64_t Q,
+    const RenderOptions* opt, float* out, float* depth, float* hit_point, int64_t* data_idx) {
+    const Tree<float> tree = make_tree<float>(features, M, K, data, child, N, offset, scaling, extra, er, ec);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t q = 0; q < Q; ++q) {
+        const RaySetup<float> r = setup_ray<float>(tree, origins + 3 * q, dirs + 3 * q, vdirs + 3 * q);
+        motion_trace_ray<float>(tree, r, *opt, er, out + q * er, depth + q, hit_point + 3 * q, data_idx + q);
+    }
+}
+
+#define SVOXT_ORACLE_MOTION_FEATURE(SUFFIX, T)                                                                  \
+    void svoxt_oracle_motion_feature_render_##SUFFIX(                                                           \
+        const T* features, int64_t M, int K, const int32_t* data, const int32_t* child, int N,                  \
+        const T* offset, const T* scaling, const T* joint_features, int n_joints, int F,                        \
+        const T* skinning_weights, const int32_t* joint_index, int B,                                           \
+        const T* origins, const T* dirs, const T* vdirs, int64_t Q, const RenderOptions* opt, T* out) {         \
+        const Tree<T> tree = make_tree<T>(features, M, K, data, child, N, offset, scaling, nullptr, 0, 0);      \
+        const Motion<T> mo = {joint_features, n_joints, F, skinning_weights, joint_index, B};                   \
+        _Pragma("omp parallel for schedule(dynamic, 256)")                                                      \
+        for (int64_t q = 0; q < Q; ++q) {                                                                       \
+            const RaySetup<T> r = setup_ray<T>(tree, origins + 3 * q, dirs + 3 * q, vdirs + 3 * q);             \
+            motion_feature_trace_ray<T>(tree, mo, r, *opt, out + q * F);                                        \
+        }                                                                                                       \
+    }                                                                                                           \
+    void svoxt_oracle_motion_feature_render_backward_##SUFFIX(                                                  \
+        const T* features, int64_t M, int K, const int32_t* data, const int32_t* child, int N,                  \
+        const T* offset, const T* scaling, const T* joint_features, int n_joints, int F,                        \
+        const T* skinning_weights, const int32_t* joint_index, int B,                                           \
+        const T* origins, const T* dirs, const T* vdirs, int64_t Q, const RenderOptions* opt,                   \
+        const T* grad_output, double* grad, double* abs_sum) {                                                  \
+        const Tree<T> tree = make_tree<T>(features, M, K, data, child, N, offset, scaling, nullptr, 0, 0);      \
+        const Motion<T> mo = {joint_features, n_joints, F, skinning_weights, joint_index, B};                   \
+        std::memset(grad, 0, sizeof(double) * (size_t)n_joints * F);                                            \
+        if (abs_sum) std::memset(abs_sum, 0, sizeof(double) * (size_t)n_joints * F);                            \
+        _Pragma("omp parallel for schedule(dynamic, 256)")                                                      \
+        for (int64_t q = 0; q < Q; ++q) {                                                                       \
+            const RaySetup<T> r = setup_ray<T>(tree, origins + 3 * q, dirs + 3 * q, vdirs + 3 * q);             \
+            motion_feature_trace_ray_backward<T>(tree, mo, r, *opt, grad_output + q * F, grad, abs_sum, true);  \
+        }                                                                                                       \
+    }
+SVOXT_ORACLE_MOTION_FEATURE(f32, float)
+SVOXT_ORACLE_MOTION_FEATURE(f64, double)
 
 // volume_render (rt_kernel.cu:1362-1379).  out is [Q, C+1].
 void svoxt_oracle_volume_render_f32(

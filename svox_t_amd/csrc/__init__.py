@@ -68,6 +68,12 @@ class _CRays(ctypes.Structure):          # struct svoxt_rays
                 ("c2w", ctypes.c_void_p), ("fx", ctypes.c_float), ("fy", ctypes.c_float)]
 
 
+class _CMotion(ctypes.Structure):        # struct svoxt_motion
+    _fields_ = [("joint_features", ctypes.c_void_p), ("n_joints", ctypes.c_int32),
+                ("feature_dim", ctypes.c_int32), ("skinning_weights", ctypes.c_void_p),
+                ("joint_index", ctypes.c_void_p), ("n_bind", ctypes.c_int32)]
+
+
 class _COptions(ctypes.Structure):       # struct svoxt_options
     _fields_ = [
         ("step_size", ctypes.c_float), ("background_brightness", ctypes.c_float),
@@ -112,6 +118,9 @@ EXPORTS = {
     "svoxt_build_count": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp]),
     "svoxt_build_emit": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "svoxt_construct_tree": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp]),
+    "svoxt_motion_render": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp, _vp, _vp]),
+    "svoxt_motion_feature_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CMotion), _P(_CRays), _P(_COptions), _vp, _vp]),
+    "svoxt_motion_feature_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CMotion), _P(_CRays), _P(_COptions), _vp, _vp, _vp]),
 }
 for _name, (_res, _args) in EXPORTS.items():
     _fn = getattr(_lib, _name)       # AttributeError here = library/header mismatch
@@ -615,6 +624,65 @@ def count_forward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.T
     return counters
 
 
+def motion_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions):
+    """rt_kernel.cu:1480-1504.  Returns (joint distances [Q, J], depth [Q, 1],
+    hit_point [Q, 3], data_idx [Q, 1] int64); J = tree.extra_data.shape[0]."""
+    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
+    if not _numel(tree.extra_data):
+        raise RuntimeError("motion_render needs extra_data [n_joints, >= 3] (the joint positions)")
+    dev = tree.features.device
+    with torch.cuda.device(dev):
+        out = torch.empty((cr.Q, ct.extra_rows), dtype=torch.float32, device=dev)
+        depth = torch.empty((cr.Q, 1), dtype=torch.float32, device=dev)
+        hit = torch.empty((cr.Q, 3), dtype=torch.float32, device=dev)
+        idx = torch.empty((cr.Q, 1), dtype=torch.int64, device=dev)
+        _call("svoxt_motion_render", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+              _ptr(out), _ptr(depth), _ptr(hit), _ptr(idx), _stream(dev))
+    return out, depth, hit, idx
+
+
+def _pack_motion(tree: TreeSpec, ct: _CTree) -> _CMotion:
+    jf, sw, ji = tree.joint_features, tree.skinning_weights, tree.joint_index
+    for nm, x in (("joint_features", jf), ("skinning_weights", sw), ("joint_index", ji)):
+        if not _numel(x):
+            raise RuntimeError(f"motion_feature_render needs {nm}")
+        _check_input(x, nm)
+    if jf.dtype != torch.float32 or jf.dim() != 2 or sw.dtype != torch.float32 or sw.dim() != 2:
+        raise RuntimeError("joint_features / skinning_weights must be float32 and 2-D")
+    if ji.dtype != torch.int32 or ji.shape != sw.shape or sw.shape[0] != ct.M:
+        raise RuntimeError("joint_index must be int32 with the shape of skinning_weights, [M, n_bind]")
+    return _CMotion(jf.data_ptr(), jf.shape[0], jf.shape[1], sw.data_ptr(), ji.data_ptr(), sw.shape[1])
+
+
+def motion_feature_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
+    """rt_kernel.cu:1525-1543: [Q, joint_features.shape[1]]."""
+    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
+    cm = _pack_motion(tree, ct)
+    dev = tree.features.device
+    with torch.cuda.device(dev):
+        out = torch.empty((cr.Q, cm.feature_dim), dtype=torch.float32, device=dev)
+        _call("svoxt_motion_feature_render_fwd", ctypes.byref(ct), ctypes.byref(cm), ctypes.byref(cr),
+              ctypes.byref(co), _ptr(out), _stream(dev))
+    return out
+
+
+def motion_feature_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
+                                   grad_output: torch.Tensor) -> torch.Tensor:
+    """rt_kernel.cu:1546-1572: gradient wrt joint_features, [n_joints, F] (the
+    derivative of the forward; the reference's kernel is defective, include/svoxt.h)."""
+    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
+    cm = _pack_motion(tree, ct)
+    _check_input(grad_output, "grad_output")
+    if grad_output.dtype != torch.float32 or tuple(grad_output.shape) != (cr.Q, cm.feature_dim):
+        raise RuntimeError("grad_output must be float32 [Q, joint feature dim]")
+    dev = tree.features.device
+    with torch.cuda.device(dev):
+        grad = torch.empty((cm.n_joints, cm.feature_dim), dtype=torch.float32, device=dev)
+        _call("svoxt_motion_feature_render_bwd", ctypes.byref(ct), ctypes.byref(cm), ctypes.byref(cr),
+              ctypes.byref(co), _ptr(grad_output), _ptr(grad), _stream(dev))
+    return grad
+
+
 def construct_tree(tree: TreeSpec, indices: torch.Tensor) -> None:
     """svox_kernel.cu:341-352: data[leaf containing point i] = i, in place on
     `tree.data`.  Where several points share a leaf the smallest index is kept
@@ -686,6 +754,5 @@ def _out_of_scope(name):
 
 for _n in ("assign_vertical", "warp_vertices", "warp_vertices_backward",
            "p2v", "p2v_backward",
-           "motion_render", "motion_feature_render", "motion_feature_render_backward",
            "calc_corners", "grid_weight_render", "quantize_median_cut"):
     globals()[_n] = _out_of_scope(_n)

@@ -1020,12 +1020,8 @@ int check_launch(const char* what) {
     return SVOXT_OK;
 }
 
-}  // namespace svoxt
-
-namespace {
-
-int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
-    return svoxt::set_error(code, fmt, a, b);
+static int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
+    return set_error(code, fmt, a, b);
 }
 
 int check_tree(const svoxt_tree* t, const char* fn) {
@@ -1110,6 +1106,10 @@ Opts to_dev(const svoxt_options* o) {
     memcpy(&d, o, sizeof(d));
     return d;
 }
+
+}  // namespace svoxt
+
+namespace {
 
 inline unsigned nblocks(int64_t Q) { return (unsigned)((Q + kBlock - 1) / kBlock); }
 

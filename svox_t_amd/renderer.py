@@ -141,6 +141,25 @@ class _VolumeRenderImageFunction(autograd.Function):
         return None, None, None, None
 
 
+class _MotionFeatureRenderFunction(autograd.Function):
+    """svox_t/renderer.py:96-116: differentiable wrt joint_features (argument 0)."""
+
+    @staticmethod
+    def forward(ctx, data, tree, rays, opt):
+        out = _C.motion_feature_render(tree, rays, opt)
+        ctx.tree = tree
+        ctx.rays = rays
+        ctx.opt = opt
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if ctx.needs_input_grad[0]:
+            return _C.motion_feature_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out.contiguous()), \
+                None, None, None
+        return None, None, None, None
+
+
 class _OpacityRenderFunction(autograd.Function):
     """svox_t/renderer.py:118-138."""
 
@@ -236,6 +255,25 @@ class VolumeRenderer(nn.Module):
         return _VolumeRenderImageFunction.apply(
             features, self.tree._spec(features), _make_camera_spec(c2w, width, height, fx, fy),
             self._get_options(fast))
+
+    def motion_render(self, features, rays: Rays, cuda=True, fast=False, image_shape=None):
+        """First sample with sigma > sigma_thresh per ray (svox_t/renderer.py:367-375):
+        (distance to each joint position in tree.extra_data [Q, J], depth [Q, 1],
+        hit_point [Q, 3], feature row index [Q, 1] int64); zeros where nothing is hit."""
+        assert self.tree.extra_data is not None, "Need extra data to store skeleton position."
+        self._require_gpu(cuda, "motion_render")
+        return _C.motion_render(self.tree._spec(features), _rays_spec_from_rays(rays, image_shape),
+                                self._get_options(fast))
+
+    def motion_feature_render(self, features, joint_features, skinning_weights, joint_index, rays: Rays,
+                              cuda=True, fast=False, image_shape=None):
+        """Composite, per ray, sigmoid(sum_j skinning_weights[row, j] * joint_features[joint_index[row, j]])
+        over the samples (svox_t/renderer.py:384-396); [Q, joint_features.shape[1]],
+        differentiable wrt `joint_features`."""
+        self._require_gpu(cuda, "motion_feature_render")
+        return _MotionFeatureRenderFunction.apply(
+            joint_features, self.tree._spec(features, joint_features, skinning_weights, joint_index),
+            _rays_spec_from_rays(rays, image_shape), self._get_options(fast))
 
     def render_depth(self, features, rays: Rays, cuda=True, fast=False, image_shape=None):
         """[Q, 1] distance to the first sample with sigma > sigma_thresh (0 if none)."""

@@ -101,7 +101,7 @@ def test_operator_layer_rejects_cpu_and_noncontiguous_tensors():
     with pytest.raises(RuntimeError, match="GPU"):
         tree(tree.features, torch.zeros(2, 3))
     with pytest.raises(NotImplementedError):
-        _C.motion_feature_render(None, None, None)
+        _C.grid_weight_render(None, None, None)
 
 
 def test_spec_and_options_field_mapping():

@@ -1,0 +1,135 @@
+"""GPU parity tests of the motion variants (csrc/svoxt_motion.hip) through
+VolumeRenderer.motion_render / motion_feature_render -> ctypes -> C ABI, against
+the CPU oracle: forward bit-exact, joint-feature gradient to the float-atomic
+tolerance (1e-5 of the summed contribution magnitudes)."""
+import numpy as np
+import pytest
+import torch
+
+import svox_t_amd as svox
+import svox_t_amd.csrc as _C
+from oracle import oracle as O
+from svox_t_amd import synth
+from tests.util import Case, assert_grads_close
+
+pytestmark = pytest.mark.gpu
+
+
+def skeleton(J, seed, radius=0.5, center=(0.5, 0.5, 0.5)):
+    rng = np.random.default_rng(seed)
+    pos = np.asarray(center) + np.asarray(radius) * rng.uniform(-0.8, 0.8, size=(J, 3))
+    return np.concatenate([pos, rng.normal(size=(J, 2))], 1).astype(np.float32)     # extra columns are ignored
+
+
+def binding(M, J, B, seed):
+    rng = np.random.default_rng(seed)
+    sw = rng.random((M, B)).astype(np.float32)
+    sw[rng.random((M, B)) < 0.3] = 0.0
+    sw[rng.random((M, B)) < 0.05] = -0.5                     # non-positive weights are skipped
+    ji = rng.integers(0, J, size=(M, B)).astype(np.int32)
+    return sw, ji
+
+
+@pytest.mark.parametrize("radius,center,fast", [
+    (0.5, (0.5, 0.5, 0.5), False),
+    ([1.0, 1.2, 0.8], (0.1, -0.2, 0.3), False),
+    (0.5, (0.5, 0.5, 0.5), True),
+])
+def test_motion_render_matches_oracle(gpu, radius, center, fast):
+    c = Case(depth=5, K=4, data_format="RGBA", width=56, height=40, radius=radius, center=center)
+    joints = skeleton(7, 1, np.atleast_1d(radius) * np.ones(3), center)
+    tree = svox.N3Tree.from_arrays(c.st.child, c.st.data, c.st.parent_depth, c.features, data_format="RGBA",
+                                   radius=radius, center=center, extra_data=torch.from_numpy(joints), device=gpu)
+    r = svox.VolumeRenderer(tree)
+    got = r.motion_render(tree.features, c.rays_gpu(gpu), fast=fast, image_shape=(40, 56))
+    ot = c.oracle_tree()
+    ot = O.Tree(ot.features, ot.data, ot.child, ot.offset, ot.scaling, extra=joints)
+    want = O.motion_render(ot, *c.rays_np(), c.oracle_opts(fast=fast))
+    assert (want[3] > 0).mean() > 0.2
+    for g, w, name in zip(got, want, ("joint distances", "depth", "hit_point", "data_idx")):
+        assert g.dtype == (torch.int64 if name == "data_idx" else torch.float32)
+        np.testing.assert_array_equal(g.cpu().numpy(), w, err_msg=name)
+    # the depth is render_depth's
+    np.testing.assert_array_equal(got[1].cpu().numpy(),
+                                  r.render_depth(tree.features, c.rays_gpu(gpu), fast=fast).cpu().numpy())
+
+
+@pytest.mark.parametrize("F,B,fast", [(3, 2, False), (8, 4, False), (13, 3, True), (32, 4, False)])
+def test_motion_feature_render_matches_oracle(gpu, F, B, fast):
+    c = Case(depth=5, K=4, data_format="RGBA", width=48, height=48, radius=[1.0, 1.2, 0.8], center=(0.1, -0.2, 0.3))
+    tree = c.tree(gpu)
+    M, J = c.st.n_features, 11
+    rng = np.random.default_rng(F)
+    jf = rng.normal(size=(J, F)).astype(np.float32)
+    sw, ji = binding(M, J, B, F)
+    r = svox.VolumeRenderer(tree, background_brightness=0.5)
+    jft = torch.from_numpy(jf).to(gpu).requires_grad_(True)
+    out = r.motion_feature_render(tree.features, jft, torch.from_numpy(sw).to(gpu), torch.from_numpy(ji).to(gpu),
+                                  c.rays_gpu(gpu), fast=fast)
+    mo = O.Motion(jf, sw, ji)
+    opt = c.oracle_opts(fast=fast, background_brightness=0.5)
+    want = O.motion_feature_render(c.oracle_tree(), mo, *c.rays_np(), opt)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
+    gout = torch.randn(c.Q, F, generator=torch.Generator().manual_seed(3))
+    out.backward(gout.to(gpu))
+    wg, wabs = O.motion_feature_render_backward(c.oracle_tree(), mo, *c.rays_np(), opt, gout.numpy(), want_abs=True)
+    assert np.abs(wg).max() > 1.0
+    assert_grads_close(jft.grad.cpu().numpy(), wg, wabs)
+
+
+def test_motion_feature_generic_branching_and_big_tables(gpu):
+    """N = 3 takes the generic descent; 700 joints x 32 features (87.5 KiB) takes the
+    global-atomic route instead of the LDS table."""
+    t = svox.N3Tree(N=3, data_dim=4, init_reserve=8)
+    for _ in range(2):
+        t.refine(1)
+    leaves = t._all_leaves()
+    g = torch.Generator().manual_seed(5)
+    occ = torch.rand(len(leaves), generator=g) < 0.35
+    M = int(occ.sum())
+    idx = torch.full((len(leaves),), synth.EMPTY_SENTINEL, dtype=torch.int32)
+    idx[occ] = torch.arange(M, dtype=torch.int32)
+    t.data[tuple(leaves.T)] = idx[:, None]
+    feats = synth.shell_features(M, 4, seed=5)
+    ot = O.Tree(feats.numpy(), t.data[:t.n_internal].numpy(), t.child[:t.n_internal].numpy())
+    o, d, v = synth.pinhole_rays(40, 40)
+    J, F, B = 700, 32, 3
+    rng = np.random.default_rng(2)
+    jf = rng.normal(size=(J, F)).astype(np.float32)
+    sw, ji = binding(M, J, B, 9)
+    tg = t.to(gpu)
+    r = svox.VolumeRenderer(tg)
+    jft = torch.from_numpy(jf).to(gpu).requires_grad_(True)
+    out = r.motion_feature_render(feats.to(gpu), jft, torch.from_numpy(sw).to(gpu), torch.from_numpy(ji).to(gpu),
+                                  svox.Rays(o.to(gpu), d.to(gpu), v.to(gpu)))
+    opt = O.make_options()
+    np.testing.assert_array_equal(out.detach().cpu().numpy(),
+                                  O.motion_feature_render(ot, O.Motion(jf, sw, ji), o.numpy(), d.numpy(), v.numpy(), opt))
+    gout = torch.randn(1600, F, generator=g)
+    out.backward(gout.to(gpu))
+    wg, wabs = O.motion_feature_render_backward(ot, O.Motion(jf, sw, ji), o.numpy(), d.numpy(), v.numpy(), opt,
+                                                gout.numpy(), want_abs=True)
+    assert_grads_close(jft.grad.cpu().numpy(), wg, wabs)
+
+
+def test_motion_argument_errors(gpu):
+    c = Case(depth=3, K=4, data_format="RGBA", width=8, height=8)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    rays = c.rays_gpu(gpu)
+    with pytest.raises(AssertionError):
+        r.motion_render(tree.features, rays)                                  # no extra_data, as the reference asserts
+    M = c.st.n_features
+    sw = torch.rand(M, 2, device=gpu)
+    ji = torch.zeros(M, 2, dtype=torch.int32, device=gpu)
+    with pytest.raises(RuntimeError, match="32"):
+        r.motion_feature_render(tree.features, torch.zeros(4, 33, device=gpu), sw, ji, rays)
+    with pytest.raises(RuntimeError, match="int32"):
+        r.motion_feature_render(tree.features, torch.zeros(4, 8, device=gpu), sw, ji.long(), rays)
+    with pytest.raises(RuntimeError, match="M, n_bind"):
+        r.motion_feature_render(tree.features, torch.zeros(4, 8, device=gpu), sw[:-1], ji[:-1], rays)
+    # joint indices outside the table are skipped, not dereferenced
+    bad = ji.clone()
+    bad[:, 1] = 1000
+    out = r.motion_feature_render(tree.features, torch.zeros(4, 8, device=gpu), sw, bad, rays)
+    assert torch.isfinite(out).all()
