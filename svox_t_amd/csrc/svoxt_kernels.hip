@@ -241,9 +241,8 @@ render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __re
 //           and the sigma term (:486-490) -- to an LDS staging row; the wave
 //           then flushes the staged rows cooperatively: lanes 0..31 and 32..63
 //           each take one row per round and issue ONE atomic instruction
-//           covering two contiguous K-float segments.  Adjacent lanes that hit
-//           the same leaf (neighbouring pixels usually do) are summed in LDS
-//           first, so they cost one segment, not several.
+//           covering two contiguous K-float segments.  (Rows of one iteration
+//           that hit the same leaf are not merged first -- see flush_staged.)
 //
 // Per-contribution values are bit-identical to the reference formulas; only
 // the order in which floats are accumulated differs (as it does between any
