@@ -319,9 +319,14 @@ typedef struct svoxt_motion {
 
 /* motion_feature_render (rt_kernel.cu:886-981, 1525-1543): out device [Q, feature_dim] =
  * sum_samples weight * sigmoid(sum_j skinning_weight_j * joint_features[joint_index_j]) + T * background
- * (zeros for a ray that misses the cube, :913-919); early stop as volume_render. */
+ * (zeros for a ray that misses the cube, :913-919); early stop as volume_render.
+ * workspace: svoxt_motion_workspace_bytes(M, feature_dim) device bytes, 16-byte aligned
+ * (the per-row blend of the joint features, evaluated once per call; for the backward
+ * also the gradient wrt it).  -1 if feature_dim is outside [1, 32]. */
+int64_t svoxt_motion_workspace_bytes(int64_t M, int32_t feature_dim);
 int svoxt_motion_feature_render_fwd(const svoxt_tree* tree, const svoxt_motion* motion, const svoxt_rays* rays,
-                                    const svoxt_options* opt, float* out, void* stream);
+                                    const svoxt_options* opt, float* out, void* workspace,
+                                    int64_t workspace_bytes, void* stream);
 
 /* Gradient of the above wrt joint_features: grad_joint_features device
  * [n_joints, feature_dim], zeroed by this call.  This is the derivative of the forward
@@ -330,7 +335,8 @@ int svoxt_motion_feature_render_fwd(const svoxt_tree* tree, const svoxt_motion* 
  * uninitialised local indexed by bone, so it defines no result to reproduce. */
 int svoxt_motion_feature_render_bwd(const svoxt_tree* tree, const svoxt_motion* motion, const svoxt_rays* rays,
                                     const svoxt_options* opt, const float* grad_out,
-                                    float* grad_joint_features, void* stream);
+                                    float* grad_joint_features, void* workspace, int64_t workspace_bytes,
+                                    void* stream);
 
 #ifdef __cplusplus
 }

@@ -119,8 +119,9 @@ EXPORTS = {
     "svoxt_build_emit": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "svoxt_construct_tree": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp]),
     "svoxt_motion_render": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp, _vp, _vp]),
-    "svoxt_motion_feature_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CMotion), _P(_CRays), _P(_COptions), _vp, _vp]),
-    "svoxt_motion_feature_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CMotion), _P(_CRays), _P(_COptions), _vp, _vp, _vp]),
+    "svoxt_motion_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
+    "svoxt_motion_feature_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CMotion), _P(_CRays), _P(_COptions), _vp, _vp, _i64, _vp]),
+    "svoxt_motion_feature_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CMotion), _P(_CRays), _P(_COptions), _vp, _vp, _vp, _i64, _vp]),
 }
 for _name, (_res, _args) in EXPORTS.items():
     _fn = getattr(_lib, _name)       # AttributeError here = library/header mismatch
@@ -654,6 +655,13 @@ def _pack_motion(tree: TreeSpec, ct: _CTree) -> _CMotion:
     return _CMotion(jf.data_ptr(), jf.shape[0], jf.shape[1], sw.data_ptr(), ji.data_ptr(), sw.shape[1])
 
 
+def _motion_workspace(ct: _CTree, cm: _CMotion, dev) -> torch.Tensor:
+    nbytes = _lib.svoxt_motion_workspace_bytes(ct.M, cm.feature_dim)
+    if nbytes < 0:
+        raise RuntimeError("joint feature dim must be in [1, 32] (the reference's tmp_data_dim)")
+    return torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+
+
 def motion_feature_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
     """rt_kernel.cu:1525-1543: [Q, joint_features.shape[1]]."""
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
@@ -661,8 +669,9 @@ def motion_feature_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) ->
     dev = tree.features.device
     with torch.cuda.device(dev):
         out = torch.empty((cr.Q, cm.feature_dim), dtype=torch.float32, device=dev)
+        ws = _motion_workspace(ct, cm, dev)
         _call("svoxt_motion_feature_render_fwd", ctypes.byref(ct), ctypes.byref(cm), ctypes.byref(cr),
-              ctypes.byref(co), _ptr(out), _stream(dev))
+              ctypes.byref(co), _ptr(out), _ptr(ws), ws.numel(), _stream(dev))
     return out
 
 
@@ -678,8 +687,9 @@ def motion_feature_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOp
     dev = tree.features.device
     with torch.cuda.device(dev):
         grad = torch.empty((cm.n_joints, cm.feature_dim), dtype=torch.float32, device=dev)
+        ws = _motion_workspace(ct, cm, dev)
         _call("svoxt_motion_feature_render_bwd", ctypes.byref(ct), ctypes.byref(cm), ctypes.byref(cr),
-              ctypes.byref(co), _ptr(grad_output), _ptr(grad), _stream(dev))
+              ctypes.byref(co), _ptr(grad_output), _ptr(grad), _ptr(ws), ws.numel(), _stream(dev))
     return grad
 
 

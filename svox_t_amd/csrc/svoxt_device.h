@@ -523,4 +523,42 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&ro
     }
 }
 
+// Cooperative flush of the rows staged in this iteration.  The lanes with a
+// sample have written their K values to consecutive staging rows (slot = rank
+// among the active lanes, destination row in sidx[slot]); the wave now walks
+// the `n` rows two at a time -- lanes 0..31 take row 2r, lanes 32..63 row 2r+1
+// (one row per round when K > 32) -- so every atomic instruction covers
+// contiguous K-float segments of the gradient table.  Rounds are independent
+// (no per-round cross-lane bookkeeping), so the LDS reads and the atomics of
+// several rounds overlap.
+//
+// Rows that hit the same leaf are NOT merged first: measured on the headline
+// workload a wavefront's k-th samples land on 28-29 distinct leaves out of
+// 36-50 active lanes, so merging saves < 1.7x atomics and its bookkeeping cost
+// more than it saved.
+template <int K, int KS>
+__device__ __forceinline__ void flush_staged(const float* __restrict__ stage, const int32_t* __restrict__ sidx,
+                                             int n, int lane, float* __restrict__ grad, int gstride) {
+    constexpr int ROWS = (K <= 32) ? 2 : 1;           // staged rows per atomic instruction
+    constexpr int LPR = 64 / ROWS;                    // lanes per row
+    constexpr int CHUNKS = (K + LPR - 1) / LPR;       // instructions per row (K > 64 only)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int half = (ROWS == 2) ? (lane >> 5) : 0;
+    const int j = (ROWS == 2) ? (lane & 31) : lane;
+#pragma unroll 4
+    for (int base = 0; base < n; base += ROWS) {
+        const int rw = base + half;
+        if (rw < n) {
+            const int32_t ridx = sidx[rw];
+#pragma unroll
+            for (int ch = 0; ch < CHUNKS; ++ch) {
+                const int col = j + ch * LPR;
+                if (col < K) atomicAdd(grad + (int64_t)ridx * gstride + col, stage[rw * KS + col]);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace svoxt
