@@ -9,6 +9,8 @@ the feature gradient.
     partitioning   every rank holds the full tree (child, data, features);
                    rank r renders the contiguous ray range shard_bounds(Q, W, r)
                    (row tiles of the image when rays are row-major pixels)
+                   -- render_sharded -- or whole cameras i = r, r + W, ...
+                   in image mode -- render_cameras
     forward        local render, then ONE all-gather of [Q/W, C+1] fp32 tiles
     backward       local backward of the rank's own rows of grad_out, then ONE
                    all-reduce(sum) of grad_features [M, K]
@@ -103,6 +105,68 @@ def render_sharded(renderer_or_fn, features: torch.Tensor, rays,
     fn: Callable = renderer_or_fn if not hasattr(renderer_or_fn, "forward") \
         else (lambda f, r: renderer_or_fn(f, r))
     return _ShardedRender.apply(features, fn, rays, group)
+
+
+class _CameraSet(autograd.Function):
+    """features -> [n_cam, H, W, C+1]: camera i is rendered by rank i % world
+    (image mode: the kernels generate the rays, nothing but the pose travels);
+    ONE all-gather of the images forward, ONE all-reduce of the gradient backward."""
+
+    @staticmethod
+    def forward(ctx, features, render_fn, c2ws, group):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        n_cam = c2ws.shape[0]
+        mine = list(range(rank, n_cam, world))
+        per_rank = (n_cam + world - 1) // world
+        with torch.enable_grad():
+            feats = features.detach().requires_grad_(True)
+            local = [render_fn(feats, c2ws[i]) for i in mine]
+        ctx.feats, ctx.local, ctx.group, ctx.mine = feats, local, group, mine
+        if world == 1:
+            return torch.stack([im.detach() for im in local])
+        # ranks with fewer cameras pad with zero images so that the gather is regular;
+        # the image shape is taken from a rendered camera (ranks without any learn it
+        # from rank 0, which always has camera 0)
+        shape = torch.tensor(list(local[0].shape) if local else [0, 0, 0], device=c2ws.device)
+        dist.broadcast(shape, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        H, W, C = (int(v) for v in shape.tolist())
+        buf = features.new_zeros((per_rank, H, W, C))
+        for j, im in enumerate(local):
+            buf[j] = im.detach()
+        full = features.new_empty((world * per_rank, H, W, C))
+        dist.all_gather_into_tensor(full, buf, group=group)
+        # slot r * per_rank + j holds camera r + j * world
+        order = [(i % world) * per_rank + i // world for i in range(n_cam)]
+        return full[torch.tensor(order, device=full.device)]
+
+    @staticmethod
+    def backward(ctx, grad_full):
+        g = torch.zeros_like(ctx.feats)
+        for im, i in zip(ctx.local, ctx.mine):
+            (gi,) = torch.autograd.grad(im, ctx.feats, grad_full[i].contiguous())
+            g += gi
+        if dist.get_world_size(ctx.group) > 1:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g, None, None, None
+
+
+def render_cameras(renderer_or_fn, features: torch.Tensor, c2ws: torch.Tensor,
+                   group: Optional[dist.ProcessGroup] = None, **persp_kwargs) -> torch.Tensor:
+    """Render a set of cameras, one (or a few) per rank: SURVEY.md 8(d) config 5,
+    eight 1024 x 1024 cameras on eight GPUs gathered to [8, 1024, 1024, C+1].
+
+    :param renderer_or_fn: a VolumeRenderer (its `render_persp` is used with
+           `persp_kwargs`: width, height, fx, fy, fast), or any callable
+           (features, c2w) -> [H, W, C+1]
+    :param c2ws: [n_cam, 3 or 4, 4] camera-to-world matrices, identical on all ranks
+    :return: [n_cam, H, W, C+1] on every rank, differentiable wrt `features`
+             (gradient all-reduced over ranks)
+    """
+    if hasattr(renderer_or_fn, "render_persp"):
+        fn: Callable = lambda f, c: renderer_or_fn.render_persp(f, c, **persp_kwargs)
+    else:
+        fn = renderer_or_fn
+    return _CameraSet.apply(features, fn, c2ws, group)
 
 
 def broadcast_tree(tree, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> None:

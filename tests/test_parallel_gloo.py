@@ -71,3 +71,47 @@ def test_render_sharded_two_ranks(tmp_path, Q):
         assert n == Q
         assert dout == 0.0                                  # gathered image == single-process image
         assert gmax > 0 and dgrad <= 1e-12 * max(gmax, 1.0) # all-reduced gradient == single-process gradient
+
+
+def _camera_worker(rank, world, port, n_cam, result_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from oracle import torch_renderer as TR
+        from svox_t_amd import synth
+        from tests.util import Case
+        c = Case(depth=4, K=4, data_format="RGBA", width=8, height=8)
+        ot, opt = c.oracle_tree(), c.oracle_opts()
+        W, H, fx = 12, 10, 16.0
+        poses = torch.stack([torch.from_numpy(synth.camera_pose(azimuth_deg=25.0 + 50.0 * k).astype(np.float32))
+                             for k in range(n_cam)])
+
+        def render_fn(features, c2w):        # the oracle's camera rays + the PyTorch oracle renderer
+            o, d, v = O.camera_rays(c2w.numpy(), fx, fx, W, H)
+            return TR.volume_render(ot, o, d, v, opt, features=features).reshape(H, W, -1)
+
+        feats = torch.from_numpy(ot.features).double().requires_grad_(True)
+        full = parallel.render_cameras(render_fn, feats, poses)
+        gout = synth.grad_output(n_cam * H * W, 4).double().reshape(n_cam, H, W, 4)
+        (full * gout).sum().backward()
+        f2 = torch.from_numpy(ot.features).double().requires_grad_(True)
+        ref = torch.stack([render_fn(f2, poses[k]) for k in range(n_cam)])
+        (ref * gout).sum().backward()
+        np.save(os.path.join(result_dir, f"cam{rank}.npy"), np.array([
+            float((full - ref).abs().max()), float((feats.grad - f2.grad).abs().max()),
+            float(f2.grad.abs().max()), full.shape[0], float(ref[..., 3].max())]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_cam", [2, 3, 1])      # one per rank, a ragged split, fewer cameras than ranks
+def test_render_cameras_two_ranks(tmp_path, n_cam):
+    port = 31500 + (os.getpid() + n_cam) % 2000
+    mp.spawn(_camera_worker, args=(2, port, n_cam, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        dout, dgrad, gmax, n, amax = np.load(tmp_path / f"cam{r}.npy")
+        assert n == n_cam and amax > 0.1
+        assert dout == 0.0
+        assert gmax > 0 and dgrad <= 1e-12 * max(gmax, 1.0)
