@@ -214,6 +214,18 @@ def render_depth(tree: Tree, origins, dirs, vdirs, opt: RenderOptions, count=Fal
     return (out, Counters(*cnt.tolist())) if count else out
 
 
+def ray_steps(tree: Tree, origins, dirs, vdirs, opt: RenderOptions):
+    """(leaf crossings, composited samples) per ray, int32 [Q] each (analysis aid)."""
+    assert tree.dtype == np.float32
+    o, d, v = _rays(tree, origins, dirs, vdirs)
+    Q = o.shape[0]
+    steps = np.zeros(Q, np.int32)
+    active = np.zeros(Q, np.int32)
+    lib().svoxt_oracle_ray_steps_f32(*tree._args(with_extra=False), _p(o), _p(d), _p(v), ctypes.c_int64(Q),
+                                     ctypes.byref(opt), _p(steps), _p(active))
+    return steps, active
+
+
 def motion_render(tree: Tree, origins, dirs, vdirs, opt: RenderOptions):
     """motion_render (rt_kernel.cu:698-778, 1480-1504), float32 only.  Returns
     (joint distances [Q, J], depth [Q, 1], hit_point [Q, 3], data_idx [Q, 1] int64);

@@ -910,6 +910,36 @@ void svoxt_oracle_motion_render_f32(
 SVOXT_ORACLE_MOTION_FEATURE(f32, float)
 SVOXT_ORACLE_MOTION_FEATURE(f64, double)
 
+// Per-ray leaf crossings and composited samples of volume_render's march (analysis
+// aid for scheduling studies; the sums are what counters5 reports).
+void svoxt_oracle_ray_steps_f32(
+    const float* features, int64_t M, int K, const int32_t* data, const int32_t* child, int N,
+    const float* offset, const float* scaling,
+    const float* origins, const float* dirs, const float* vdirs, int64_t Q,
+    const RenderOptions* opt, int32_t* steps, int32_t* active) {
+    const Tree<float> tree = make_tree<float>(features, M, K, data, child, N, offset, scaling, nullptr, 0, 0);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t q = 0; q < Q; ++q) {
+        const RaySetup<float> r = setup_ray<float>(tree, origins + 3 * q, dirs + 3 * q, vdirs + 3 * q);
+        int32_t ns = 0, na = 0;
+        if (r.hit) {
+            float light = 1.f, t = r.tmin;
+            while (t < r.tmax) {
+                const Step<float> s = march_step<float>(tree, r, *opt, t);
+                ++ns;
+                if (s.sigma > opt->sigma_thresh) {
+                    ++na;
+                    light *= exp_T<float>(-s.delta_t * r.delta_scale * s.sigma);
+                    if (light <= opt->stop_thresh) break;
+                }
+                t += s.delta_t;
+            }
+        }
+        steps[q] = ns;
+        active[q] = na;
+    }
+}
+
 // volume_render (rt_kernel.cu:1362-1379).  out is [Q, C+1].
 void svoxt_oracle_volume_render_f32(
     const float* features, int64_t M, int K, const int32_t* data, const int32_t* child, int N,
