@@ -100,25 +100,36 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
     float light = 1.f;
     float t = r.tmin;
     bool stopped = false;
-    while (t < r.tmax) {
-        Sample s;
-        march_step<N2>(tr, r, opt.step_size, t, s);
-        if (s.valid) {
-            const float* rowp = tr.features + (int64_t)s.idx * K;
-            float row[K];
-            load_row<K>(rowp, row);   // whole row at once: sigma is its last element
+    // Software pipeline: where the ray goes next depends on the leaf geometry only,
+    // not on the leaf's features, so the descent of step k+1 is issued right after
+    // the row load of step k and the two latencies overlap (memory operations of a
+    // wavefront return in order: waiting for the younger descent load covers the row).
+    Sample s;
+    bool have = t < r.tmax;
+    if (have) march_step<N2>(tr, r, opt.step_size, t, s);
+    while (have) {
+        float row[K];
+        const bool valid = s.valid;
+        if (valid) load_row<K>(tr.features + (int64_t)s.idx * K, row);   // whole row at once: sigma is its last element
+        const float t_cur = t, delta_t = s.delta_t;
+        const int32_t idx = s.idx;
+        const uint32_t slot = s.leaf.slot;
+        t = march_advance(t, delta_t);
+        have = t < r.tmax;
+        if (have) march_step<N2>(tr, r, opt.step_size, t, s);           // next descent, in flight with the row
+        if (valid) {
             const float sigma = row[K - 1];
             if (sigma > opt.sigma_thresh) {
                 if constexpr (REC) {
                     if (nrec < S) {
-                        rec_put(rec + ((int64_t)nrec * rays.Q + q), (uint32_t)s.idx, s.delta_t);
+                        rec_put(rec + ((int64_t)nrec * rays.Q + q), (uint32_t)idx, delta_t);
                         ++nrec;
                     } else if (!over) {
                         over = true;
-                        t_resume = t;
+                        t_resume = t_cur;
                     }
                 }
-                const float att = pexpf(-s.delta_t * r.delta_scale * sigma);
+                const float att = pexpf(-delta_t * r.delta_scale * sigma);
                 const float weight = light * (1.f - att);
                 if constexpr (FMT == FMT_SH) {
 #pragma unroll
@@ -134,13 +145,12 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
                         acc[j] = (float)((double)acc[j] + (double)weight / (1.0 + (double)pexpf(-row[j])));
                 }
                 light *= att;
-                if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + s.leaf.slot, weight);
+                if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + slot, weight);
                 if constexpr (!REC) {
                     if (light <= opt.stop_thresh) { stopped = true; break; }
                 }
             }
         }
-        t = march_advance(t, s.delta_t);
     }
     if (stopped) {
         const float scale = (float)(1.0 / (1.0 - (double)light));
