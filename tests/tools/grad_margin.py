@@ -1,3 +1,8 @@
+"""Report how far the HIP gradient sits from the oracle's, as a fraction of the
+1e-5 * S tolerance.  Test tooling: uses oracle/.
+
+    python tests/tools/grad_margin.py        # on the GPU box, from the repo root
+"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
