@@ -80,12 +80,15 @@ typedef struct svoxt_tree {
     int32_t        extra_rows;
     int32_t        extra_cols;
     float*         weight_accum; /* device [capacity * N^3] or NULL (TreeSpec._weight_accum) */
-    const float*   xform;        /* device [M,3,3] TreeSpec.transformation_matrices (per-leaf rotation of the view
-                                    direction, rt_kernel.cu:283-291) or NULL; volume_render fwd/bwd only */
+    const float*   xform;        /* device [M,d,d] TreeSpec.transformation_matrices (per-leaf rotation of the view
+                                    direction by the upper-left 3x3, rt_kernel.cu:283-291) or NULL;
+                                    volume_render fwd/bwd only; d = xform_dim below */
     const void*    accel;        /* device, optional: acceleration grid built by svoxt_accel_build for THIS
                                     child/data content (N == 2), or NULL.  Pure cache: results are identical
                                     with or without it; rebuild after any change to child or data. */
     int32_t        accel_log2;   /* log2 of the grid resolution per axis the grid was built with */
+    int32_t        xform_dim;    /* rows = columns of each xform matrix: 3, or 4 (the [M,4,4] that
+                                    warp_vertices / blend_transformation_matrix produce); 0 means 3 */
 } svoxt_tree;
 
 /* RaysSpec (data_spec.hpp:52-65); with c2w set, CameraSpec (data_spec.hpp:113-126):
@@ -337,6 +340,28 @@ int svoxt_motion_feature_render_bwd(const svoxt_tree* tree, const svoxt_motion* 
                                     const svoxt_options* opt, const float* grad_out,
                                     float* grad_joint_features, void* workspace, int64_t workspace_bytes,
                                     void* stream);
+
+/* ---- Linear blend skinning of points: the producer of transformation_matrices ------
+ *
+ * warp_vertices (svox_kernel.cu:123-154, 354-378; svox.py:58-76, 974-981):
+ *   matrix_out[q]   device [Q, 4, 4] = sum_j (w_qj > 0) w_qj * matrices[joint_qj] on rows 0..2,
+ *                   row 3 = (0, 0, 0, 1); 16-byte aligned
+ *   vertices_out[q] device [Q, 3]    = matrix_out[q][0:3, 0:3] * points[q] + matrix_out[q][0:3, 3]
+ * matrices: device [n_joints, 4, 4]; skinning_weights [Q, n_bind]; joint_index [Q, n_bind] int32
+ * (entries outside [0, n_joints) are skipped).  matrix_out is what volume_render takes as
+ * svoxt_tree.xform with xform_dim = 4 when rows of `features` are points. */
+int svoxt_warp_vertices(const float* matrices, int32_t n_joints, const float* points, int64_t Q,
+                        const float* skinning_weights, const int32_t* joint_index, int32_t n_bind,
+                        float* vertices_out, float* matrix_out, void* stream);
+
+/* warp_vertices_backward (svox_kernel.cu:156-211, 404-436): from grad_vertices [Q, 3] and
+ * grad_matrix_out [Q, 4, 4] to grad_points [Q, 3], grad_matrices [n_joints, 4, 4] (zeroed by
+ * this call, float atomics) and grad_skinning_weights [Q, n_bind] (every entry written). */
+int svoxt_warp_vertices_bwd(const float* matrices, int32_t n_joints, const float* points, int64_t Q,
+                            const float* skinning_weights, const int32_t* joint_index, int32_t n_bind,
+                            const float* grad_vertices, const float* grad_matrix_out,
+                            float* grad_points, float* grad_matrices, float* grad_skinning_weights,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -156,14 +156,14 @@ class transformation_matrices:
 
     def __init__(self, xform):
         self.x = _c(xform, np.float32)
-        assert self.x.ndim == 3 and self.x.shape[1:] == (3, 3)
+        assert self.x.ndim == 3 and self.x.shape[1:] in ((3, 3), (4, 4))
 
     def __enter__(self):
-        lib().svoxt_oracle_set_transformation_matrices(_p(self.x))
+        lib().svoxt_oracle_set_transformation_matrices(_p(self.x), int(self.x.shape[1]))
         return self
 
     def __exit__(self, *exc):
-        lib().svoxt_oracle_set_transformation_matrices(None)
+        lib().svoxt_oracle_set_transformation_matrices(None, 3)
 
 
 def volume_render(tree: Tree, origins, dirs, vdirs, opt: RenderOptions, count=False):

@@ -67,7 +67,8 @@ struct Tree {
     T scaling[3];
     const T* extra;         // [extra_rows, extra_cols] (SG / ASG lobes)
     int extra_rows, extra_cols;
-    const T* xform;         // transformation_matrices [M, 3, 3] or null (rt_kernel.cu:283-291)
+    const T* xform;         // transformation_matrices [M, d, d] or null (rt_kernel.cu:283-291)
+    int xform_dim;          // d: 3 or 4
 };
 
 struct Counters {           // sums that define algorithmic bytes
@@ -214,11 +215,12 @@ void precalc_basis(int format, int basis_dim, const Tree<T>& tree,
 // is re-evaluated for ray_dir = M[idx] * vdir.
 template <typename T>
 inline void rotated_basis(const Tree<T>& tree, const RenderOptions& opt, int32_t idx, const T* vdir, T* basis_fn) {
-    const T* m = tree.xform + (int64_t)idx * 9;
+    const int d = tree.xform_dim;
+    const T* m = tree.xform + (int64_t)idx * (d * d);
     T ray_dir[3];
     ray_dir[0] = m[0] * vdir[0] + m[1] * vdir[1] + m[2] * vdir[2];
-    ray_dir[1] = m[3] * vdir[0] + m[4] * vdir[1] + m[5] * vdir[2];
-    ray_dir[2] = m[6] * vdir[0] + m[7] * vdir[1] + m[8] * vdir[2];
+    ray_dir[1] = m[d] * vdir[0] + m[d + 1] * vdir[1] + m[d + 2] * vdir[2];
+    ray_dir[2] = m[2 * d] * vdir[0] + m[2 * d + 1] * vdir[1] + m[2 * d + 2] * vdir[2];
     precalc_basis<T>(opt.format, opt.basis_dim, tree, ray_dir, basis_fn);
 }
 
@@ -729,6 +731,7 @@ void motion_feature_trace_ray_backward(const Tree<T>& tree, const Motion<T>& mo,
 
 // transformation_matrices for the next f32 render / backward calls (test hook)
 static const float* g_xform_f32 = nullptr;
+static int g_xform_dim = 3;
 template <typename T> inline const T* current_xform() { return nullptr; }
 template <> inline const float* current_xform<float>() { return g_xform_f32; }
 
@@ -741,6 +744,7 @@ Tree<T> make_tree(const T* features, int64_t M, int K, const int32_t* data,
     for (int i = 0; i < 3; ++i) { t.offset[i] = offset[i]; t.scaling[i] = scaling[i]; }
     t.extra = extra; t.extra_rows = extra_rows; t.extra_cols = extra_cols;
     t.xform = current_xform<T>();
+    t.xform_dim = g_xform_dim;
     return t;
 }
 
@@ -798,9 +802,12 @@ int svoxt_oracle_sizeof_options(void) { return (int)sizeof(RenderOptions); }
 
 void svoxt_oracle_use_libm_exp(int on) { g_use_libm_exp = on != 0; }
 
-// [M, 3, 3] float per-leaf view rotation used by the f32 volume_render /
+// [M, dim, dim] float (dim 3 or 4) per-leaf view rotation used by the f32 volume_render /
 // volume_render_backward entry points until reset with NULL.
-void svoxt_oracle_set_transformation_matrices(const float* xform) { g_xform_f32 = xform; }
+void svoxt_oracle_set_transformation_matrices(const float* xform, int dim) {
+    g_xform_f32 = xform;
+    g_xform_dim = dim == 4 ? 4 : 3;
+}
 
 // exp for a batch (pins portable_expf against libm and against the GPU's pexpf)
 void svoxt_oracle_expf(const float* x, int64_t n, float* y) {

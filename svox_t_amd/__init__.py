@@ -10,9 +10,11 @@ Importing this package loads libsvoxt_hip.so; build it first with
 `python svox_t_amd/build.py` (there is no CPU fallback).
 """
 from svox_t_amd.helpers import DataFormat, LocalIndex, N3TreeView  # noqa: F401
-from svox_t_amd.svox import N3Tree  # noqa: F401
+from svox_t_amd.svox import (N3Tree, blend_transformation_matrix, get_transformation_matrix,  # noqa: F401
+                            warp_vertices)
 from svox_t_amd.renderer import NDCConfig, Rays, VolumeRenderer  # noqa: F401
 
 __version__ = "0.1.0"
 __all__ = ["N3Tree", "N3TreeView", "VolumeRenderer", "Rays", "NDCConfig",
-           "DataFormat", "LocalIndex"]
+           "DataFormat", "LocalIndex", "get_transformation_matrix", "warp_vertices",
+           "blend_transformation_matrix"]

@@ -58,6 +58,7 @@ class _CTree(ctypes.Structure):          # struct svoxt_tree
         ("extra_rows", ctypes.c_int32), ("extra_cols", ctypes.c_int32),
         ("weight_accum", ctypes.c_void_p), ("xform", ctypes.c_void_p),
         ("accel", ctypes.c_void_p), ("accel_log2", ctypes.c_int32),
+        ("xform_dim", ctypes.c_int32),
     ]
 
 
@@ -119,6 +120,8 @@ EXPORTS = {
     "svoxt_build_emit": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "svoxt_construct_tree": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp]),
     "svoxt_motion_render": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp, _vp, _vp]),
+    "svoxt_warp_vertices": (ctypes.c_int, [_vp, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "svoxt_warp_vertices_bwd": (ctypes.c_int, [_vp, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "svoxt_motion_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
     "svoxt_motion_feature_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CMotion), _P(_CRays), _P(_COptions), _vp, _vp, _i64, _vp]),
     "svoxt_motion_feature_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CMotion), _P(_CRays), _P(_COptions), _vp, _vp, _vp, _i64, _vp]),
@@ -261,9 +264,12 @@ def _pack_tree(tree: TreeSpec) -> _CTree:
         c.weight_accum = tree._weight_accum.data_ptr()
     if _numel(tree.transformation_matrices):
         x = tree.transformation_matrices
-        if x.dtype != torch.float32 or x.dim() != 3 or tuple(x.shape) != (tree.features.shape[0], 3, 3):
-            raise RuntimeError("transformation_matrices must be float32 [M, 3, 3]")
+        if x.dtype != torch.float32 or x.dim() != 3 or x.shape[0] != tree.features.shape[0] or \
+                tuple(x.shape[1:]) not in ((3, 3), (4, 4)):
+            raise RuntimeError("transformation_matrices must be float32 [M, 3, 3] or [M, 4, 4]")
+        _check_input(x, "transformation_matrices")
         c.xform = x.data_ptr()
+        c.xform_dim = x.shape[1]
     return c
 
 
@@ -693,6 +699,56 @@ def motion_feature_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOp
     return grad
 
 
+def _check_warp(matrices, indices, skinning_weights, joint_index):
+    _check_indices(indices)
+    for nm, x in (("matrices", matrices), ("skinning_weights", skinning_weights), ("joint_index", joint_index)):
+        _check_input(x, nm)
+    if matrices.dtype != torch.float32 or matrices.dim() != 3 or tuple(matrices.shape[1:]) != (4, 4):
+        raise RuntimeError("matrices must be float32 [n_joints, 4, 4]")
+    Q = indices.shape[0]
+    if skinning_weights.dtype != torch.float32 or skinning_weights.dim() != 2 or skinning_weights.shape[0] != Q:
+        raise RuntimeError("skinning_weights must be float32 [Q, n_bind]")
+    if joint_index.dtype != torch.int32 or joint_index.shape != skinning_weights.shape:
+        raise RuntimeError("joint_index must be int32 with the shape of skinning_weights")
+    return Q, matrices.shape[0], skinning_weights.shape[1]
+
+
+def warp_vertices(matrices: torch.Tensor, indices: torch.Tensor, skinning_weights: torch.Tensor,
+                  joint_index: torch.Tensor):
+    """svox_kernel.cu:354-378: linear blend skinning of points.  Returns
+    (vertices_out [Q, 3], matrix_out [Q, 4, 4])."""
+    Q, J, B = _check_warp(matrices, indices, skinning_weights, joint_index)
+    dev = indices.device
+    with torch.cuda.device(dev):
+        vout = torch.empty((Q, 3), dtype=torch.float32, device=dev)
+        mout = torch.empty((Q, 4, 4), dtype=torch.float32, device=dev)
+        _call("svoxt_warp_vertices", _ptr(matrices), J, _ptr(indices), Q, _ptr(skinning_weights),
+              _ptr(joint_index), B, _ptr(vout), _ptr(mout), _stream(dev))
+    return [vout, mout]
+
+
+def warp_vertices_backward(matrices: torch.Tensor, indices: torch.Tensor, skinning_weights: torch.Tensor,
+                           joint_index: torch.Tensor, indices_grad_out: torch.Tensor,
+                           matrices_grad_out: torch.Tensor):
+    """svox_kernel.cu:404-436.  Returns [grad_indices [Q, 3], grad_matrices [n_joints, 4, 4],
+    grad_skinning_weights [Q, n_bind]]."""
+    Q, J, B = _check_warp(matrices, indices, skinning_weights, joint_index)
+    _check_input(indices_grad_out, "indices_grad_out")
+    _check_input(matrices_grad_out, "matrices_grad_out")
+    if indices_grad_out.dtype != torch.float32 or tuple(indices_grad_out.shape) != (Q, 3) or \
+            matrices_grad_out.dtype != torch.float32 or tuple(matrices_grad_out.shape) != (Q, 4, 4):
+        raise RuntimeError("gradients must be float32 [Q, 3] and [Q, 4, 4]")
+    dev = indices.device
+    with torch.cuda.device(dev):
+        gi = torch.empty((Q, 3), dtype=torch.float32, device=dev)
+        gm = torch.empty((J, 4, 4), dtype=torch.float32, device=dev)
+        gs = torch.empty((Q, B), dtype=torch.float32, device=dev)
+        _call("svoxt_warp_vertices_bwd", _ptr(matrices), J, _ptr(indices), Q, _ptr(skinning_weights),
+              _ptr(joint_index), B, _ptr(indices_grad_out), _ptr(matrices_grad_out), _ptr(gi), _ptr(gm),
+              _ptr(gs), _stream(dev))
+    return [gi, gm, gs]
+
+
 def construct_tree(tree: TreeSpec, indices: torch.Tensor) -> None:
     """svox_kernel.cu:341-352: data[leaf containing point i] = i, in place on
     `tree.data`.  Where several points share a leaf the smallest index is kept
@@ -762,7 +818,6 @@ def _out_of_scope(name):
     return fn
 
 
-for _n in ("assign_vertical", "warp_vertices", "warp_vertices_backward",
-           "p2v", "p2v_backward",
+for _n in ("assign_vertical", "p2v", "p2v_backward",
            "calc_corners", "grid_weight_render", "quantize_median_cut"):
     globals()[_n] = _out_of_scope(_n)

@@ -37,7 +37,8 @@ struct TreeDev {
     int extra_rows;
     int extra_cols;
     float* weight_accum;
-    const float* __restrict__ xform;   // transformation_matrices [M, 3, 3] or null (generic kernels only)
+    const float* __restrict__ xform;   // transformation_matrices [M, d, d] or null (generic kernels only)
+    int xform_dim;                     // d: 3 or 4
     // optional acceleration grid (N == 2 only): 2^G cells per axis, one uint2 per
     // cell, see locate_accel().  Derived data: a cache of what a root descent
     // of `child` / `data` would find, never a different answer.
@@ -493,10 +494,11 @@ __device__ __forceinline__ void precalc_basis(int format, int basis_dim_rt, cons
 // is re-evaluated for ray_dir = M[idx] * vdir.
 __device__ __forceinline__ void rotated_basis(const TreeDev& tr, int format, int basis_dim, int32_t idx,
                                               const float* vdir, float* basis) {
-    const float* m = tr.xform + (int64_t)idx * 9;
+    const int d = tr.xform_dim;
+    const float* m = tr.xform + (int64_t)idx * (d * d);
     const float x = m[0] * vdir[0] + m[1] * vdir[1] + m[2] * vdir[2];
-    const float y = m[3] * vdir[0] + m[4] * vdir[1] + m[5] * vdir[2];
-    const float z = m[6] * vdir[0] + m[7] * vdir[1] + m[8] * vdir[2];
+    const float y = m[d] * vdir[0] + m[d + 1] * vdir[1] + m[d + 2] * vdir[2];
+    const float z = m[2 * d] * vdir[0] + m[2 * d + 1] * vdir[1] + m[2 * d + 2] * vdir[2];
     precalc_basis<0>(format, basis_dim, tr, x, y, z, basis);
 }
 

@@ -1007,6 +1007,8 @@ int check_tree(const svoxt_tree* t, const char* fn) {
         return fail(SVOXT_ERR_INVALID, "%s: tree too large for 32-bit slot indices", fn);
     if (t->accel != nullptr && (t->accel_log2 < 1 || t->accel_log2 > 8))
         return fail(SVOXT_ERR_INVALID, "%s: accel_log2 must be in [1, 8]", fn);
+    if (t->xform != nullptr && t->xform_dim != 0 && t->xform_dim != 3 && t->xform_dim != 4)
+        return fail(SVOXT_ERR_INVALID, "%s: xform_dim must be 3 or 4", fn);
     return SVOXT_OK;
 }
 
@@ -1052,6 +1054,7 @@ TreeDev to_dev(const svoxt_tree* t) {
     d.extra = t->extra_data; d.extra_rows = t->extra_rows; d.extra_cols = t->extra_cols;
     d.weight_accum = t->weight_accum;
     d.xform = t->xform;   // consulted by the generic render kernels only
+    d.xform_dim = t->xform_dim == 4 ? 4 : 3;
     // the grid caches data words but not slot ids: per-slot weight accumulation takes the plain descent
     const bool use_accel = t->accel != nullptr && t->N == 2 && t->weight_accum == nullptr;
     d.accel = use_accel ? reinterpret_cast<const uint2*>(t->accel) : nullptr;

@@ -260,6 +260,116 @@ motion_reduce_kernel(MotionDev mo, int64_t M, const float* __restrict__ grad_ble
     }
 }
 
+// ---------------------------------------------------------------------------
+// Linear blend skinning of points: warp_vertices (svox_kernel.cu:123-154, 354-378)
+// and its backward (:156-211, 404-436).  The per-point [4, 4] matrices it returns
+// are what callers hand to volume_render as transformation_matrices.
+// ---------------------------------------------------------------------------
+
+// blended[m][n] = sum_j (w_j > 0) w_j * matrices[joint_j][m][n], m < 3, in the reference's order
+__device__ __forceinline__ void blend_matrix(const float* __restrict__ matrices, int n_joints,
+                                             const float* __restrict__ sw, const int32_t* __restrict__ ji, int B,
+                                             float (&mo)[12]) {
+#pragma unroll
+    for (int e = 0; e < 12; ++e) mo[e] = 0.f;
+    for (int j = 0; j < B; ++j) {
+        const float w = sw[j];
+        const int32_t joint = ji[j];
+        if (w > 0.f && joint >= 0 && joint < n_joints) {
+            const float* m = matrices + (int64_t)joint * 16;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) mo[e] += w * m[e];       // rows 0..2 of a row-major 4x4: elements 0..11
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+warp_vertices_kernel(const float* __restrict__ matrices, int n_joints, const float* __restrict__ points, int64_t Q,
+                     const float* __restrict__ sw, const int32_t* __restrict__ ji, int B,
+                     float* __restrict__ vertices_out, float* __restrict__ matrix_out) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= Q) return;
+    float mo[12];
+    blend_matrix(matrices, n_joints, sw + q * B, ji + q * B, B, mo);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f* dst = reinterpret_cast<v4f*>(matrix_out + q * 16);
+    dst[0] = v4f{mo[0], mo[1], mo[2], mo[3]};
+    dst[1] = v4f{mo[4], mo[5], mo[6], mo[7]};
+    dst[2] = v4f{mo[8], mo[9], mo[10], mo[11]};
+    dst[3] = v4f{0.f, 0.f, 0.f, 1.f};                              // :148
+    const float x = points[3 * q], y = points[3 * q + 1], z = points[3 * q + 2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        vertices_out[3 * q + i] = x * mo[4 * i] + y * mo[4 * i + 1] + z * mo[4 * i + 2] + mo[4 * i + 3];   // :151-153
+}
+
+// grad_points and grad_skinning_weights are per point (written, not accumulated);
+// grad_matrices [n_joints, 4, 4] meets all points: per-workgroup LDS table, one global
+// atomic per touched cell per workgroup (USE_LDS = false: tables over 64 KiB).
+template <bool USE_LDS>
+__global__ void __launch_bounds__(256)
+warp_vertices_bwd_kernel(const float* __restrict__ matrices, int n_joints, const float* __restrict__ points,
+                         int64_t Q, const float* __restrict__ sw_all, const int32_t* __restrict__ ji_all, int B,
+                         const float* __restrict__ grad_vertices, const float* __restrict__ grad_matrix_out,
+                         float* __restrict__ grad_points, float* __restrict__ grad_matrices,
+                         float* __restrict__ grad_sw) {
+    extern __shared__ float table[];                              // [n_joints * 16] when USE_LDS
+    const int cells = n_joints * 16;
+    if constexpr (USE_LDS) {
+        for (int i = threadIdx.x; i < cells; i += 256) table[i] = 0.f;
+        __syncthreads();
+    }
+    float* dst = USE_LDS ? table : grad_matrices;
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q < Q) {
+        const float* sw = sw_all + q * B;
+        const int32_t* ji = ji_all + q * B;
+        float mo[12];
+        blend_matrix(matrices, n_joints, sw, ji, B, mo);
+        float mg[12];                                             // rows 0..2 of matrices_grad_out[q]
+#pragma unroll
+        for (int e = 0; e < 12; ++e) mg[e] = grad_matrix_out[q * 16 + e];
+        const float g0 = grad_vertices[3 * q], g1 = grad_vertices[3 * q + 1], g2 = grad_vertices[3 * q + 2];
+        const float gv[3] = {g0, g1, g2};
+        const float x = points[3 * q], y = points[3 * q + 1], z = points[3 * q + 2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            grad_points[3 * q + i] = g0 * mo[i] + g1 * mo[4 + i] + g2 * mo[8 + i];       // :193
+        float tg[12];                                             // tmp_grad_matrix (:194-197)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            tg[4 * i] = gv[i] * x; tg[4 * i + 1] = gv[i] * y; tg[4 * i + 2] = gv[i] * z; tg[4 * i + 3] = gv[i];
+        }
+        for (int j = 0; j < B; ++j) {
+            const float w = sw[j];
+            const int32_t joint = ji[j];
+            float gs = 0.f;                                       // torch::zeros (:419)
+            if (w > 0.f && joint >= 0 && joint < n_joints) {
+                const float* m = matrices + (int64_t)joint * 16;
+                // the reference adds into grad_skinning_weights[q][j] first over its loop at
+                // :176-185 (matrices_grad_out), then over the one at :200-208 (tmp_grad_matrix)
+#pragma unroll
+                for (int e = 0; e < 12; ++e) gs += m[e] * mg[e];
+#pragma unroll
+                for (int e = 0; e < 12; ++e) gs += m[e] * tg[e];
+#pragma unroll
+                for (int e = 0; e < 12; ++e) {
+                    atomicAdd(dst + joint * 16 + e, w * mg[e]);
+                    atomicAdd(dst + joint * 16 + e, w * tg[e]);
+                }
+            }
+            grad_sw[q * B + j] = gs;
+        }
+    }
+    if constexpr (USE_LDS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < cells; i += 256) {
+            const float v = table[i];
+            if (v != 0.f) atomicAdd(grad_matrices + i, v);
+        }
+    }
+}
+
 }  // namespace svoxt
 
 using namespace svoxt;
@@ -403,6 +513,57 @@ int svoxt_motion_feature_render_bwd(const svoxt_tree* tree, const svoxt_motion* 
         else
             hipLaunchKernelGGL((motion_reduce_kernel<FMAX, false>), dim3(nbm), dim3(256), 0, st, mo, tree->M, grad_blended, grad_joint_features);
     )
+    return check_launch(fn);
+}
+
+static int check_warp(const char* fn, const float* matrices, int32_t n_joints, const float* points, int64_t Q,
+                      const float* sw, const int32_t* ji, int32_t n_bind) {
+    if (Q < 0 || n_joints < 1 || n_bind < 1) return set_error(SVOXT_ERR_INVALID, "%s: bad extents", fn);
+    if (matrices == nullptr || (Q > 0 && (points == nullptr || sw == nullptr || ji == nullptr)))
+        return set_error(SVOXT_ERR_INVALID, "%s: matrices / points / skinning_weights / joint_index is NULL", fn);
+    return SVOXT_OK;
+}
+
+int svoxt_warp_vertices(const float* matrices, int32_t n_joints, const float* points, int64_t Q,
+                        const float* skinning_weights, const int32_t* joint_index, int32_t n_bind,
+                        float* vertices_out, float* matrix_out, void* stream) {
+    const char* fn = "svoxt_warp_vertices";
+    int rc;
+    if ((rc = check_warp(fn, matrices, n_joints, points, Q, skinning_weights, joint_index, n_bind))) return rc;
+    if (Q == 0) return SVOXT_OK;
+    if (vertices_out == nullptr || matrix_out == nullptr || ((uintptr_t)matrix_out & 15) != 0)
+        return set_error(SVOXT_ERR_INVALID, "%s: an output is NULL or matrix_out is not 16-byte aligned", fn);
+    hipLaunchKernelGGL(warp_vertices_kernel, dim3(blocks_of(Q, 256)), dim3(256), 0, (hipStream_t)stream,
+                       matrices, (int)n_joints, points, Q, skinning_weights, joint_index, (int)n_bind,
+                       vertices_out, matrix_out);
+    return check_launch(fn);
+}
+
+int svoxt_warp_vertices_bwd(const float* matrices, int32_t n_joints, const float* points, int64_t Q,
+                            const float* skinning_weights, const int32_t* joint_index, int32_t n_bind,
+                            const float* grad_vertices, const float* grad_matrix_out,
+                            float* grad_points, float* grad_matrices, float* grad_skinning_weights,
+                            void* stream) {
+    const char* fn = "svoxt_warp_vertices_bwd";
+    int rc;
+    if ((rc = check_warp(fn, matrices, n_joints, points, Q, skinning_weights, joint_index, n_bind))) return rc;
+    if (grad_matrices == nullptr) return set_error(SVOXT_ERR_INVALID, "%s: grad_matrices is NULL", fn);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = sizeof(float) * 16 * (size_t)n_joints;
+    const hipError_t e = hipMemsetAsync(grad_matrices, 0, bytes, st);
+    if (e != hipSuccess) return set_error(SVOXT_ERR_HIP, "%s: %s", fn, hipGetErrorString(e));
+    if (Q == 0) return SVOXT_OK;
+    if (grad_vertices == nullptr || grad_matrix_out == nullptr || grad_points == nullptr || grad_skinning_weights == nullptr)
+        return set_error(SVOXT_ERR_INVALID, "%s: a gradient pointer is NULL", fn);
+    const unsigned nb = blocks_of(Q, 256);
+    if (bytes <= 65536)
+        hipLaunchKernelGGL((warp_vertices_bwd_kernel<true>), dim3(nb), dim3(256), bytes, st, matrices, (int)n_joints,
+                           points, Q, skinning_weights, joint_index, (int)n_bind, grad_vertices, grad_matrix_out,
+                           grad_points, grad_matrices, grad_skinning_weights);
+    else
+        hipLaunchKernelGGL((warp_vertices_bwd_kernel<false>), dim3(nb), dim3(256), 0, st, matrices, (int)n_joints,
+                           points, Q, skinning_weights, joint_index, (int)n_bind, grad_vertices, grad_matrix_out,
+                           grad_points, grad_matrices, grad_skinning_weights);
     return check_launch(fn);
 }
 

@@ -46,6 +46,44 @@ class _QueryVerticalFunction(autograd.Function):
         return None, None, None
 
 
+class _WarpVerticalFunction(autograd.Function):
+    """svox_t/svox.py:58-76.  As there, gradients flow only when the
+    transformation matrices require one; then all three inputs get theirs."""
+
+    @staticmethod
+    def forward(ctx, transformation_matrix, coordinates, skinning_weights, joint_index):
+        vertices, matrices = _C.warp_vertices(transformation_matrix, coordinates, skinning_weights, joint_index)
+        ctx.save_for_backward(transformation_matrix, coordinates, skinning_weights, joint_index)
+        return vertices, matrices
+
+    @staticmethod
+    def backward(ctx, vertices_grad_out, matrices_grad_out):
+        if ctx.needs_input_grad[0]:
+            grad_indices, grad_matrices, grad_skinning_weights = _C.warp_vertices_backward(
+                *ctx.saved_tensors, vertices_grad_out.contiguous(), matrices_grad_out.contiguous())
+            return grad_matrices, grad_indices, grad_skinning_weights, None
+        return None, None, None, None
+
+
+def get_transformation_matrix(src_pose, tgt_pose):
+    """svox_t/svox.py:971-972."""
+    return torch.matmul(tgt_pose, torch.inverse(src_pose))
+
+
+def warp_vertices(transformation_matrix, coordinates, skinning_weights, joint_index):
+    """Linear blend skinning of points (svox_t/svox.py:974-976): returns
+    (warped points [Q, 3], per-point matrices [Q, 4, 4]); differentiable."""
+    return _WarpVerticalFunction.apply(transformation_matrix, coordinates, skinning_weights, joint_index)
+
+
+def blend_transformation_matrix(transformation_matrix, skinning_weights, joint_index):
+    """Per-point blended joint matrices [Q, 4, 4] (svox_t/svox.py:978-981) -- what
+    VolumeRenderer.forward takes as `transformation_matrices`."""
+    coordinates = torch.zeros((skinning_weights.size(0), 3), device=skinning_weights.device)
+    _, matrices = _C.warp_vertices(transformation_matrix, coordinates, skinning_weights, joint_index)
+    return matrices
+
+
 class N3Tree(nn.Module):
     def __init__(self, N=2, data_dim=4, depth_limit=10, init_reserve=1, init_refine=0,
                  geom_resize_fact=1.5, radius=0.5, center=(0.5, 0.5, 0.5),

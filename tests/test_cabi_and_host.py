@@ -36,14 +36,16 @@ def test_struct_layouts_match_header(tmp_path):
     import subprocess
     src = tmp_path / "probe.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "svoxt.h"\n'
-                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(svoxt_options), sizeof(svoxt_rays),'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu ", sizeof(svoxt_options), sizeof(svoxt_rays),'
                    ' sizeof(svoxt_tree), sizeof(svoxt_sample_lists), offsetof(svoxt_rays, c2w), offsetof(svoxt_rays, fy),'
-                   ' offsetof(svoxt_tree, accel_log2)); return 0;}\n')
+                   ' offsetof(svoxt_tree, accel_log2)); printf("%zu %zu\\n", offsetof(svoxt_tree, xform_dim),'
+                   ' sizeof(svoxt_motion)); return 0;}\n')
     exe = tmp_path / "probe"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert got == [ctypes.sizeof(_C._COptions), ctypes.sizeof(_C._CRays), ctypes.sizeof(_C._CTree),
-                   ctypes.sizeof(_C._CLists), _C._CRays.c2w.offset, _C._CRays.fy.offset, _C._CTree.accel_log2.offset]
+                   ctypes.sizeof(_C._CLists), _C._CRays.c2w.offset, _C._CRays.fy.offset, _C._CTree.accel_log2.offset,
+                   _C._CTree.xform_dim.offset, ctypes.sizeof(_C._CMotion)]
     assert got[:3] == [44, 56, 112]
 
 

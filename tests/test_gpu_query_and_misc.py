@@ -157,6 +157,8 @@ def test_rejects_noncontiguous_and_wrong_dtype(gpu):
         r(tree.features, svox.Rays(rays.origins.double(), rays.dirs.double(), rays.viewdirs.double()))
     with pytest.raises(RuntimeError, match="M, 3, 3"):
         r(tree.features, rays, transformation_matrices=torch.eye(3, device=gpu).repeat(5, 1, 1))
+    with pytest.raises(RuntimeError, match="M, 4, 4"):
+        r(tree.features, rays, transformation_matrices=torch.zeros(tree.features.shape[0], 3, 4, device=gpu))
 
 
 def test_weight_accumulation(gpu):
