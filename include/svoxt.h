@@ -82,7 +82,7 @@ typedef struct svoxt_tree {
     float*         weight_accum; /* device [capacity * N^3] or NULL (TreeSpec._weight_accum) */
     const float*   xform;        /* device [M,d,d] TreeSpec.transformation_matrices (per-leaf rotation of the view
                                     direction by the upper-left 3x3, rt_kernel.cu:283-291) or NULL;
-                                    volume_render fwd/bwd only; d = xform_dim below */
+                                    volume_render fwd/bwd only (ignored by the other entry points); d = xform_dim below */
     const void*    accel;        /* device, optional: acceleration grid built by svoxt_accel_build for THIS
                                     child/data content (N == 2), or NULL.  Pure cache: results are identical
                                     with or without it; rebuild after any change to child or data. */

@@ -427,6 +427,13 @@ class SampleLists:
         return _CLists(self.rec.data_ptr(), self.aux.data_ptr(), self.S)
 
 
+def can_record(tree: TreeSpec, opt: RenderOptions) -> bool:
+    """True when volume_render(..., record=True) can hand sample lists to the backward
+    (a specialised payload, both thresholds 0; include/svoxt.h svoxt_can_record)."""
+    ct, co = _pack_tree(tree), _pack_opts(opt)
+    return bool(_lib.svoxt_can_record(ctypes.byref(ct), ctypes.byref(co)))
+
+
 def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bool = False):
     """rt_kernel.cu:1362-1379.
 

@@ -502,6 +502,16 @@ __device__ __forceinline__ void rotated_basis(const TreeDev& tr, int format, int
     precalc_basis<0>(format, basis_dim, tr, x, y, z, basis);
 }
 
+template <int BD>
+__device__ __forceinline__ void rotated_sh_basis(const TreeDev& tr, int32_t idx, const float* vdir, float* basis) {
+    const int d = tr.xform_dim;
+    const float* m = tr.xform + (int64_t)idx * (d * d);
+    const float x = m[0] * vdir[0] + m[1] * vdir[1] + m[2] * vdir[2];
+    const float y = m[d] * vdir[0] + m[d + 1] * vdir[1] + m[d + 2] * vdir[2];
+    const float z = m[2 * d] * vdir[0] + m[2 * d + 1] * vdir[1] + m[2 * d + 2] * vdir[2];
+    precalc_basis<BD>(FMT_SH, BD, tr, x, y, z, basis);
+}
+
 // The reference's `w / (1.0 + expf(-x))` family is evaluated in double
 // (rt_kernel.cu:300,304,408,420,472,476).
 __device__ __forceinline__ double sigmoid_d(float x) {

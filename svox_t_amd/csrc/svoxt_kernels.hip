@@ -67,10 +67,13 @@ __device__ __forceinline__ uint2 rec_get(const uint2* p) {
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 
-template <int FMT, int C, int BD, bool N2, bool REC>
+// XF (SH only): per-leaf view rotations (tree.xform): the basis is re-evaluated
+// for every composited sample with the leaf's matrix (rt_kernel.cu:283-291).
+template <int FMT, int C, int BD, bool N2, bool REC, bool XF = false>
 __global__ void __launch_bounds__(kBlock)
 render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
                   uint2* __restrict__ rec, int S, uint4* __restrict__ aux) {
+    static_assert(!XF || FMT == FMT_SH, "view rotations only matter for view-dependent formats");
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     if (q >= rays.Q) return;
@@ -88,10 +91,10 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
     bool over = false;
     float t_resume = 0.f;
     float basis[BD > 0 ? BD : 1];
+    float vd[3] = {0.f, 0.f, 0.f};
     if constexpr (FMT == FMT_SH) {
-        float vd[3];
         load_vdir(rays, q, vd);
-        precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
+        if constexpr (!XF) precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
     }
     float acc[C];
 #pragma unroll
@@ -132,6 +135,7 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
                 const float att = pexpf(-delta_t * r.delta_scale * sigma);
                 const float weight = light * (1.f - att);
                 if constexpr (FMT == FMT_SH) {
+                    if constexpr (XF) rotated_sh_basis<BD>(tr, idx, vd, basis);
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         float tmp = 0.f;
@@ -261,10 +265,14 @@ render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __re
 // Colour / sigma contributions of one sample -> staging row `st`; advances the
 // ray's transmittance and the running `accum` exactly as pass 2 of the
 // reference does.
-template <int FMT, int C, int BD, int K>
+// XF: `basis` is the sample's own (rotated) basis, used for the colour terms;
+// `basis_sig` is the one the reference's second pass sees for total_color -- the
+// basis its first pass ended with (rt_kernel.cu:439-494 never re-evaluates it).
+template <int FMT, int C, int BD, int K, bool XF = false>
 __device__ __forceinline__ void stage_sample(const float (&row)[K], const float* basis, const float* g,
                                              float delta_t, float delta_scale, float light_ray,
-                                             float& light, float& accum, float* __restrict__ st) {
+                                             float& light, float& accum, float* __restrict__ st,
+                                             const float* basis_sig = nullptr) {
     const float sigma = row[K - 1];
     const float att = pexpf(-delta_t * sigma * delta_scale);
     const float weight = light * (1.f - att);
@@ -280,7 +288,14 @@ __device__ __forceinline__ void stage_sample(const float (&row)[K], const float*
             const float gsig = (float)((double)sig * (1.0 - (double)sig));
 #pragma unroll
             for (int i = 0; i < BD; ++i) st[c * BD + i] = weight * basis[i] * gsig * g[c];
-            total_color = (float)((double)total_color + sd * (double)g[c]);
+            if constexpr (XF) {
+                float tmp2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < BD; ++i) tmp2 += basis_sig[i] * row[c * BD + i];
+                total_color = (float)((double)total_color + sigmoid_d(tmp2) * (double)g[c]);
+            } else {
+                total_color = (float)((double)total_color + sd * (double)g[c]);
+            }
         }
     } else {
 #pragma unroll
@@ -323,7 +338,7 @@ __device__ __forceinline__ void accum_sample(const float (&row)[K], const float*
 
 // REPLAY: rec / aux were filled by render_fwd_kernel<..., REC=true> for the
 // same tree, rays and options: pass 1 walks the list instead of the tree.
-template <int FMT, int C, int BD, bool N2, bool REPLAY>
+template <int FMT, int C, int BD, bool N2, bool REPLAY, bool XF = false>
 __global__ void __launch_bounds__(kBlock)
 render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                   float* __restrict__ grad, int gstride, uint2* __restrict__ rec, int S,
@@ -343,16 +358,22 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     if (alive) alive = setup_ray(tr, rays, opt, q, r);
     if (!__any(alive)) return;
 
-    float basis[BD > 0 ? BD : 1];
+    static_assert(!XF || FMT == FMT_SH, "view rotations only matter for view-dependent formats");
+    float basis[BD > 0 ? BD : 1];          // the unrotated basis; with XF: scratch for the current sample's
+    float basis_last[XF ? BD : 1];         // XF: the basis pass 1 ends with, which pass 2's total_color uses
+    float vd[3] = {0.f, 0.f, 0.f};
     float g[C + 1];
     if (alive) {
         if constexpr (FMT == FMT_SH) {
-            float vd[3];
-        load_vdir(rays, q, vd);
+            load_vdir(rays, q, vd);
             precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
         }
 #pragma unroll
         for (int j = 0; j <= C; ++j) g[j] = grad_out[q * (C + 1) + j];
+    }
+    if constexpr (XF) {
+#pragma unroll
+        for (int i = 0; i < BD; ++i) basis_last[i] = basis[i];     // a ray without samples never evaluates another
     }
 
     float accum = 0.f;
@@ -362,6 +383,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     float tmax2 = -1.f;           // ... and until where (-1: nothing left to march)
     if (alive) {   // pass 1
         bool skip_pass1 = false;
+        int32_t last_idx = -1;    // XF: feature row of the ray's last composited sample
         float light = 1.f, t = r.tmin;
         t_resume = r.tmin;
         tmax2 = (S > 0) ? -1.f : r.tmax;
@@ -381,15 +403,22 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 for (int c = 0; c < C; ++c) accum += g[c] * o[c];
                 light_ray = __uint_as_float(a.z);
                 skip_pass1 = true;
+                if constexpr (XF) {
+                    if (nrec > 0) last_idx = (int32_t)rec_get(rec + ((int64_t)(nrec - 1) * rays.Q + q)).x;
+                }
             } else {
                 for (int k = 0; k < nrec; ++k) {
                     const uint2 e = rec_get(rec + ((int64_t)k * rays.Q + q));
                     float row[K];
                     load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
+                    if constexpr (XF) { rotated_sh_basis<BD>(tr, (int32_t)e.x, vd, basis); last_idx = (int32_t)e.x; }
                     accum_sample<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, light, accum);
                 }
             }
-            t = (tmax2 < 0.f || skip_pass1) ? r.tmax : t_resume;   // march only what the list does not cover
+            // march only what the list does not cover (with the forward's output at hand
+            // that is nothing -- unless XF still has to find the last sample past the list)
+            const bool tail = tmax2 >= 0.f && (!skip_pass1 || XF);
+            t = tail ? t_resume : r.tmax;
         }
         while (t < r.tmax) {
             Sample s;
@@ -409,7 +438,11 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                             }
                         }
                     }
-                    accum_sample<FMT, C, BD, K>(row, basis, g, s.delta_t, r.delta_scale, light, accum);
+                    if constexpr (XF) last_idx = s.idx;
+                    if (!skip_pass1) {
+                        if constexpr (XF) rotated_sh_basis<BD>(tr, s.idx, vd, basis);
+                        accum_sample<FMT, C, BD, K>(row, basis, g, s.delta_t, r.delta_scale, light, accum);
+                    }
                 }
             }
             t = march_advance(t, s.delta_t);
@@ -420,6 +453,9 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             for (int j = 0; j < C; ++j) total_grad += g[j];
             accum += light * opt.background_brightness * total_grad;
             light_ray = light;
+        }
+        if constexpr (XF) {
+            if (last_idx >= 0) rotated_sh_basis<BD>(tr, last_idx, vd, basis_last);
         }
     }
 
@@ -456,8 +492,14 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         if (active) {
             const int slot = __popcll(amask & lane_lt);       // compact: staging row = rank among active lanes
             sidx[slot] = idx;
-            stage_sample<FMT, C, BD, K>(row, basis, g, delta_t, r.delta_scale, light_ray,
-                                        light, accum, stage + slot * KS);
+            if constexpr (XF) {
+                rotated_sh_basis<BD>(tr, idx, vd, basis);
+                stage_sample<FMT, C, BD, K, true>(row, basis, g, delta_t, r.delta_scale, light_ray,
+                                                  light, accum, stage + slot * KS, basis_last);
+            } else {
+                stage_sample<FMT, C, BD, K>(row, basis, g, delta_t, r.delta_scale, light_ray,
+                                            light, accum, stage + slot * KS);
+            }
         }
         flush_staged<K, KS>(stage, sidx, __popcll(amask), lane, grad, gstride);
     }
@@ -1100,6 +1142,54 @@ bool full_comp(const svoxt_options* o) {
     return o->format == SVOXT_FORMAT_RGBA || (o->min_comp == 0 && o->max_comp == o->basis_dim - 1);
 }
 
+// specialised kernels with per-leaf view rotations: SH payloads on N = 2 trees
+template <bool REC>
+bool launch_fwd_xform(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C, float* out,
+                      uint2* rec, int S, uint4* aux, hipStream_t st) {
+    if (opt.format != FMT_SH || C != 3) return false;
+    const unsigned nb = nblocks(rays.Q);
+#define SVOXT_FWD_XF(BB)                                                                                    \
+    hipLaunchKernelGGL((render_fwd_kernel<FMT_SH, 3, BB, true, REC, true>), dim3(nb), dim3(kBlock), 0, st,  \
+                       tr, rays, opt, out, rec, S, aux);                                                    \
+    return true;
+    switch (opt.basis_dim) {
+        case 1: SVOXT_FWD_XF(1)
+        case 4: SVOXT_FWD_XF(4)
+        case 9: SVOXT_FWD_XF(9)
+        case 16: SVOXT_FWD_XF(16)
+        case 25: SVOXT_FWD_XF(25)
+    }
+#undef SVOXT_FWD_XF
+    return false;
+}
+
+template <bool REPLAY>
+bool launch_bwd_xform(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
+                      const float* grad_out, float* grad, int gstride, uint2* rec, int S, const uint4* aux,
+                      const float* fwd_out, hipStream_t st) {
+    if (opt.format != FMT_SH || C != 3) return false;
+    const unsigned nb = nblocks(rays.Q);
+#define SVOXT_BWD_XF(BB)                                                                                      \
+    hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, REPLAY, true>), dim3(nb), dim3(kBlock), 0, st, \
+                       tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out);                         \
+    return true;
+    switch (opt.basis_dim) {
+        case 1: SVOXT_BWD_XF(1)
+        case 4: SVOXT_BWD_XF(4)
+        case 9: SVOXT_BWD_XF(9)
+        case 16: SVOXT_BWD_XF(16)
+        case 25: SVOXT_BWD_XF(25)
+    }
+#undef SVOXT_BWD_XF
+    return false;
+}
+
+// can the specialised kernels serve this tree / options pair with its view rotations?
+bool xform_special(const svoxt_tree* t, const svoxt_options* o) {
+    return t->N == 2 && o->format == SVOXT_FORMAT_SH && t->K == 3 * o->basis_dim + 1 &&
+           (o->basis_dim == 1 || o->basis_dim == 4 || o->basis_dim == 9 || o->basis_dim == 16 || o->basis_dim == 25);
+}
+
 template <bool N2, bool REC>
 bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C, float* out,
                         uint2* rec, int S, uint4* aux, hipStream_t st) {
@@ -1178,9 +1268,19 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
     const Opts od = to_dev(opt);
     const bool n2 = tree->N == 2;
     bool done = false;
-    if (uses_xform(tree, opt) && lists != nullptr)
-        return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists with transformation_matrices", fn);
-    if (C > 0 && full_comp(opt) && !uses_xform(tree, opt))
+    const bool xf = uses_xform(tree, opt);
+    if (xf && lists != nullptr && !(full_comp(opt) && xform_special(tree, opt)))
+        return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists with transformation_matrices need an SH payload on an N = 2 tree", fn);
+    if (C > 0 && full_comp(opt) && xf && xform_special(tree, opt)) {
+        int64_t S = (workspace != nullptr && workspace_bytes > 0) ? workspace_bytes / (8 * rays->Q) : 0;
+        if (S > 4096) S = 4096;
+        if (lists != nullptr)
+            done = launch_bwd_xform<true>(tr, rd, od, C, grad_out, grad_features, gs, reinterpret_cast<uint2*>(lists->rec),
+                                          lists->max_samples, reinterpret_cast<const uint4*>(lists->aux), fwd_out, st);
+        else
+            done = launch_bwd_xform<false>(tr, rd, od, C, grad_out, grad_features, gs,
+                                           S > 0 ? reinterpret_cast<uint2*>(workspace) : nullptr, (int)S, nullptr, nullptr, st);
+    } else if (C > 0 && full_comp(opt) && !xf)
     {
         // per-ray sample lists: S entries of 8 bytes per ray, laid out rec[k][q]
         int64_t S = (workspace != nullptr && workspace_bytes > 0) ? workspace_bytes / (8 * rays->Q) : 0;
@@ -1246,8 +1346,8 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
     if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) || (rc = check_opts(opt, tree, fn, true)))
         return rc;
     if (lists != nullptr && (rc = check_lists(lists, opt, fn))) return rc;
-    if (lists != nullptr && uses_xform(tree, opt))
-        return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists with transformation_matrices", fn);
+    if (lists != nullptr && uses_xform(tree, opt) && !(full_comp(opt) && xform_special(tree, opt)))
+        return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists with transformation_matrices need an SH payload on an N = 2 tree", fn);
     if (rays->Q == 0) return SVOXT_OK;
     if (out == nullptr) return fail(SVOXT_ERR_INVALID, "%s: out is NULL", fn);
     const int C = svoxt_out_data_dim(opt, tree->K) - 1;
@@ -1261,8 +1361,15 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
     const bool n2 = tree->N == 2;
     bool done = false;
     if (uses_xform(tree, opt)) {
-        // per-leaf view rotations re-evaluate the basis per sample: generic kernel only
-        if (lists != nullptr) return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists with transformation_matrices", fn);
+        // per-leaf view rotations re-evaluate the basis per sample: specialised for SH
+        // payloads on N = 2 trees, the generic kernel otherwise
+        if (full_comp(opt) && xform_special(tree, opt)) {
+            if (lists != nullptr)
+                done = launch_fwd_xform<true>(tr, rd, od, C, out, reinterpret_cast<uint2*>(lists->rec),
+                                              lists->max_samples, reinterpret_cast<uint4*>(lists->aux), st);
+            else
+                done = launch_fwd_xform<false>(tr, rd, od, C, out, nullptr, 0, nullptr, st);
+        }
     } else if (full_comp(opt)) {
         if (lists != nullptr) {
             uint2* rec = reinterpret_cast<uint2*>(lists->rec);
@@ -1289,8 +1396,9 @@ int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
 }
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt) {
-    if (tree == nullptr || opt == nullptr || uses_xform(tree, opt)) return 0;
+    if (tree == nullptr || opt == nullptr) return 0;
     if (opt->sigma_thresh != 0.f || opt->stop_thresh != 0.f || !full_comp(opt)) return 0;
+    if (uses_xform(tree, opt)) return xform_special(tree, opt) ? 1 : 0;
     const int C = svoxt_out_data_dim(opt, tree->K) - 1;
     if (opt->format == SVOXT_FORMAT_RGBA) return (C == 3 || C == 31) ? 1 : 0;
     if (opt->format == SVOXT_FORMAT_SH && C == 3 && tree->K == 3 * opt->basis_dim + 1)

@@ -375,28 +375,58 @@ def test_acceleration_grid_never_goes_stale(gpu):
     np.testing.assert_array_equal(got, O.volume_render(ot, *c.rays_np(), opt))
 
 
-def test_transformation_matrices(gpu):
+@pytest.mark.parametrize("fmt,K,depth,mode", [
+    ("SH9", 28, 5, "lists"),          # specialised kernels, forward-recorded lists, single-march backward
+    ("SH9", 28, 6, "overflow"),       # ... with lists of 4 samples: most rays march their tail
+    ("SH9", 28, 5, "exact"),          # ... two list walks (SVOXT_BWD_EXACT)
+    ("SH9", 28, 5, "standalone"),     # ... backward without forward lists (own workspace)
+    ("SH4", 13, 5, "lists"),
+    ("SH16", 49, 4, "lists"),
+    ("SG6", 19, 4, "generic"),        # view-dependent format without a specialised kernel
+])
+def test_transformation_matrices(gpu, monkeypatch, fmt, K, depth, mode):
     """Per-leaf rotation of the view direction (rt_kernel.cu:283-291, :387-395),
     including the reference's quirk that pass 2 of the backward keeps the basis
-    of the last sample of pass 1."""
-    c = Case(depth=5, K=28, data_format="SH9", width=48, height=48)
-    tree = c.tree(gpu)
+    of the last sample of pass 1 -- through every route the backward can take."""
+    c = Case(depth=depth, K=K, data_format=fmt, width=48, height=48)
+    extra = None
+    if fmt.startswith("SG"):
+        ge = torch.Generator().manual_seed(4)
+        extra = torch.cat([torch.rand(6, 1, generator=ge) * 4 + 0.5,
+                           torch.nn.functional.normalize(torch.randn(6, 3, generator=ge), dim=-1)], -1)
+    tree = svox.N3Tree.from_arrays(c.st.child, c.st.data, c.st.parent_depth, c.features, data_format=fmt,
+                                   extra_data=extra, device=gpu)
     M = tree.features.shape[0]
     g = torch.Generator().manual_seed(9)
     A = torch.randn(M, 3, 3, generator=g)
     Qm, _ = torch.linalg.qr(A)                                # random rotations
+    if mode == "overflow":
+        monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", 4)
+    if mode == "exact":
+        monkeypatch.setattr(_C, "BWD_EXACT", True)
     r = svox.VolumeRenderer(tree)
     rays = c.rays_gpu(gpu)
-    out = r(tree.features, rays, transformation_matrices=Qm.to(gpu).contiguous())
+    xf = Qm.to(gpu).contiguous()
+    ot = O.Tree(c.features.numpy(), c.st.data, c.st.child, extra=None if extra is None else extra.numpy())
+    opt = c.oracle_opts()
+    spec = tree._spec(tree.features, transformation_matrices=xf)
+    assert _C.can_record(spec, r._get_options()) == (mode != "generic")
+    out = r(tree.features, rays, transformation_matrices=xf)
     with O.transformation_matrices(Qm.numpy()):
-        want = O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts())
+        want = O.volume_render(ot, *c.rays_np(), opt)
         gout = synth.grad_output(c.Q, 4)
-        gw, ab = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), gout.numpy(), want_abs=True)
+        gw, ab = O.volume_render_backward(ot, *c.rays_np(), opt, gout.numpy(), want_abs=True)
     np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
-    plain = O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts())
+    plain = O.volume_render(ot, *c.rays_np(), opt)
     assert np.abs(plain - want).max() > 1e-3                  # the rotations do change the image
-    out.backward(gout.to(gpu))
-    assert_grads_close(tree.features.grad.cpu().numpy(), gw, ab)
+    if mode == "standalone":
+        grad = _C.volume_render_backward(spec, _rays_spec_from_rays(rays), r._get_options(), gout.to(gpu))
+        assert_grads_close(grad.cpu().numpy(), gw, ab)
+    else:
+        out.backward(gout.to(gpu))
+        assert_grads_close(tree.features.grad.cpu().numpy(), gw, ab)
+    if fmt != "SH9" or mode != "lists":
+        return
     # identity matrices reproduce the plain render exactly
     eye = torch.eye(3).repeat(M, 1, 1).contiguous()
     with torch.no_grad():
