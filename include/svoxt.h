@@ -167,9 +167,9 @@ int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
  * rt_kernel.cu:365-494).  Rays with more than max_samples composited samples
  * march the remainder, so the result does not depend on max_samples.  Needs
  * sigma_thresh == stop_thresh == 0 (the reference's backward ignores both) and
- * one of the specialised payloads (svoxt_can_record returns 1); the lists are
- * valid for the tree, features' sign of sigma, rays and options they were
- * recorded with. */
+ * one of the specialised payloads (svoxt_can_record returns 1; with tree->xform
+ * set: SH payloads on N = 2 trees); the lists are valid for the tree, features'
+ * sign of sigma, rays and options they were recorded with. */
 typedef struct svoxt_sample_lists {
     void*   rec;           /* device, max_samples * Q * 8 bytes */
     void*   aux;           /* device, Q * 16 bytes: count | overflow, resume point, final transmittance, pad */
