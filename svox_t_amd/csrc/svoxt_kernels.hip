@@ -5,9 +5,11 @@
 // wavefront takes 64 consecutive rays, or an 8x8 pixel tile when the caller says
 // the batch is an image.  The per-ray output accumulators live in registers for
 // the specialised payloads (RGBA C=3 / C=31, SH with 1/4/9/16/25 basis functions
-// x 3 channels) and in global memory only for the generic fallback (any K / SG /
-// ASG / component sub-ranges / per-leaf view rotations), which mirrors the
-// reference's read-modify-write of `out` (svox_t/csrc/rt_kernel.cu:300,304).
+// x 3 channels; the SH ones also with per-leaf view rotations, XF) and in global
+// memory only for the generic fallback (any K / SG / ASG / component sub-ranges /
+// view rotations on other payloads), which mirrors the reference's
+// read-modify-write of `out` (svox_t/csrc/rt_kernel.cu:300,304).  Rays come from
+// tensors or, in camera mode, are generated per pixel (svoxt_device.h setup_ray).
 //
 // Kernels, in file order:
 //   render_fwd_kernel          trace_ray; optionally records each ray's composited samples
@@ -17,8 +19,10 @@
 //   render_bwd_generic_kernel  fallback backward, per-lane atomics (opacity backward, K > 64)
 //   render_bwd_generic_staged_kernel  fallback backward with LDS-staged, shaped atomics
 //   opacity_fwd_kernel, depth_kernel, count_fwd_kernel
-//   query_fwd_kernel, query_bwd_kernel
+//   query_fwd_kernel, query_bwd_kernel, leaves_count / scan / scatter kernels
 //   compact_rows_kernel, accel_build_kernel
+// Other translation units of the library: svoxt_build.hip (octree from a point
+// cloud, construct_tree), svoxt_motion.hip (motion variants, point skinning).
 // The design rationale and the measurements behind each choice are in DESIGN.md 5.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
