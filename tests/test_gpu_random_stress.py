@@ -101,3 +101,56 @@ def test_random_tree_and_rays(gpu, seed, N, fmt, K):
     np.testing.assert_array_equal(vals.cpu().numpy(), wv)
     np.testing.assert_array_equal(nid.cpu().numpy(), wn)
     np.testing.assert_array_equal(did.cpu().numpy(), wd)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_random_tree_view_rotations_and_motion(gpu, seed):
+    """The same adversarial trees and rays through the view-rotation kernels (arbitrary,
+    not even orthonormal, 4x4 matrices; with and without thresholds) and the motion
+    variants."""
+    t, feats = random_tree(seed, N=2, max_depth=6, data_format="SH4", K=13)
+    n = t.n_internal
+    M = feats.shape[0]
+    o, d, v = random_rays(300 + seed, 5000, t)
+    g = torch.Generator().manual_seed(seed)
+    joints = torch.randn(9, 5, generator=g)
+    data_np, child_np = t.data[:n].numpy().copy(), t.child[:n].numpy().copy()
+    off, scl = t.offset.numpy().copy(), t.invradius.numpy().copy()
+    ot = O.Tree(feats.numpy(), data_np, child_np, offset=off, scaling=scl, extra=joints.numpy())
+    xf = torch.randn(M, 4, 4, generator=g)
+    tg = svox.N3Tree.from_arrays(child_np, data_np, t.parent_depth[:n].numpy(), feats, data_format="SH4",
+                                 radius=[0.7, 1.3, 0.9], center=[0.2, -0.1, 0.4], extra_data=joints, device=gpu)
+    np.testing.assert_array_equal(tg.offset.cpu().numpy(), off)
+    r = svox.VolumeRenderer(tg, step_size=2e-3, background_brightness=0.5)
+    rays = svox.Rays(o.to(gpu), d.to(gpu), v.to(gpu))
+    rnp = (o.numpy(), d.numpy(), v.numpy())
+    for fast in (False, True):
+        th = 1e-2 if fast else 0.0
+        opt = O.make_options(step_size=2e-3, background_brightness=0.5, format=O.FORMAT_SH, basis_dim=4,
+                             sigma_thresh=th, stop_thresh=th)
+        opt0 = O.make_options(step_size=2e-3, background_brightness=0.5, format=O.FORMAT_SH, basis_dim=4)
+        f = feats.to(gpu).requires_grad_(True)
+        out = r(f, rays, transformation_matrices=xf.to(gpu), fast=fast)
+        gout = synth.grad_output(len(o), 4, seed=seed)
+        out.backward(gout.to(gpu))
+        with O.transformation_matrices(xf.numpy()):
+            want = O.volume_render(ot, *rnp, opt)
+            gw, ab = O.volume_render_backward(ot, *rnp, opt0, gout.numpy(), want_abs=True)
+        np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
+        assert_grads_close(f.grad.cpu().numpy(), gw, ab)
+        # motion variants
+        got = r.motion_render(feats.to(gpu), rays, fast=fast)
+        for a, b in zip(got, O.motion_render(ot, *rnp, opt)):
+            np.testing.assert_array_equal(a.cpu().numpy(), b)
+        jf = torch.randn(9, 7, generator=g)
+        sw = torch.rand(M, 3, generator=g)
+        sw[torch.rand(M, 3, generator=g) < 0.3] = 0.0
+        ji = torch.randint(0, 9, (M, 3), generator=g, dtype=torch.int32)
+        jft = jf.to(gpu).requires_grad_(True)
+        mf = r.motion_feature_render(feats.to(gpu), jft, sw.to(gpu), ji.to(gpu), rays, fast=fast)
+        mo = O.Motion(jf.numpy(), sw.numpy(), ji.numpy())
+        np.testing.assert_array_equal(mf.detach().cpu().numpy(), O.motion_feature_render(ot, mo, *rnp, opt))
+        gm = synth.grad_output(len(o), 7, seed=seed + 5)
+        mf.backward(gm.to(gpu))
+        wg, wabs = O.motion_feature_render_backward(ot, mo, *rnp, opt0, gm.numpy(), want_abs=True)
+        assert_grads_close(jft.grad.cpu().numpy(), wg, wabs)
