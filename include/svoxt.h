@@ -290,6 +290,15 @@ int svoxt_build_emit(const float* points, int64_t P, const float* offset, const 
                      int32_t* child, int32_t* data, int32_t* parent_depth,
                      int64_t n_internal, int32_t empty_index, void* stream);
 
+/* N3Tree.refine for an explicit selector (svox.py:520-546; any N): leaf i of
+ * leaf_node (device [n_leaves, 4] int64 rows (node, u, v, w), unique, each a leaf
+ * slot of a node < filled) becomes internal node filled + i: child[leaf] = offset to
+ * it, its N^3 slots inherit the leaf's data word and have child 0, parent_depth =
+ * (packed leaf id -- or node_id[i] when node_id is given -- , depth of the leaf's node
+ * + 1).  Rows [filled, filled + n_leaves) of the three tables must exist (capacity). */
+int svoxt_refine(const int64_t* leaf_node, int64_t n_leaves, int32_t N, int64_t filled, int64_t capacity,
+                 int32_t* child, int32_t* data, int32_t* parent_depth, const int32_t* node_id, void* stream);
+
 /* construct_tree (svox.py:160-161, svox_kernel.cu:110-121, 341-352) on an existing
  * tree of any N: data[leaf containing point i] = i; of several points in one
  * leaf the smallest index is kept (the reference: whichever wrote last).

@@ -119,6 +119,7 @@ EXPORTS = {
     "svoxt_build_count": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp]),
     "svoxt_build_emit": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "svoxt_construct_tree": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp]),
+    "svoxt_refine": (ctypes.c_int, [_vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "svoxt_motion_render": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp, _vp, _vp]),
     "svoxt_warp_vertices": (ctypes.c_int, [_vp, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
     "svoxt_warp_vertices_bwd": (ctypes.c_int, [_vp, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -754,6 +755,31 @@ def warp_vertices_backward(matrices: torch.Tensor, indices: torch.Tensor, skinni
               _ptr(joint_index), B, _ptr(indices_grad_out), _ptr(matrices_grad_out), _ptr(gi), _ptr(gm),
               _ptr(gs), _stream(dev))
     return [gi, gm, gs]
+
+
+def refine_leaves(child: torch.Tensor, data: torch.Tensor, parent_depth: torch.Tensor, filled: int,
+                  leaf_node: torch.Tensor, node_id: torch.Tensor = None) -> None:
+    """The table updates of N3Tree.refine for the leaves in `leaf_node` [U, 4] int64
+    (svox.py:535-546), in place, as one kernel (not an entry of the reference's
+    extension, which does this with tensor ops).  The tables must have room for
+    filled + U nodes."""
+    for nm, x in (("child", child), ("data", data), ("parent_depth", parent_depth), ("leaf_node", leaf_node)):
+        _check_input(x, nm)
+    if leaf_node.dtype != torch.int64 or leaf_node.dim() != 2 or leaf_node.shape[1] != 4:
+        raise RuntimeError("leaf_node must be int64 [U, 4]")
+    if child.dtype != torch.int32 or data.dtype != torch.int32 or parent_depth.dtype != torch.int32:
+        raise RuntimeError("child / data / parent_depth must be int32")
+    if node_id is not None:
+        _check_input(node_id, "node_id")
+        if node_id.dtype != torch.int32 or node_id.numel() != leaf_node.shape[0]:
+            raise RuntimeError("node_id must be int32 [U]")
+    dev = child.device
+    with torch.cuda.device(dev):
+        _call("svoxt_refine", _ptr(leaf_node), leaf_node.shape[0], child.shape[1], int(filled), child.shape[0],
+              _ptr(child), _ptr(data), _ptr(parent_depth), _ptr(node_id), _stream(dev))
+    for t in (child, data, parent_depth):
+        torch.autograd.graph.increment_version(t)
+    _ACCEL_CACHE.pop(id(child), None)
 
 
 def construct_tree(tree: TreeSpec, indices: torch.Tensor) -> None:

@@ -391,6 +391,29 @@ construct_kernel(TreeDev tr, const float* __restrict__ points, int64_t P, int pa
     else atomicMin(d, (int32_t)i);
 }
 
+// N3Tree.refine for an explicit leaf list (svox.py:520-546) on a tree of any N:
+// leaf i of the list becomes internal node `filled + i`; its N^3 slots inherit the
+// leaf's data word; child / parent_depth bookkeeping as refine() does with tensor ops.
+__global__ void __launch_bounds__(kBuildBlock)
+refine_kernel(const int64_t* __restrict__ leaf_node, int64_t U, int N, int64_t filled,
+              int32_t* __restrict__ child, int32_t* __restrict__ data, int32_t* __restrict__ parent_depth,
+              const int32_t* __restrict__ node_id) {
+    const int64_t i = (int64_t)blockIdx.x * kBuildBlock + threadIdx.x;
+    if (i >= U) return;
+    const int64_t* ln = leaf_node + 4 * i;
+    const int64_t n3 = (int64_t)N * N * N;
+    const int64_t slot = ((ln[0] * N + ln[1]) * N + ln[2]) * N + ln[3];
+    const int64_t node = filled + i;
+    child[slot] = (int32_t)(node - ln[0]);                       // :535-536
+    const int32_t word = data[slot];
+    for (int64_t k = 0; k < n3; ++k) {                            // :537-538
+        data[node * n3 + k] = word;
+        child[node * n3 + k] = 0;
+    }
+    parent_depth[2 * node + 0] = node_id != nullptr ? node_id[i] : (int32_t)slot;   // :539 (_pack_index)
+    parent_depth[2 * node + 1] = parent_depth[2 * ln[0] + 1] + 1;                   // :540-541
+}
+
 }  // namespace svoxt
 
 using namespace svoxt;
@@ -502,6 +525,21 @@ int svoxt_construct_tree(const svoxt_tree* t, const float* points, int64_t P, vo
         else
             hipLaunchKernelGGL((construct_kernel<false>), dim3(blocks_for(P)), dim3(kBuildBlock), 0, st, tr, points, P, pass);
     }
+    return check_launch(fn);
+}
+
+int svoxt_refine(const int64_t* leaf_node, int64_t n_leaves, int32_t N, int64_t filled, int64_t capacity,
+                 int32_t* child, int32_t* data, int32_t* parent_depth, const int32_t* node_id, void* stream) {
+    const char* fn = "svoxt_refine";
+    if (n_leaves < 0 || N < 2 || filled < 1 || filled + n_leaves > capacity)
+        return set_error(SVOXT_ERR_INVALID, "%s: bad extents (filled + n_leaves must fit the capacity)", fn);
+    if ((double)capacity * N * N * N >= 2147483648.0)
+        return set_error(SVOXT_ERR_INVALID, "%s: tree too large for 32-bit slot indices", fn);
+    if (n_leaves == 0) return SVOXT_OK;
+    if (leaf_node == nullptr || child == nullptr || data == nullptr || parent_depth == nullptr)
+        return set_error(SVOXT_ERR_INVALID, "%s: a pointer is NULL", fn);
+    hipLaunchKernelGGL(refine_kernel, dim3(blocks_for(n_leaves)), dim3(kBuildBlock), 0, (hipStream_t)stream,
+                       leaf_node, n_leaves, (int)N, filled, child, data, parent_depth, node_id);
     return check_launch(fn);
 }
 

@@ -237,12 +237,19 @@ class N3Tree(nn.Module):
                 if need > 0:
                     self._resize_add_cap(need)
                     resized = True
-                new_ids = torch.arange(filled, filled + n_new, device=self.data.device, dtype=torch.int32)
-                self.child[sel] = new_ids - leaf_node[:, 0].to(torch.int32)
-                self.data[filled:filled + n_new] = self.data[sel][:, None, None, None]
-                self.parent_depth[filled:filled + n_new, 0] = \
-                    self._pack_index(leaf_node).to(torch.int32) if node_id is None else node_id
-                self.parent_depth[filled:filled + n_new, 1] = self.parent_depth[leaf_node[:, 0].long(), 1] + 1
+                if self.data.is_cuda:
+                    # one kernel instead of a dozen tensor ops (same tables, bit for bit)
+                    nid = None if node_id is None else \
+                        torch.as_tensor(node_id, dtype=torch.int32, device=self.data.device).contiguous()
+                    _C.refine_leaves(self.child, self.data, self.parent_depth, filled,
+                                     leaf_node.long().contiguous(), nid)
+                else:
+                    new_ids = torch.arange(filled, filled + n_new, device=self.data.device, dtype=torch.int32)
+                    self.child[sel] = new_ids - leaf_node[:, 0].to(torch.int32)
+                    self.data[filled:filled + n_new] = self.data[sel][:, None, None, None]
+                    self.parent_depth[filled:filled + n_new, 0] = \
+                        self._pack_index(leaf_node).to(torch.int32) if node_id is None else node_id
+                    self.parent_depth[filled:filled + n_new, 1] = self.parent_depth[leaf_node[:, 0].long(), 1] + 1
                 self._n_internal += n_new
                 self.filled += n_new
                 self._invalidate()

@@ -69,16 +69,28 @@ def test_validation_codes_without_touching_the_gpu():
     assert b"NULL" in lib.svoxt_last_error()
     buf = (ctypes.c_float * 64)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    t = _C._CTree(features=p, M=1, K=13, N=2, data=p, child=p, n_internal=1, offset=p, scaling=p, xform=p)
-    # sample lists cannot be combined with per-leaf view rotations
+    t = _C._CTree(features=p, M=1, K=13, N=3, data=p, child=p, n_internal=1, offset=p, scaling=p, xform=p, xform_dim=3)
+    # sample lists combine with per-leaf view rotations only for SH payloads on N = 2 trees
     o = _C._COptions(format=1, basis_dim=4, min_comp=0, max_comp=3)
     r = _C._CRays(Q=0)
     l = _C._CLists(rec=p, aux=p, max_samples=4)
     assert lib.svoxt_volume_render_fwd_record(ctypes.byref(t), ctypes.byref(r), ctypes.byref(o), None,
                                               ctypes.byref(l), None) == 2       # SVOXT_ERR_UNSUPPORTED
     assert lib.svoxt_can_record(ctypes.byref(t), ctypes.byref(o)) == 0
-    t.xform = None
+    t.N = 2
     assert lib.svoxt_can_record(ctypes.byref(t), ctypes.byref(o)) == 1
+    assert lib.svoxt_volume_render_fwd_record(ctypes.byref(t), ctypes.byref(r), ctypes.byref(o), None,
+                                              ctypes.byref(l), None) == 0       # empty batch: accepted
+    t.xform_dim = 5
+    assert lib.svoxt_volume_render_fwd(ctypes.byref(t), ctypes.byref(r), ctypes.byref(o), None, None) == 1
+    assert b"xform_dim" in lib.svoxt_last_error()
+    t.xform, t.xform_dim = None, 0
+    assert lib.svoxt_can_record(ctypes.byref(t), ctypes.byref(o)) == 1
+    # the table-editing entry points validate before launching
+    assert lib.svoxt_refine(None, 3, 2, 1, 2, None, None, None, None, None) == 1
+    assert b"capacity" in lib.svoxt_last_error()
+    assert lib.svoxt_build_workspace_bytes(0) == -1 and lib.svoxt_build_workspace_bytes(8) > 0
+    assert lib.svoxt_motion_workspace_bytes(10, 33) == -1
     t.K = 4
     r = _C._CRays(Q=0)
     o = _C._COptions(format=1, basis_dim=7)

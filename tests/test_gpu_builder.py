@@ -184,3 +184,28 @@ def test_builder_argument_errors(gpu):
     with pytest.raises(RuntimeError):
         svox.N3Tree(N=2, data_dim=4).build_from_points(p.cpu(), 3)
     assert tree.build_from_points(torch.empty(0, 3, device=gpu), 4) == 1         # no points: the root alone
+
+
+@pytest.mark.parametrize("N", [2, 3])
+def test_refine_on_gpu_equals_refine_on_cpu(gpu, N):
+    """N3Tree.refine with tensors on the GPU runs svoxt_refine; on the CPU the tensor
+    ops of svox.py:535-546.  Same tables, selective and full, with and without node_id."""
+    g = torch.Generator().manual_seed(N)
+    a = svox.N3Tree(N=N, data_dim=4, init_reserve=4)
+    b = svox.N3Tree(N=N, data_dim=4, init_reserve=4, map_location=gpu)
+    for rnd in range(4 if N == 2 else 3):
+        leaves = a._all_leaves()
+        pick = torch.rand(len(leaves), generator=g) < (1.0 if rnd == 0 else 0.4)
+        sel = leaves[pick]
+        nid = torch.arange(len(sel), dtype=torch.int32) * 7 if rnd == 2 else None
+        # give the leaves distinct data words so that inheritance is visible
+        a.data.view(-1)[: a.n_internal * N ** 3] = torch.arange(a.n_internal * N ** 3, dtype=torch.int32)
+        b.data.view(-1)[: b.n_internal * N ** 3] = torch.arange(b.n_internal * N ** 3, dtype=torch.int32, device=gpu)
+        ra = a.refine(1, sel=tuple(sel.T), leaf_node=sel, node_id=nid)
+        rb = b.refine(1, sel=tuple(sel.to(gpu).T), leaf_node=sel.to(gpu), node_id=None if nid is None else nid.to(gpu))
+        assert ra == rb and a.n_internal == b.n_internal
+        n = a.n_internal
+        assert torch.equal(a.child[:n], b.child[:n].cpu())
+        assert torch.equal(a.data[:n], b.data[:n].cpu())
+        assert torch.equal(a.parent_depth[:n], b.parent_depth[:n].cpu())
+    assert torch.equal(a._all_leaves(), b._all_leaves())
