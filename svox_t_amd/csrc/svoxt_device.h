@@ -356,15 +356,25 @@ __device__ __forceinline__ void march_step(const TreeDev& tr, const Ray& r, floa
     // negative index is therefore "valid" for the reference (and reads out of
     // bounds).  Treat it as empty instead of faulting.
     s.valid = s.idx >= 0 && (int64_t)s.idx < tr.M;
-    float sub_tmin, sub_tmax;
-    dda_unit(s.leaf.lx, s.leaf.ly, s.leaf.lz, r.ix, r.iy, r.iz, sub_tmin, sub_tmax);
+    // _dda_unit on the leaf-local point (:273).  The point lies inside its leaf
+    // (local coordinates in [0, 1)), so on every axis one of t1 = -c*inv and
+    // t2 = t1 + inv is <= 0: the entry distance max(0, min...) is 0 and
+    // `subcube_tmax - subcube_tmin` (:275) is subcube_tmax itself -- only the exit
+    // distance is evaluated.
+    float sub_tmax = 1e9f;
+    {
+        float t1, t2;
+        t1 = -s.leaf.lx * r.ix; t2 = t1 + r.ix; sub_tmax = fminf(sub_tmax, fmaxf(t1, t2));
+        t1 = -s.leaf.ly * r.iy; t2 = t1 + r.iy; sub_tmax = fminf(sub_tmax, fmaxf(t1, t2));
+        t1 = -s.leaf.lz * r.iz; t2 = t1 + r.iz; sub_tmax = fminf(sub_tmax, fmaxf(t1, t2));
+    }
     float t_subcube;
     if constexpr (N2) {
         // cube_sz is a power of two: multiplying by its reciprocal is the
         // same correctly rounded result as the reference's division (:275).
-        t_subcube = (sub_tmax - sub_tmin) * __int_as_float((254 << 23) - __float_as_int(s.leaf.cube_sz));
+        t_subcube = sub_tmax * __int_as_float((254 << 23) - __float_as_int(s.leaf.cube_sz));
     } else {
-        t_subcube = (sub_tmax - sub_tmin) / s.leaf.cube_sz;
+        t_subcube = sub_tmax / s.leaf.cube_sz;
     }
     s.delta_t = t_subcube + step_size;
 }
