@@ -87,7 +87,8 @@ class _COptions(ctypes.Structure):       # struct svoxt_options
 
 
 class _CLists(ctypes.Structure):         # struct svoxt_sample_lists
-    _fields_ = [("rec", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("max_samples", ctypes.c_int32)]
+    _fields_ = [("rec", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("max_samples", ctypes.c_int32),
+                ("coef", ctypes.c_void_p)]
 
 
 _P = ctypes.POINTER
@@ -423,9 +424,12 @@ class SampleLists:
         self.rec = torch.empty((S, Q, 2), dtype=torch.int32, device=device)
         self.aux = torch.empty((Q, 4), dtype=torch.int32, device=device)
         self.S = S
+        self.coef = None        # allocated by the backward when it takes the two-kernel route,
+        self.consumed = False   # which rewrites `rec`: the lists then serve no second backward
 
     def c_struct(self):
-        return _CLists(self.rec.data_ptr(), self.aux.data_ptr(), self.S)
+        return _CLists(self.rec.data_ptr(), self.aux.data_ptr(), self.S,
+                       None if self.coef is None else self.coef.data_ptr())
 
 
 def can_record(tree: TreeSpec, opt: RenderOptions) -> bool:
@@ -463,6 +467,10 @@ def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bo
 # every contribution bit-identical to the reference formulas; ~0.2 ms slower on
 # the headline workload).
 BWD_EXACT = os.environ.get("SVOXT_BWD_EXACT", "0") not in ("", "0")
+# SVOXT_BWD_GATHER=0: keep the one-kernel backward (every sample's row goes to memory as
+# shaped atomics) instead of the two-kernel one (list walk -> factored records -> per-tile
+# merge in LDS -> one atomic row per tile and feature row), include/svoxt.h svoxt_sample_lists.coef
+BWD_GATHER = os.environ.get("SVOXT_BWD_GATHER", "1") not in ("", "0")
 
 
 def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
@@ -481,11 +489,20 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
     # Accumulate into rows that start on 64-byte boundaries (fewer memory-side
     # atomic requests per row), then hand back the dense [M, K] the caller expects.
     stride = K if (K <= 8 or K % 16 == 0) else (K + 15) // 16 * 16
+    if lists is not None and lists.consumed:
+        lists = None              # a second backward over the same forward: the lists were rewritten
+    gather = lists is not None and BWD_GATHER and K <= 32 and grad_output.shape[1] == 4 and \
+        ct.N == 2 and ct.xform is None
+    if gather:
+        stride = K                # ~5x fewer row updates: aligned rows no longer pay for the extra copy
     with torch.cuda.device(dev):
         buf = torch.empty((M, stride), dtype=torch.float32, device=dev)
         if lists is not None:
             if lists.aux.shape[0] != cr.Q or lists.aux.device != dev:
                 raise RuntimeError("sample lists do not belong to this ray batch")
+            if gather:
+                lists.coef = torch.empty((lists.S, cr.Q, 4), dtype=torch.float32, device=dev)
+                lists.consumed = True
             cl = lists.c_struct()
             fo = None
             if fwd_output is not None and not BWD_EXACT:

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/svoxt.h"
@@ -340,13 +341,58 @@ __device__ __forceinline__ void accum_sample(const float (&row)[K], const float*
     accum += weight * total_color;
 }
 
+// A sample's contribution in factored form, for the two-kernel backward: the colour
+// entry (c, i) is ((weight * basis_i) * coef_c) * g_c with coef_c = sigmoid'(.) for SH,
+// or coef_c itself for RGBA; `sg` is the sigma entry.  Same operations as stage_sample.
+template <int FMT, int C, int BD, int K>
+__device__ __forceinline__ void coef_sample(const float (&row)[K], const float* basis, const float* g,
+                                            float delta_t, float delta_scale, float light_ray,
+                                            float& light, float& accum, float& weight_out,
+                                            float (&coef)[C], float& sg) {
+    const float sigma = row[K - 1];
+    const float att = pexpf(-delta_t * sigma * delta_scale);
+    const float weight = light * (1.f - att);
+    float total_color = 0.f;
+    if constexpr (FMT == FMT_SH) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float tmp = 0.f;
+#pragma unroll
+            for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
+            const double sd = sigmoid_d(tmp);
+            const float sig = (float)sd;
+            coef[c] = (float)((double)sig * (1.0 - (double)sig));
+            total_color = (float)((double)total_color + sd * (double)g[c]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const double sd = sigmoid_d(row[j]);
+            const float sig = (float)sd;
+            coef[j] = weight * sig * (1.f - sig) * g[j];
+            total_color = (float)((double)total_color + sd * (double)g[j]);
+        }
+    }
+    light *= att;
+    accum -= weight * total_color;
+    sg = delta_t * delta_scale * (total_color * light - accum)
+       + delta_t * delta_scale * g[C] * light_ray;
+    weight_out = weight;
+}
+
 // REPLAY: rec / aux were filled by render_fwd_kernel<..., REC=true> for the
 // same tree, rays and options: pass 1 walks the list instead of the tree.
-template <int FMT, int C, int BD, bool N2, bool REPLAY, bool XF = false>
+// GATHER (C == 3, lists only): the listed samples are not sent to the gradient table
+// here; their factored contributions overwrite the list -- rec[k][q] = (row, sigma
+// entry), coef[k][q] = (weight, c0, c1, c2) -- and grad_merge_kernel adds them up per
+// 8x8 tile.  Samples past the list (overflowed rays) still go out as shaped atomics.
+template <int FMT, int C, int BD, bool N2, bool REPLAY, bool XF = false, bool GATHER = false>
 __global__ void __launch_bounds__(kBlock)
 render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                   float* __restrict__ grad, int gstride, uint2* __restrict__ rec, int S,
-                  const uint4* __restrict__ aux, const float* __restrict__ fwd_out) {
+                  const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
+                  float4* __restrict__ coef_out = nullptr) {
+    static_assert(!GATHER || (REPLAY && !XF && C == 3), "two-kernel backward: lists, 3 channels, no view rotations");
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     constexpr int KS = K | 1;                         // odd LDS row stride: conflict-free column writes
     __shared__ float stage_all[(kBlock / 64) * 64 * KS];
@@ -468,6 +514,25 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     float light = 1.f;
     int k = 0;
     float t = t_resume;
+    if constexpr (GATHER) {
+        // lane-independent: no wavefront-wide synchronisation while walking the list
+        if (alive) {
+            for (; k < nrec; ++k) {
+                uint2* slot = rec + ((int64_t)k * rays.Q + q);
+                const uint2 e = rec_get(slot);
+                float row[K];
+                load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
+                float w, cf[C], sg;
+                coef_sample<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, light_ray,
+                                           light, accum, w, cf, sg);
+                rec_put(slot, e.x, sg);
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(v4f{w, cf[0], cf[1], cf[2]},
+                                            reinterpret_cast<v4f*>(coef_out + ((int64_t)k * rays.Q + q)));
+            }
+        }
+        k = nrec;
+    }
     while (__any(k < nrec || t < tmax2)) {
         // which lanes have a sample this iteration, and which feature row it is
         bool active = false;
@@ -507,6 +572,196 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         }
         flush_staged<K, KS>(stage, sidx, __popcll(amask), lane, grad, gstride);
     }
+}
+
+// Second kernel of the two-kernel backward.  One wavefront per 64 rays (the same
+// ray <-> lane map as the march: an 8x8 tile).  Neighbouring rays hit the same leaves
+// (5.9x on the headline workload), so the tile's records are grouped by feature row
+// and a row leaves the CU once per tile instead of once per sample:
+//   load     lane = ray: the tile's records go to LDS; a hash table (atomicCAS on the
+//            key) maps each feature row to a slot, a counter per slot counts its records
+//   sort     exclusive scan of the counters, scatter of the record numbers (counting sort)
+//   reduce   64 sorted records at a time.  lane = record: expand it into its K gradient
+//            values -- from the factored form ((weight * basis_i) * coef_c) * g_c, the
+//            reference's own order of operations, with the rays' bases and upstream
+//            gradients in LDS -- and stage them; then lane = gradient column: each
+//            half-wavefront adds up 32 staged rows in order and, when the feature row
+//            changes, sends the sum out: one atomic instruction per row, K contiguous floats.
+// LDS float atomics are not used: ds_add_f32 retires about one lane per 4-5 clocks
+// (measured: 1.2 ms for this kernel written with a table of ds_add_f32 rows).  Also
+// measured: a row per lane summed in registers, 64 rows at a time (most lanes idle behind
+// the longest row, 0.55 ms); column lanes reading record fields straight from LDS
+// (a dependent read chain per record, 1.16 ms).
+template <int FMT, int BD, int T, int R>
+__global__ void __launch_bounds__(kBlock)
+grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, const uint2* __restrict__ rec,
+                  const float4* __restrict__ coef, const uint4* __restrict__ aux,
+                  float* __restrict__ grad, int gstride) {
+    constexpr int C = 3;
+    constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
+    constexpr int BDS = (FMT == FMT_SH) ? (BD | 1) : 1;      // odd stride: conflict-free basis rows
+    static_assert(K <= 32 && (T & (T - 1)) == 0 && T >= 128 && T <= 1024 && R >= 128 && R <= 4096, "sizes");
+    __shared__ int32_t keys[T];
+    __shared__ int32_t cnt[T];
+    __shared__ int32_t start[T];
+    __shared__ int32_t fill[T];
+    __shared__ uint16_t order[R];
+    __shared__ uint16_t r_sl[R];                 // slot << 6 | lane
+    __shared__ float r_sg[R], r_w[R], r_c[3 * R];
+    __shared__ float bases[64 * BDS];
+    __shared__ float gl[64 * 3];
+    constexpr int KS = K | 1;
+    __shared__ float stage[64 * KS];
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+    const bool alive = q < rays.Q;
+    int nrec = 0;
+    if (alive) nrec = (int)(aux[q].x & ~kRecOverflow);
+    int maxn = nrec;
+    for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
+    if (maxn == 0) return;
+    if (alive && nrec > 0) {
+        if constexpr (FMT == FMT_SH) {
+            float vd[3], b[BD];
+            load_vdir(rays, q, vd);
+            precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], b);
+#pragma unroll
+            for (int i = 0; i < BD; ++i) bases[lane * BDS + i] = b[i];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) gl[lane * 3 + c] = grad_out[q * (C + 1) + c];
+    }
+    for (int i = lane; i < T; i += 64) { keys[i] = -1; cnt[i] = 0; fill[i] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int nb = 0;        // records in the LDS buffer
+    int used = 0;      // occupied slots
+    const int half = lane >> 5, col = lane & 31;      // reduce phase: lane = gradient column
+
+    auto process = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // exclusive scan of cnt[0..T) -> start[]: T / 64 consecutive slots per lane
+        constexpr int PER = T / 64;
+        int mine[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { mine[j] = cnt[lane * PER + j]; sum += mine[j]; }
+        int incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        int run = incl - sum;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { start[lane * PER + j] = run; run += mine[j]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // counting sort: record numbers grouped by slot
+        for (int rr = lane; rr < nb; rr += 64) {
+            const int sl = (int)r_sl[rr] >> 6;
+            const int pos = start[sl] + atomicAdd(fill + sl, 1);
+            order[pos] = (uint16_t)rr;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 64 sorted records at a time: lane = record expands it into its K gradient values
+        // (staged in LDS); then lane = column: each half-wavefront adds up 32 staged rows in
+        // order and sends a sum out whenever the feature row changes.
+        for (int base = 0; base < nb; base += 64) {
+            const int p = base + lane;
+            int my_sl = -1;
+            if (p < nb) {
+                const int rr = (int)order[p];
+                const int v = (int)r_sl[rr];
+                my_sl = v >> 6;
+                const int rl = v & 63;
+                float* st = stage + lane * KS;
+                if constexpr (FMT == FMT_SH) {
+                    const float w = r_w[rr];
+                    const float* b = bases + rl * BDS;
+#pragma unroll
+                    for (int c3 = 0; c3 < C; ++c3) {
+                        const float cc = r_c[c3 * R + rr], gc = gl[rl * 3 + c3];
+#pragma unroll
+                        for (int i = 0; i < BD; ++i) st[c3 * BD + i] = w * b[i] * cc * gc;
+                    }
+                } else {
+                    st[0] = r_c[rr]; st[1] = r_c[R + rr]; st[2] = r_c[2 * R + rr];
+                }
+                st[K - 1] = r_sg[rr];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int cur = -1;
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 32; ++t) {
+                // slot of staged row t of this half-wavefront, from the registers of the lanes that staged it
+                const int s_lo = __builtin_amdgcn_readlane(my_sl, t), s_hi = __builtin_amdgcn_readlane(my_sl, 32 + t);
+                const int sl = half == 0 ? s_lo : s_hi;
+                const float x = col < K ? stage[(half * 32 + t) * KS + col] : 0.f;
+                if (sl != cur) {
+                    if (cur >= 0 && col < K) atomicAdd(grad + (int64_t)keys[cur] * gstride + col, acc);
+                    acc = 0.f;
+                    cur = sl;
+                }
+                acc += x;
+            }
+            if (cur >= 0 && col < K) atomicAdd(grad + (int64_t)keys[cur] * gstride + col, acc);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int i = lane; i < T; i += 64) { keys[i] = -1; cnt[i] = 0; fill[i] = 0; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        nb = 0;
+        used = 0;
+    };
+
+    // The records were written with streaming stores and come from memory: request
+    // kUnroll list positions at once so their latencies overlap.
+    constexpr int kUnroll = 8;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    for (int k0 = 0; k0 < maxn; k0 += kUnroll) {
+        uint2 e[kUnroll];
+        v4f c4[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            e[u] = make_uint2(0u, 0u);
+            c4[u] = v4f{0.f, 0.f, 0.f, 0.f};
+            if (k0 + u < nrec) {
+                e[u] = rec_get(rec + ((int64_t)(k0 + u) * rays.Q + q));
+                c4[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(k0 + u) * rays.Q + q)));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            if (k0 + u >= maxn) break;
+            if (nb + 64 > R || used + 64 > T - T / 4) process();
+            const bool active = k0 + u < nrec;
+            const unsigned long long am = __ballot(active);
+            bool fresh = false;
+            if (active) {
+                const int32_t idx = (int32_t)e[u].x;
+                uint32_t h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
+                while (true) {
+                    const int32_t old = atomicCAS(keys + h, -1, idx);
+                    if (old == -1) { fresh = true; break; }
+                    if (old == idx) break;
+                    h = (h + 1u) & (uint32_t)(T - 1);
+                }
+                atomicAdd(cnt + h, 1);
+                const int pos = nb + __popcll(am & lane_lt);
+                r_sl[pos] = (uint16_t)((h << 6) | (uint32_t)lane);
+                r_sg[pos] = __uint_as_float(e[u].y);
+                r_w[pos] = c4[u].x; r_c[pos] = c4[u].y; r_c[R + pos] = c4[u].z; r_c[2 * R + pos] = c4[u].w;
+            }
+            nb += __popcll(am);
+            used += __popcll(__ballot(fresh));
+        }
+    }
+    process();
 }
 
 // Generic backward: any K / format / component range / channel count
@@ -1218,6 +1473,30 @@ bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
     return false;
 }
 
+// two-kernel backward: SH 1/4/9 and RGBA with 3 channels (K <= 32) on N = 2 trees
+bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
+                       const float* grad_out, float* grad, int gstride, uint2* rec, int S, const uint4* aux,
+                       const float* fwd_out, float4* coef, hipStream_t st) {
+    if (C != 3) return false;
+    const unsigned nb = nblocks(rays.Q);
+#define SVOXT_GATHER(F, BB)                                                                                   \
+    hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
+                       tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out, coef);                   \
+    hipLaunchKernelGGL((grad_merge_kernel<F, BB, 256, 512>), dim3(nb), dim3(kBlock), 0, st, tr, rays,       \
+                       grad_out, rec, coef, aux, grad, gstride);                                              \
+    return true;
+    if (opt.format == FMT_RGBA) { SVOXT_GATHER(FMT_RGBA, 0) }
+    if (opt.format == FMT_SH) {
+        switch (opt.basis_dim) {
+            case 1: SVOXT_GATHER(FMT_SH, 1)
+            case 4: SVOXT_GATHER(FMT_SH, 4)
+            case 9: SVOXT_GATHER(FMT_SH, 9)
+        }
+    }
+#undef SVOXT_GATHER
+    return false;
+}
+
 template <bool N2, bool REPLAY>
 bool launch_bwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
                         const float* grad_out, float* grad, int gstride, uint2* rec, int S, const uint4* aux,
@@ -1293,7 +1572,10 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
         if (lists != nullptr) {
             uint2* lrec = reinterpret_cast<uint2*>(lists->rec);
             const uint4* laux = reinterpret_cast<const uint4*>(lists->aux);
-            done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux, fwd_out, st)
+            if (n2 && lists->coef != nullptr && tree->K <= 32)
+                done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux,
+                                         fwd_out, reinterpret_cast<float4*>(lists->coef), st);
+            if (!done) done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux, fwd_out, st)
                       : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux, fwd_out, st);
             if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no specialised kernel for this payload", fn);
         } else {

@@ -98,14 +98,16 @@ def test_counters_match_oracle(case, gpu):
 
 
 @pytest.mark.parametrize("list_samples", [0, 1, 3, 64])
-@pytest.mark.parametrize("from_forward", [True, False, "exact"])
+@pytest.mark.parametrize("from_forward", [True, False, "exact", "one_kernel"])
 def test_backward_sample_list_capacity_does_not_change_results(gpu, list_samples, from_forward, monkeypatch):
     """The backward records up to S samples per ray in pass 1 and replays them in
     pass 2; rays with more samples march the rest.  Any S gives the same
-    gradient (S = 0: march twice like the reference)."""
+    gradient (S = 0: march twice like the reference) -- through the two-kernel
+    backward (default with forward lists) and the one-kernel one alike."""
     import svox_t_amd.csrc as _C
     from svox_t_amd import synth
     monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", list_samples)
+    monkeypatch.setattr(_C, "BWD_GATHER", from_forward != "one_kernel")
     # "exact": lists from the forward, but two list walks instead of using the
     # forward's output for accum (SVOXT_BWD_EXACT=1)
     monkeypatch.setattr(_C, "BWD_EXACT", from_forward == "exact")
@@ -123,6 +125,37 @@ def test_backward_sample_list_capacity_does_not_change_results(gpu, list_samples
         tree.features.grad = _C.volume_render_backward(tree._spec(tree.features), _rays_spec_from_rays(c.rays_gpu(gpu)),
                                                        r._get_options(), g.to(gpu))
     want, abs_sum = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.numpy(), want_abs=True)
+    assert_grads_close(tree.features.grad.cpu().numpy(), want, abs_sum)
+
+
+@pytest.mark.parametrize("name", ["d5_sh9", "d5_rgba4", "d5_sh4_world", "d5_sh1"])
+def test_two_kernel_backward_and_repeated_backward(gpu, name, monkeypatch):
+    """The two-kernel backward rewrites the forward's lists: a second backward over the
+    same graph must still be right (it falls back to marching), and both kernels' routes
+    agree with the one-kernel backward to the float-accumulation tolerance."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd import synth
+    c = Case(**CASES[name])
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    g = synth.grad_output(c.Q, 4)
+    want, abs_sum = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.numpy(), want_abs=True)
+    out = r(tree.features, c.rays_gpu(gpu))
+    out.backward(g.to(gpu), retain_graph=True)
+    first = tree.features.grad.clone()
+    assert_grads_close(first.cpu().numpy(), want, abs_sum)
+    tree.features.grad = None
+    out.backward(g.to(gpu))                                   # lists consumed: re-march
+    assert_grads_close(tree.features.grad.cpu().numpy(), want, abs_sum)
+    # image tiles: the merge works per 8x8 tile when the batch is declared an image
+    tree.features.grad = None
+    side = int(round(c.Q ** 0.5))
+    out = r(tree.features, c.rays_gpu(gpu), image_shape=(side, side))
+    out.backward(g.to(gpu))
+    assert_grads_close(tree.features.grad.cpu().numpy(), want, abs_sum)
+    monkeypatch.setattr(_C, "BWD_GATHER", False)
+    tree.features.grad = None
+    r(tree.features, c.rays_gpu(gpu)).backward(g.to(gpu))
     assert_grads_close(tree.features.grad.cpu().numpy(), want, abs_sum)
 
 
