@@ -8,12 +8,14 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        short = "bwd" if "render_bwd" in k else "fwd" if "render_fwd" in k else None
+        short = "bwd" if "render_bwd" in k else "fwd" if "render_fwd" in k else "merge" if "grad_merge" in k else None
         if short is None:
             continue
         acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
-for k in ("fwd", "bwd"):
+for k in ("fwd", "bwd", "merge"):
+    if k not in acc:
+        continue
     print(f"== {k}")
     out[k] = {}
     for c, v in sorted(acc[k].items()):
@@ -22,5 +24,6 @@ for k in ("fwd", "bwd"):
 if len(sys.argv) > 2:
     import json
     json.dump({"tag": tag, "units": "mean counter value per dispatch; FETCH_SIZE / WRITE_SIZE in KiB",
-               "kernels": {"fwd": "render_fwd_kernel<SH,3,9,N2,REC>", "bwd": "render_bwd_kernel<SH,3,9,N2,REPLAY>"},
+               "kernels": {"fwd": "render_fwd_kernel<SH,3,9,N2,REC>", "bwd": "render_bwd_kernel<SH,3,9,N2,REPLAY[,GATHER]>",
+                           "merge": "grad_merge_kernel<SH,9> (second kernel of the two-kernel backward)"},
                "counters": out}, open(sys.argv[2], "w"), indent=1)
