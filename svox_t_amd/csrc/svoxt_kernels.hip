@@ -600,7 +600,7 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
     constexpr int C = 3;
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     constexpr int BDS = (FMT == FMT_SH) ? (BD | 1) : 1;      // odd stride: conflict-free basis rows
-    static_assert(K <= 32 && (T & (T - 1)) == 0 && T >= 128 && T <= 1024 && R >= 128 && R <= 4096, "sizes");
+    static_assert(K <= 32 && (T & (T - 1)) == 0 && T >= 128 && T <= 1024 && R >= 128 && R <= 4096 && T * 64 <= 65536, "sizes");
     __shared__ int32_t keys[T];
     __shared__ int32_t cnt[T];
     __shared__ int32_t start[T];
@@ -612,6 +612,7 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
     __shared__ float gl[64 * 3];
     constexpr int KS = K | 1;
     __shared__ float stage[64 * KS];
+    __shared__ int32_t seg[64];
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
@@ -637,7 +638,6 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
     __builtin_amdgcn_wave_barrier();
     int nb = 0;        // records in the LDS buffer
     int used = 0;      // occupied slots
-    const int half = lane >> 5, col = lane & 31;      // reduce phase: lane = gradient column
 
     auto process = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -691,24 +691,44 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
                 }
                 st[K - 1] = r_sg[rr];
             }
+            seg[lane] = my_sl >= 0 ? keys[my_sl] : -1;          // the feature row staged row `lane` belongs to
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            // four groups of 16 lanes, each walking 16 staged rows; a lane owns two columns
+            // (sub and sub + HALF), so a row leaves as two atomic instructions of HALF floats
+            constexpr int HALF = (K + 1) / 2;
+            const int grp = lane >> 4, sub = lane & 15;
+            const bool has0 = sub < HALF, has1 = sub + HALF < K;
             int cur = -1;
-            float acc = 0.f;
+            float acc0 = 0.f, acc1 = 0.f;
+            // all LDS reads of the 16 steps first (independent), then the sequential logic
+            int keyv[16];
+            float x0v[16], x1v[16];
 #pragma unroll
-            for (int t = 0; t < 32; ++t) {
-                // slot of staged row t of this half-wavefront, from the registers of the lanes that staged it
-                const int s_lo = __builtin_amdgcn_readlane(my_sl, t), s_hi = __builtin_amdgcn_readlane(my_sl, 32 + t);
-                const int sl = half == 0 ? s_lo : s_hi;
-                const float x = col < K ? stage[(half * 32 + t) * KS + col] : 0.f;
-                if (sl != cur) {
-                    if (cur >= 0 && col < K) atomicAdd(grad + (int64_t)keys[cur] * gstride + col, acc);
-                    acc = 0.f;
-                    cur = sl;
-                }
-                acc += x;
+            for (int t = 0; t < 16; ++t) {
+                const int row = grp * 16 + t;
+                keyv[t] = seg[row];
+                x0v[t] = stage[row * KS + (has0 ? sub : 0)];
+                x1v[t] = stage[row * KS + (has1 ? sub + HALF : 0)];
             }
-            if (cur >= 0 && col < K) atomicAdd(grad + (int64_t)keys[cur] * gstride + col, acc);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int key = keyv[t];
+                if (key != cur) {
+                    if (cur >= 0) {
+                        if (has0) atomicAdd(grad + (int64_t)cur * gstride + sub, acc0);
+                        if (has1) atomicAdd(grad + (int64_t)cur * gstride + sub + HALF, acc1);
+                    }
+                    acc0 = 0.f; acc1 = 0.f;
+                    cur = key;
+                }
+                acc0 += x0v[t];
+                acc1 += x1v[t];
+            }
+            if (cur >= 0) {
+                if (has0) atomicAdd(grad + (int64_t)cur * gstride + sub, acc0);
+                if (has1) atomicAdd(grad + (int64_t)cur * gstride + sub + HALF, acc1);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -719,49 +739,54 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
         used = 0;
     };
 
-    // The records were written with streaming stores and come from memory: request
-    // kUnroll list positions at once so their latencies overlap.
-    constexpr int kUnroll = 8;
+    // The records were written with streaming stores and come from memory: kGroup list
+    // positions are requested at once so that their latencies overlap.  process() has
+    // one call site (it is large; inlined copies would not fit the instruction cache).
+    constexpr int kGroup = (T >= 512 && R >= 512) ? 4 : 2;
+    static_assert(R >= 64 * kGroup && T > 64 * kGroup, "a group of list positions must fit the buffer and the table");
     typedef float v4f __attribute__((ext_vector_type(4)));
-    for (int k0 = 0; k0 < maxn; k0 += kUnroll) {
-        uint2 e[kUnroll];
-        v4f c4[kUnroll];
+    int k0 = 0;
+    while (true) {
+        while (k0 < maxn && nb + 64 * kGroup <= R && used + 64 * kGroup < T) {
+            uint2 e[kGroup];
+            v4f c4[kGroup];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            e[u] = make_uint2(0u, 0u);
-            c4[u] = v4f{0.f, 0.f, 0.f, 0.f};
-            if (k0 + u < nrec) {
-                e[u] = rec_get(rec + ((int64_t)(k0 + u) * rays.Q + q));
-                c4[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(k0 + u) * rays.Q + q)));
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            if (k0 + u >= maxn) break;
-            if (nb + 64 > R || used + 64 > T - T / 4) process();
-            const bool active = k0 + u < nrec;
-            const unsigned long long am = __ballot(active);
-            bool fresh = false;
-            if (active) {
-                const int32_t idx = (int32_t)e[u].x;
-                uint32_t h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
-                while (true) {
-                    const int32_t old = atomicCAS(keys + h, -1, idx);
-                    if (old == -1) { fresh = true; break; }
-                    if (old == idx) break;
-                    h = (h + 1u) & (uint32_t)(T - 1);
+            for (int u = 0; u < kGroup; ++u) {
+                e[u] = make_uint2(0u, 0u);
+                c4[u] = v4f{0.f, 0.f, 0.f, 0.f};
+                if (k0 + u < nrec) {
+                    e[u] = rec_get(rec + ((int64_t)(k0 + u) * rays.Q + q));
+                    c4[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(k0 + u) * rays.Q + q)));
                 }
-                atomicAdd(cnt + h, 1);
-                const int pos = nb + __popcll(am & lane_lt);
-                r_sl[pos] = (uint16_t)((h << 6) | (uint32_t)lane);
-                r_sg[pos] = __uint_as_float(e[u].y);
-                r_w[pos] = c4[u].x; r_c[pos] = c4[u].y; r_c[R + pos] = c4[u].z; r_c[2 * R + pos] = c4[u].w;
             }
-            nb += __popcll(am);
-            used += __popcll(__ballot(fresh));
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u) {
+                const bool active = k0 + u < nrec;
+                const unsigned long long am = __ballot(active);
+                bool fresh = false;
+                if (active) {
+                    const int32_t idx = (int32_t)e[u].x;
+                    uint32_t h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
+                    while (true) {
+                        const int32_t old = atomicCAS(keys + h, -1, idx);
+                        if (old == -1) { fresh = true; break; }
+                        if (old == idx) break;
+                        h = (h + 1u) & (uint32_t)(T - 1);
+                    }
+                    atomicAdd(cnt + h, 1);
+                    const int pos = nb + __popcll(am & lane_lt);
+                    r_sl[pos] = (uint16_t)((h << 6) | (uint32_t)lane);
+                    r_sg[pos] = __uint_as_float(e[u].y);
+                    r_w[pos] = c4[u].x; r_c[pos] = c4[u].y; r_c[R + pos] = c4[u].z; r_c[2 * R + pos] = c4[u].w;
+                }
+                nb += __popcll(am);
+                used += __popcll(__ballot(fresh));
+            }
+            k0 += kGroup;
         }
+        process();
+        if (k0 >= maxn) break;
     }
-    process();
 }
 
 // Generic backward: any K / format / component range / channel count
@@ -1482,7 +1507,7 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
 #define SVOXT_GATHER(F, BB)                                                                                   \
     hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
                        tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out, coef);                   \
-    hipLaunchKernelGGL((grad_merge_kernel<F, BB, 256, 512>), dim3(nb), dim3(kBlock), 0, st, tr, rays,       \
+    hipLaunchKernelGGL((grad_merge_kernel<F, BB, 512, 512>), dim3(nb), dim3(kBlock), 0, st, tr, rays,       \
                        grad_out, rec, coef, aux, grad, gstride);                                              \
     return true;
     if (opt.format == FMT_RGBA) { SVOXT_GATHER(FMT_RGBA, 0) }
