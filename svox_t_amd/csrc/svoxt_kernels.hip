@@ -592,14 +592,21 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 // measured: a row per lane summed in registers, 64 rows at a time (most lanes idle behind
 // the longest row, 0.55 ms); column lanes reading record fields straight from LDS
 // (a dependent read chain per record, 1.16 ms).
-template <int FMT, int BD, int T, int R>
-__global__ void __launch_bounds__(kBlock)
+template <int FMT, int BD, int T, int R, int W>
+__global__ void __launch_bounds__(64 * W)
 grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, const uint2* __restrict__ rec,
                   const float4* __restrict__ coef, const uint4* __restrict__ aux,
                   float* __restrict__ grad, int gstride) {
+    // W wavefronts share one tile (64 rays) and its LDS: the phases below are latency
+    // chains of LDS operations, and LDS -- not registers -- limits how many tiles a CU
+    // holds, so the way to more wavefronts per CU is more wavefronts per tile.  Lane l of
+    // every wavefront stands for ray l of the tile; list positions (load) and batches of
+    // 64 sorted records (reduce) are dealt round-robin to the wavefronts.
     constexpr int C = 3;
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     constexpr int BDS = (FMT == FMT_SH) ? (BD | 1) : 1;      // odd stride: conflict-free basis rows
+    constexpr int KS = K | 1;
+    constexpr int NT = 64 * W;
     static_assert(K <= 32 && (T & (T - 1)) == 0 && T >= 128 && T <= 1024 && R >= 128 && R <= 4096 && T * 64 <= 65536, "sizes");
     __shared__ int32_t keys[T];
     __shared__ int32_t cnt[T];
@@ -610,19 +617,21 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
     __shared__ float r_sg[R], r_w[R], r_c[3 * R];
     __shared__ float bases[64 * BDS];
     __shared__ float gl[64 * 3];
-    constexpr int KS = K | 1;
-    __shared__ float stage[64 * KS];
-    __shared__ int32_t seg[64];
-    const int lane = threadIdx.x & 63;
+    __shared__ float stage_all[W * 64 * KS];
+    __shared__ int32_t seg_all[W * 64];
+    __shared__ int32_t s_nb, s_used;             // records in the buffer, occupied slots
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* stage = stage_all + wave * 64 * KS;
+    int32_t* seg = seg_all + wave * 64;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * 64 + lane);
     const bool alive = q < rays.Q;
     int nrec = 0;
     if (alive) nrec = (int)(aux[q].x & ~kRecOverflow);
     int maxn = nrec;
     for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
-    if (maxn == 0) return;
-    if (alive && nrec > 0) {
+    if (maxn == 0) return;                       // the same in every wavefront of the workgroup
+    if (wave == 0 && alive && nrec > 0) {
         if constexpr (FMT == FMT_SH) {
             float vd[3], b[BD];
             load_vdir(rays, q, vd);
@@ -633,42 +642,96 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
 #pragma unroll
         for (int c = 0; c < C; ++c) gl[lane * 3 + c] = grad_out[q * (C + 1) + c];
     }
-    for (int i = lane; i < T; i += 64) { keys[i] = -1; cnt[i] = 0; fill[i] = 0; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    int nb = 0;        // records in the LDS buffer
-    int used = 0;      // occupied slots
+    for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; fill[i] = 0; }
+    if (threadIdx.x == 0) { s_nb = 0; s_used = 0; }
+    __syncthreads();
 
-    auto process = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // exclusive scan of cnt[0..T) -> start[]: T / 64 consecutive slots per lane
-        constexpr int PER = T / 64;
-        int mine[PER], sum = 0;
+    // list positions are taken kGroup at a time per wavefront (their loads overlap)
+    constexpr int kGroup = W >= 8 ? 1 : 2;
+    static_assert(R >= 64 * kGroup * W && T > 64 * kGroup * W, "a round of list positions must fit the buffer and the table");
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    int k0 = 0;                                  // next list position of the workgroup (uniform)
+    while (true) {
+        // ---- load: fill the record buffer and the hash table
+        while (true) {
+            __syncthreads();
+            const int nb = s_nb, used = s_used;
+            __syncthreads();                     // everyone has read the counters before anyone moves them
+            if (!(k0 < maxn && nb + 64 * kGroup * W <= R && used + 64 * kGroup * W < T)) break;
+            const int kb = k0 + wave * kGroup;   // this wavefront's positions of the round
+            uint2 e[kGroup];
+            v4f c4[kGroup];
 #pragma unroll
-        for (int j = 0; j < PER; ++j) { mine[j] = cnt[lane * PER + j]; sum += mine[j]; }
-        int incl = sum;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
+            for (int u = 0; u < kGroup; ++u) {
+                e[u] = make_uint2(0u, 0u);
+                c4[u] = v4f{0.f, 0.f, 0.f, 0.f};
+                if (kb + u < nrec) {
+                    e[u] = rec_get(rec + ((int64_t)(kb + u) * rays.Q + q));
+                    c4[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(kb + u) * rays.Q + q)));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u) {
+                const bool active = kb + u < nrec;
+                const unsigned long long am = __ballot(active);
+                if (am == 0ull) continue;
+                bool fresh = false;
+                uint32_t h = 0;
+                if (active) {
+                    const int32_t idx = (int32_t)e[u].x;
+                    h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
+                    while (true) {
+                        const int32_t old = atomicCAS(keys + h, -1, idx);
+                        if (old == -1) { fresh = true; break; }
+                        if (old == idx) break;
+                        h = (h + 1u) & (uint32_t)(T - 1);
+                    }
+                    atomicAdd(cnt + h, 1);
+                }
+                const unsigned long long fm = __ballot(fresh);
+                int base = 0;
+                if (lane == 0) {
+                    base = atomicAdd(&s_nb, __popcll(am));
+                    if (fm != 0ull) atomicAdd(&s_used, __popcll(fm));
+                }
+                base = __shfl(base, 0, 64);
+                if (active) {
+                    const int pos = base + __popcll(am & lane_lt);
+                    r_sl[pos] = (uint16_t)((h << 6) | (uint32_t)lane);
+                    r_sg[pos] = __uint_as_float(e[u].y);
+                    r_w[pos] = c4[u].x; r_c[pos] = c4[u].y; r_c[R + pos] = c4[u].z; r_c[2 * R + pos] = c4[u].w;
+                }
+            }
+            k0 += kGroup * W;
         }
-        int run = incl - sum;
+        // ---- sort: exclusive scan of the counters (wavefront 0), counting sort of the record numbers
+        const int nb = s_nb;
+        if (wave == 0) {
+            constexpr int PER = T / 64;
+            int mine[PER], sum = 0;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) { start[lane * PER + j] = run; run += mine[j]; }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // counting sort: record numbers grouped by slot
-        for (int rr = lane; rr < nb; rr += 64) {
+            for (int j2 = 0; j2 < PER; ++j2) { mine[j2] = cnt[lane * PER + j2]; sum += mine[j2]; }
+            int incl = sum;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += v;
+            }
+            int run = incl - sum;
+#pragma unroll
+            for (int j2 = 0; j2 < PER; ++j2) { start[lane * PER + j2] = run; run += mine[j2]; }
+        }
+        __syncthreads();
+        for (int rr = threadIdx.x; rr < nb; rr += NT) {
             const int sl = (int)r_sl[rr] >> 6;
             const int pos = start[sl] + atomicAdd(fill + sl, 1);
             order[pos] = (uint16_t)rr;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // 64 sorted records at a time: lane = record expands it into its K gradient values
-        // (staged in LDS); then lane = column: each half-wavefront adds up 32 staged rows in
-        // order and sends a sum out whenever the feature row changes.
-        for (int base = 0; base < nb; base += 64) {
+        __syncthreads();
+        // ---- reduce: 64 sorted records at a time per wavefront.  lane = record expands it into
+        // its K gradient values (staged in LDS); then four groups of 16 lanes each walk 16 staged
+        // rows, a lane owning two columns (sub and sub + HALF), and send a sum out whenever the
+        // feature row changes: a row leaves as two atomic instructions of HALF floats.
+        for (int base = wave * 64; base < nb; base += NT) {
             const int p = base + lane;
             int my_sl = -1;
             if (p < nb) {
@@ -694,8 +757,6 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
             seg[lane] = my_sl >= 0 ? keys[my_sl] : -1;          // the feature row staged row `lane` belongs to
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // four groups of 16 lanes, each walking 16 staged rows; a lane owns two columns
-            // (sub and sub + HALF), so a row leaves as two atomic instructions of HALF floats
             constexpr int HALF = (K + 1) / 2;
             const int grp = lane >> 4, sub = lane & 15;
             const bool has0 = sub < HALF, has1 = sub + HALF < K;
@@ -732,60 +793,10 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        for (int i = lane; i < T; i += 64) { keys[i] = -1; cnt[i] = 0; fill[i] = 0; }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        nb = 0;
-        used = 0;
-    };
-
-    // The records were written with streaming stores and come from memory: kGroup list
-    // positions are requested at once so that their latencies overlap.  process() has
-    // one call site (it is large; inlined copies would not fit the instruction cache).
-    constexpr int kGroup = (T >= 512 && R >= 512) ? 4 : 2;
-    static_assert(R >= 64 * kGroup && T > 64 * kGroup, "a group of list positions must fit the buffer and the table");
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    int k0 = 0;
-    while (true) {
-        while (k0 < maxn && nb + 64 * kGroup <= R && used + 64 * kGroup < T) {
-            uint2 e[kGroup];
-            v4f c4[kGroup];
-#pragma unroll
-            for (int u = 0; u < kGroup; ++u) {
-                e[u] = make_uint2(0u, 0u);
-                c4[u] = v4f{0.f, 0.f, 0.f, 0.f};
-                if (k0 + u < nrec) {
-                    e[u] = rec_get(rec + ((int64_t)(k0 + u) * rays.Q + q));
-                    c4[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(k0 + u) * rays.Q + q)));
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < kGroup; ++u) {
-                const bool active = k0 + u < nrec;
-                const unsigned long long am = __ballot(active);
-                bool fresh = false;
-                if (active) {
-                    const int32_t idx = (int32_t)e[u].x;
-                    uint32_t h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
-                    while (true) {
-                        const int32_t old = atomicCAS(keys + h, -1, idx);
-                        if (old == -1) { fresh = true; break; }
-                        if (old == idx) break;
-                        h = (h + 1u) & (uint32_t)(T - 1);
-                    }
-                    atomicAdd(cnt + h, 1);
-                    const int pos = nb + __popcll(am & lane_lt);
-                    r_sl[pos] = (uint16_t)((h << 6) | (uint32_t)lane);
-                    r_sg[pos] = __uint_as_float(e[u].y);
-                    r_w[pos] = c4[u].x; r_c[pos] = c4[u].y; r_c[R + pos] = c4[u].z; r_c[2 * R + pos] = c4[u].w;
-                }
-                nb += __popcll(am);
-                used += __popcll(__ballot(fresh));
-            }
-            k0 += kGroup;
-        }
-        process();
         if (k0 >= maxn) break;
+        __syncthreads();
+        for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; fill[i] = 0; }
+        if (threadIdx.x == 0) { s_nb = 0; s_used = 0; }
     }
 }
 
@@ -1504,11 +1515,19 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
                        const float* fwd_out, float4* coef, hipStream_t st) {
     if (C != 3) return false;
     const unsigned nb = nblocks(rays.Q);
+    static const int mw = [] { const char* e = getenv("SVOXT_MERGE_WAVES"); return e ? atoi(e) : 4; }();
 #define SVOXT_GATHER(F, BB)                                                                                   \
     hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
                        tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out, coef);                   \
-    hipLaunchKernelGGL((grad_merge_kernel<F, BB, 512, 512>), dim3(nb), dim3(kBlock), 0, st, tr, rays,       \
-                       grad_out, rec, coef, aux, grad, gstride);                                              \
+    if (mw == 4)                                                                                              \
+        hipLaunchKernelGGL((grad_merge_kernel<F, BB, 1024, 1024, 4>), dim3(nb), dim3(256), 0, st, tr, rays,  \
+                           grad_out, rec, coef, aux, grad, gstride);                                          \
+    else if (mw == 2)                                                                                         \
+        hipLaunchKernelGGL((grad_merge_kernel<F, BB, 512, 512, 2>), dim3(nb), dim3(128), 0, st, tr, rays,    \
+                           grad_out, rec, coef, aux, grad, gstride);                                          \
+    else                                                                                                      \
+        hipLaunchKernelGGL((grad_merge_kernel<F, BB, 512, 512, 1>), dim3(nb), dim3(64), 0, st, tr, rays,     \
+                           grad_out, rec, coef, aux, grad, gstride);                                          \
     return true;
     if (opt.format == FMT_RGBA) { SVOXT_GATHER(FMT_RGBA, 0) }
     if (opt.format == FMT_SH) {
