@@ -607,7 +607,7 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
     constexpr int BDS = (FMT == FMT_SH) ? (BD | 1) : 1;      // odd stride: conflict-free basis rows
     constexpr int KS = K | 1;
     constexpr int NT = 64 * W;
-    static_assert(K <= 32 && (T & (T - 1)) == 0 && T >= 128 && T <= 1024 && R >= 128 && R <= 4096 && T * 64 <= 65536, "sizes");
+    static_assert(K <= 32 && (T & (T - 1)) == 0 && T >= 128 && T <= 1024 && R >= 128 && R <= 1024 && T * 64 <= 65536, "sizes");
     __shared__ int32_t keys[T];
     __shared__ int32_t cnt[T];
     __shared__ int32_t start[T];
@@ -619,7 +619,7 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
     __shared__ float gl[64 * 3];
     __shared__ float stage_all[W * 64 * KS];
     __shared__ int32_t seg_all[W * 64];
-    __shared__ int32_t s_nb, s_used;             // records in the buffer, occupied slots
+    __shared__ int32_t s_nb;                     // records in the buffer
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* stage = stage_all + wave * 64 * KS;
     int32_t* seg = seg_all + wave * 64;
@@ -630,6 +630,9 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
     if (alive) nrec = (int)(aux[q].x & ~kRecOverflow);
     int maxn = nrec;
     for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
+    // wavefront-uniform by construction; said so to the compiler, because everything that
+    // decides how many workgroup barriers a wavefront executes must be scalar control flow
+    maxn = __builtin_amdgcn_readfirstlane(maxn);
     if (maxn == 0) return;                       // the same in every wavefront of the workgroup
     if (wave == 0 && alive && nrec > 0) {
         if constexpr (FMT == FMT_SH) {
@@ -643,22 +646,25 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
         for (int c = 0; c < C; ++c) gl[lane * 3 + c] = grad_out[q * (C + 1) + c];
     }
     for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; fill[i] = 0; }
-    if (threadIdx.x == 0) { s_nb = 0; s_used = 0; }
+    if (threadIdx.x == 0) s_nb = 0;
     __syncthreads();
 
-    // list positions are taken kGroup at a time per wavefront (their loads overlap)
+    // List positions are taken kGroup at a time per wavefront (their loads overlap), RPP
+    // rounds of W * kGroup positions per pass: the schedule is fixed by maxn alone -- a
+    // pass holds at most RPP * W * kGroup * 64 <= R records and as many distinct rows <= T,
+    // so neither the buffer nor the table (which may run full: every key searched for is
+    // then present) needs a data-dependent check between workgroup barriers.
     constexpr int kGroup = W >= 8 ? 1 : 2;
-    static_assert(R >= 64 * kGroup * W && T > 64 * kGroup * W, "a round of list positions must fit the buffer and the table");
+    constexpr int kRound = kGroup * W;                       // list positions per round
+    constexpr int RPP = R / (64 * kRound);                   // rounds per pass
+    static_assert(RPP >= 1 && RPP * 64 * kRound <= T, "a pass must fit the buffer and the table");
     typedef float v4f __attribute__((ext_vector_type(4)));
-    int k0 = 0;                                  // next list position of the workgroup (uniform)
-    while (true) {
+    for (int k0 = 0; k0 < maxn; k0 += RPP * kRound) {
         // ---- load: fill the record buffer and the hash table
-        while (true) {
-            __syncthreads();
-            const int nb = s_nb, used = s_used;
-            __syncthreads();                     // everyone has read the counters before anyone moves them
-            if (!(k0 < maxn && nb + 64 * kGroup * W <= R && used + 64 * kGroup * W < T)) break;
-            const int kb = k0 + wave * kGroup;   // this wavefront's positions of the round
+#pragma unroll 1
+        for (int rd = 0; rd < RPP; ++rd) {
+            const int kb = k0 + rd * kRound + wave * kGroup;   // this wavefront's positions of the round
+            if (kb >= maxn) break;                             // wavefront-uniform; no barrier inside this loop
             uint2 e[kGroup];
             v4f c4[kGroup];
 #pragma unroll
@@ -675,25 +681,19 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
                 const bool active = kb + u < nrec;
                 const unsigned long long am = __ballot(active);
                 if (am == 0ull) continue;
-                bool fresh = false;
                 uint32_t h = 0;
                 if (active) {
                     const int32_t idx = (int32_t)e[u].x;
                     h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
                     while (true) {
                         const int32_t old = atomicCAS(keys + h, -1, idx);
-                        if (old == -1) { fresh = true; break; }
-                        if (old == idx) break;
+                        if (old == -1 || old == idx) break;
                         h = (h + 1u) & (uint32_t)(T - 1);
                     }
                     atomicAdd(cnt + h, 1);
                 }
-                const unsigned long long fm = __ballot(fresh);
                 int base = 0;
-                if (lane == 0) {
-                    base = atomicAdd(&s_nb, __popcll(am));
-                    if (fm != 0ull) atomicAdd(&s_used, __popcll(fm));
-                }
+                if (lane == 0) base = atomicAdd(&s_nb, __popcll(am));
                 base = __shfl(base, 0, 64);
                 if (active) {
                     const int pos = base + __popcll(am & lane_lt);
@@ -702,10 +702,10 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
                     r_w[pos] = c4[u].x; r_c[pos] = c4[u].y; r_c[R + pos] = c4[u].z; r_c[2 * R + pos] = c4[u].w;
                 }
             }
-            k0 += kGroup * W;
         }
+        __syncthreads();
         // ---- sort: exclusive scan of the counters (wavefront 0), counting sort of the record numbers
-        const int nb = s_nb;
+        const int nb = __builtin_amdgcn_readfirstlane(s_nb);
         if (wave == 0) {
             constexpr int PER = T / 64;
             int mine[PER], sum = 0;
@@ -793,10 +793,11 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        if (k0 >= maxn) break;
+        if (k0 + RPP * kRound >= maxn) break;            // last pass (scalar condition)
         __syncthreads();
         for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; fill[i] = 0; }
-        if (threadIdx.x == 0) { s_nb = 0; s_used = 0; }
+        if (threadIdx.x == 0) s_nb = 0;
+        __syncthreads();
     }
 }
 
