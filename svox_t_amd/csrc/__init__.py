@@ -467,10 +467,11 @@ def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bo
 # every contribution bit-identical to the reference formulas; ~0.2 ms slower on
 # the headline workload).
 BWD_EXACT = os.environ.get("SVOXT_BWD_EXACT", "0") not in ("", "0")
-# SVOXT_BWD_GATHER=0: keep the one-kernel backward (every sample's row goes to memory as
-# shaped atomics) instead of the two-kernel one (list walk -> factored records -> per-tile
-# merge in LDS -> one atomic row per tile and feature row), include/svoxt.h svoxt_sample_lists.coef
-BWD_GATHER = os.environ.get("SVOXT_BWD_GATHER", "1") not in ("", "0")
+# SVOXT_BWD_GATHER=0: always the one-kernel backward (every sample's row goes to memory as
+# shaped atomics); 1 (default): the two-kernel one (list walk -> factored records -> per-tile
+# merge in LDS -> one atomic row per tile and feature row, include/svoxt.h
+# svoxt_sample_lists.coef) for batches declared as images; 2: whenever the payload allows
+BWD_GATHER = int(os.environ.get("SVOXT_BWD_GATHER", "1") or 0)     # 0 never, 1 for image batches, 2 whenever possible
 
 
 def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
@@ -491,8 +492,12 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
     stride = K if (K <= 8 or K % 16 == 0) else (K + 15) // 16 * 16
     if lists is not None and lists.consumed:
         lists = None              # a second backward over the same forward: the lists were rewritten
-    gather = lists is not None and BWD_GATHER and K <= 32 and grad_output.shape[1] == 4 and \
-        ct.N == 2 and ct.xform is None
+    # the two-kernel backward pays off when a wavefront's 64 rays revisit the same leaves,
+    # i.e. for image batches walked in 8x8 tiles (0.94 -> 0.54 ms on the headline workload);
+    # on shuffled rays it loses to the one-kernel backward (2.4 vs 1.65 ms)
+    tiled = cr.image_width > 0 and cr.image_width % 8 == 0 and cr.image_height % 8 == 0
+    gather = lists is not None and K <= 32 and grad_output.shape[1] == 4 and ct.N == 2 and \
+        ct.xform is None and (BWD_GATHER == 2 or (BWD_GATHER == 1 and tiled))
     if gather:
         stride = K                # ~5x fewer row updates: aligned rows no longer pay for the extra copy
     with torch.cuda.device(dev):

@@ -107,7 +107,7 @@ def test_backward_sample_list_capacity_does_not_change_results(gpu, list_samples
     import svox_t_amd.csrc as _C
     from svox_t_amd import synth
     monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", list_samples)
-    monkeypatch.setattr(_C, "BWD_GATHER", from_forward != "one_kernel")
+    monkeypatch.setattr(_C, "BWD_GATHER", 0 if from_forward == "one_kernel" else 2)
     # "exact": lists from the forward, but two list walks instead of using the
     # forward's output for accum (SVOXT_BWD_EXACT=1)
     monkeypatch.setattr(_C, "BWD_EXACT", from_forward == "exact")
@@ -140,6 +140,7 @@ def test_two_kernel_backward_and_repeated_backward(gpu, name, monkeypatch):
     r = svox.VolumeRenderer(tree)
     g = synth.grad_output(c.Q, 4)
     want, abs_sum = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.numpy(), want_abs=True)
+    monkeypatch.setattr(_C, "BWD_GATHER", 2)                 # also without the image declaration
     out = r(tree.features, c.rays_gpu(gpu))
     out.backward(g.to(gpu), retain_graph=True)
     first = tree.features.grad.clone()
@@ -153,7 +154,7 @@ def test_two_kernel_backward_and_repeated_backward(gpu, name, monkeypatch):
     out = r(tree.features, c.rays_gpu(gpu), image_shape=(side, side))
     out.backward(g.to(gpu))
     assert_grads_close(tree.features.grad.cpu().numpy(), want, abs_sum)
-    monkeypatch.setattr(_C, "BWD_GATHER", False)
+    monkeypatch.setattr(_C, "BWD_GATHER", 0)
     tree.features.grad = None
     r(tree.features, c.rays_gpu(gpu)).backward(g.to(gpu))
     assert_grads_close(tree.features.grad.cpu().numpy(), want, abs_sum)
