@@ -180,3 +180,31 @@ def test_image_tile_hint_changes_nothing_but_the_lane_assignment(gpu, shape):
         a = r.opacity_render(tree.features, rays, image_shape=(H, W)).cpu().numpy()
     np.testing.assert_array_equal(d, O.render_depth(c.oracle_tree(), *c.rays_np(), c.oracle_opts()))
     np.testing.assert_array_equal(a, O.opacity_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts()))
+
+
+@pytest.mark.parametrize("kind", ["identical", "zoomed", "wide"])
+def test_two_kernel_backward_extreme_coherence(gpu, kind):
+    """The per-tile merge at its extremes: every ray of a tile hitting the same leaves
+    (64 records per feature row), a camera zoomed into a few leaves, and a wide view in
+    which most records of a tile are different rows."""
+    from svox_t_amd import synth
+    c = Case(depth=6, K=28, data_format="SH9", width=64, height=64)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    if kind == "identical":
+        o = c.origins[2080:2081].repeat(4096, 1)
+        d = c.dirs[2080:2081].repeat(4096, 1)
+    elif kind == "zoomed":
+        o, d, _ = synth.pinhole_rays(64, 64, fx=1111.111 * 64 / 800.0 * 40.0)
+    else:
+        o, d, _ = synth.pinhole_rays(64, 64, fx=1111.111 * 64 / 800.0 * 0.35)
+    v = d.clone()
+    rays = svox.Rays(o.contiguous().to(gpu), d.contiguous().to(gpu), v.contiguous().to(gpu))
+    g = synth.grad_output(4096, 4)
+    out = r(tree.features, rays, image_shape=(64, 64))
+    want = O.volume_render(c.oracle_tree(), o.numpy(), d.numpy(), v.numpy(), c.oracle_opts())
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
+    assert (want[:, 3] > 0.1).mean() > (0.02 if kind == "wide" else 0.2)
+    out.backward(g.to(gpu))
+    gw, ab = O.volume_render_backward(c.oracle_tree(), o.numpy(), d.numpy(), v.numpy(), c.oracle_opts(), g.numpy(), want_abs=True)
+    assert_grads_close(tree.features.grad.cpu().numpy(), gw, ab)
