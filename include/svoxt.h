@@ -174,12 +174,15 @@ typedef struct svoxt_sample_lists {
     void*   rec;           /* device, max_samples * Q * 8 bytes */
     void*   aux;           /* device, Q * 16 bytes: count | overflow, resume point, final transmittance, pad */
     int32_t max_samples;   /* S, 1..4096 */
-    void*   coef;          /* device, max_samples * Q * 16 bytes, 16-byte aligned, or NULL.  Only read by
+    void*   coef;          /* device, coef_bytes >= max_samples * Q * 16 bytes (twice that with tree->xform:
+                              the second half takes each sample's rotated view direction), 16-byte
+                              aligned, or NULL.  Only read by
                               svoxt_volume_render_bwd_replay: with it (3-channel payloads of at most 32
                               floats per row, N = 2) the backward runs as two kernels -- the list walk
                               leaves each sample's contribution in factored form in rec / coef (rec is
                               overwritten), and a second kernel adds them up per 8x8 tile in LDS, so a
                               gradient row goes to memory once per tile instead of once per sample. */
+    int64_t coef_bytes;    /* size of coef (a buffer too small for the route is ignored) */
 } svoxt_sample_lists;
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt);

@@ -88,7 +88,7 @@ class _COptions(ctypes.Structure):       # struct svoxt_options
 
 class _CLists(ctypes.Structure):         # struct svoxt_sample_lists
     _fields_ = [("rec", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("max_samples", ctypes.c_int32),
-                ("coef", ctypes.c_void_p)]
+                ("coef", ctypes.c_void_p), ("coef_bytes", ctypes.c_int64)]
 
 
 _P = ctypes.POINTER
@@ -429,7 +429,8 @@ class SampleLists:
 
     def c_struct(self):
         return _CLists(self.rec.data_ptr(), self.aux.data_ptr(), self.S,
-                       None if self.coef is None else self.coef.data_ptr())
+                       None if self.coef is None else self.coef.data_ptr(),
+                       0 if self.coef is None else self.coef.numel() * 4)
 
 
 def can_record(tree: TreeSpec, opt: RenderOptions) -> bool:
@@ -497,7 +498,7 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
     # on shuffled rays it loses to the one-kernel backward (2.4 vs 1.65 ms)
     tiled = cr.image_width > 0 and cr.image_width % 8 == 0 and cr.image_height % 8 == 0
     gather = lists is not None and K <= 32 and grad_output.shape[1] == 4 and ct.N == 2 and \
-        ct.xform is None and (BWD_GATHER == 2 or (BWD_GATHER == 1 and tiled))
+        (BWD_GATHER == 2 or (BWD_GATHER == 1 and tiled))
     if gather:
         stride = K                # ~5x fewer row updates: aligned rows no longer pay for the extra copy
     with torch.cuda.device(dev):
@@ -506,7 +507,9 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
             if lists.aux.shape[0] != cr.Q or lists.aux.device != dev:
                 raise RuntimeError("sample lists do not belong to this ray batch")
             if gather:
-                lists.coef = torch.empty((lists.S, cr.Q, 4), dtype=torch.float32, device=dev)
+                # with view rotations a second plane holds each sample's rotated direction
+                planes = 2 if ct.xform is not None else 1
+                lists.coef = torch.empty((planes * lists.S, cr.Q, 4), dtype=torch.float32, device=dev)
                 lists.consumed = True
             cl = lists.c_struct()
             fo = None

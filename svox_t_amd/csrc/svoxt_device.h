@@ -512,6 +512,15 @@ __device__ __forceinline__ void rotated_basis(const TreeDev& tr, int format, int
     precalc_basis<0>(format, basis_dim, tr, x, y, z, basis);
 }
 
+// the rotated view direction alone (rt_kernel.cu:284-288)
+__device__ __forceinline__ void rotated_dir(const TreeDev& tr, int32_t idx, const float* vdir, float (&out)[3]) {
+    const int d = tr.xform_dim;
+    const float* m = tr.xform + (int64_t)idx * (d * d);
+    out[0] = m[0] * vdir[0] + m[1] * vdir[1] + m[2] * vdir[2];
+    out[1] = m[d] * vdir[0] + m[d + 1] * vdir[1] + m[d + 2] * vdir[2];
+    out[2] = m[2 * d] * vdir[0] + m[2 * d + 1] * vdir[1] + m[2 * d + 2] * vdir[2];
+}
+
 template <int BD>
 __device__ __forceinline__ void rotated_sh_basis(const TreeDev& tr, int32_t idx, const float* vdir, float* basis) {
     const int d = tr.xform_dim;

@@ -344,11 +344,11 @@ __device__ __forceinline__ void accum_sample(const float (&row)[K], const float*
 // A sample's contribution in factored form, for the two-kernel backward: the colour
 // entry (c, i) is ((weight * basis_i) * coef_c) * g_c with coef_c = sigmoid'(.) for SH,
 // or coef_c itself for RGBA; `sg` is the sigma entry.  Same operations as stage_sample.
-template <int FMT, int C, int BD, int K>
+template <int FMT, int C, int BD, int K, bool XF = false>
 __device__ __forceinline__ void coef_sample(const float (&row)[K], const float* basis, const float* g,
                                             float delta_t, float delta_scale, float light_ray,
                                             float& light, float& accum, float& weight_out,
-                                            float (&coef)[C], float& sg) {
+                                            float (&coef)[C], float& sg, const float* basis_sig = nullptr) {
     const float sigma = row[K - 1];
     const float att = pexpf(-delta_t * sigma * delta_scale);
     const float weight = light * (1.f - att);
@@ -362,7 +362,14 @@ __device__ __forceinline__ void coef_sample(const float (&row)[K], const float* 
             const double sd = sigmoid_d(tmp);
             const float sig = (float)sd;
             coef[c] = (float)((double)sig * (1.0 - (double)sig));
-            total_color = (float)((double)total_color + sd * (double)g[c]);
+            if constexpr (XF) {      // pass 2 of the reference evaluates total_color with the stale basis
+                float tmp2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < BD; ++i) tmp2 += basis_sig[i] * row[c * BD + i];
+                total_color = (float)((double)total_color + sigmoid_d(tmp2) * (double)g[c]);
+            } else {
+                total_color = (float)((double)total_color + sd * (double)g[c]);
+            }
         }
     } else {
 #pragma unroll
@@ -392,7 +399,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                   float* __restrict__ grad, int gstride, uint2* __restrict__ rec, int S,
                   const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
                   float4* __restrict__ coef_out = nullptr) {
-    static_assert(!GATHER || (REPLAY && !XF && C == 3), "two-kernel backward: lists, 3 channels, no view rotations");
+    static_assert(!GATHER || (REPLAY && C == 3), "two-kernel backward: lists, 3 channels");
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     constexpr int KS = K | 1;                         // odd LDS row stride: conflict-free column writes
     __shared__ float stage_all[(kBlock / 64) * 64 * KS];
@@ -523,10 +530,21 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 float row[K];
                 load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
                 float w, cf[C], sg;
-                coef_sample<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, light_ray,
-                                           light, accum, w, cf, sg);
-                rec_put(slot, e.x, sg);
                 typedef float v4f __attribute__((ext_vector_type(4)));
+                if constexpr (XF) {
+                    // the sample's own (rotated) direction goes along: coef[S + k][q]
+                    float rd[3];
+                    rotated_dir(tr, (int32_t)e.x, vd, rd);
+                    precalc_basis<BD>(FMT_SH, BD, tr, rd[0], rd[1], rd[2], basis);
+                    coef_sample<FMT, C, BD, K, true>(row, basis, g, __uint_as_float(e.y), r.delta_scale, light_ray,
+                                                     light, accum, w, cf, sg, basis_last);
+                    __builtin_nontemporal_store(v4f{rd[0], rd[1], rd[2], 0.f},
+                                                reinterpret_cast<v4f*>(coef_out + ((int64_t)(S + k) * rays.Q + q)));
+                } else {
+                    coef_sample<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, light_ray,
+                                               light, accum, w, cf, sg);
+                }
+                rec_put(slot, e.x, sg);
                 __builtin_nontemporal_store(v4f{w, cf[0], cf[1], cf[2]},
                                             reinterpret_cast<v4f*>(coef_out + ((int64_t)k * rays.Q + q)));
             }
@@ -592,11 +610,13 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 // measured: a row per lane summed in registers, 64 rows at a time (most lanes idle behind
 // the longest row, 0.55 ms); column lanes reading record fields straight from LDS
 // (a dependent read chain per record, 1.16 ms).
-template <int FMT, int BD, int T, int R, int W>
+// XF: the basis is per record (view rotations): evaluated in the expand step from the
+// rotated direction the list walk stored in coef[S + k][q].
+template <int FMT, int BD, int T, int R, int W, bool XF = false>
 __global__ void __launch_bounds__(64 * W)
 grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, const uint2* __restrict__ rec,
                   const float4* __restrict__ coef, const uint4* __restrict__ aux,
-                  float* __restrict__ grad, int gstride) {
+                  float* __restrict__ grad, int gstride, int S = 0) {
     // W wavefronts share one tile (64 rays) and its LDS: the phases below are latency
     // chains of LDS operations, and LDS -- not registers -- limits how many tiles a CU
     // holds, so the way to more wavefronts per CU is more wavefronts per tile.  Lane l of
@@ -615,7 +635,8 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
     __shared__ uint16_t order[R];
     __shared__ uint16_t r_sl[R];                 // slot << 6 | lane
     __shared__ float r_sg[R], r_w[R], r_c[3 * R];
-    __shared__ float bases[64 * BDS];
+    __shared__ float r_d[XF ? 3 * R : 1];        // XF: the record's rotated view direction
+    __shared__ float bases[XF ? 1 : 64 * BDS];
     __shared__ float gl[64 * 3];
     __shared__ float stage_all[W * 64 * KS];
     __shared__ int32_t seg_all[W * 64];
@@ -635,7 +656,7 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
     maxn = __builtin_amdgcn_readfirstlane(maxn);
     if (maxn == 0) return;                       // the same in every wavefront of the workgroup
     if (wave == 0 && alive && nrec > 0) {
-        if constexpr (FMT == FMT_SH) {
+        if constexpr (FMT == FMT_SH && !XF) {
             float vd[3], b[BD];
             load_vdir(rays, q, vd);
             precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], b);
@@ -666,14 +687,17 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
             const int kb = k0 + rd * kRound + wave * kGroup;   // this wavefront's positions of the round
             if (kb >= maxn) break;                             // wavefront-uniform; no barrier inside this loop
             uint2 e[kGroup];
-            v4f c4[kGroup];
+            v4f c4[kGroup], d4[kGroup];
 #pragma unroll
             for (int u = 0; u < kGroup; ++u) {
                 e[u] = make_uint2(0u, 0u);
                 c4[u] = v4f{0.f, 0.f, 0.f, 0.f};
+                d4[u] = v4f{0.f, 0.f, 0.f, 0.f};
                 if (kb + u < nrec) {
                     e[u] = rec_get(rec + ((int64_t)(kb + u) * rays.Q + q));
                     c4[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(kb + u) * rays.Q + q)));
+                    if constexpr (XF)
+                        d4[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(S + kb + u) * rays.Q + q)));
                 }
             }
 #pragma unroll
@@ -700,6 +724,7 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
                     r_sl[pos] = (uint16_t)((h << 6) | (uint32_t)lane);
                     r_sg[pos] = __uint_as_float(e[u].y);
                     r_w[pos] = c4[u].x; r_c[pos] = c4[u].y; r_c[R + pos] = c4[u].z; r_c[2 * R + pos] = c4[u].w;
+                    if constexpr (XF) { r_d[pos] = d4[u].x; r_d[R + pos] = d4[u].y; r_d[2 * R + pos] = d4[u].z; }
                 }
             }
         }
@@ -742,7 +767,12 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
                 float* st = stage + lane * KS;
                 if constexpr (FMT == FMT_SH) {
                     const float w = r_w[rr];
+                    float bx[XF ? BD : 1];
                     const float* b = bases + rl * BDS;
+                    if constexpr (XF) {
+                        precalc_basis<BD>(FMT_SH, BD, tr, r_d[rr], r_d[R + rr], r_d[2 * R + rr], bx);
+                        b = bx;
+                    }
 #pragma unroll
                     for (int c3 = 0; c3 < C; ++c3) {
                         const float cc = r_c[c3 * R + rr], gc = gl[rl * 3 + c3];
@@ -1510,10 +1540,11 @@ bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
     return false;
 }
 
-// two-kernel backward: SH 1/4/9 and RGBA with 3 channels (K <= 32) on N = 2 trees
+// two-kernel backward: SH 1/4/9 (also with view rotations) and RGBA with 3 channels
+// (K <= 32) on N = 2 trees
 bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
                        const float* grad_out, float* grad, int gstride, uint2* rec, int S, const uint4* aux,
-                       const float* fwd_out, float4* coef, hipStream_t st) {
+                       const float* fwd_out, float4* coef, bool xf, hipStream_t st) {
     if (C != 3) return false;
     const unsigned nb = nblocks(rays.Q);
     static const int mw = [] { const char* e = getenv("SVOXT_MERGE_WAVES"); return e ? atoi(e) : 4; }();
@@ -1530,6 +1561,21 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
         hipLaunchKernelGGL((grad_merge_kernel<F, BB, 512, 512, 1>), dim3(nb), dim3(64), 0, st, tr, rays,     \
                            grad_out, rec, coef, aux, grad, gstride);                                          \
     return true;
+#define SVOXT_GATHER_XF(BB)                                                                                       \
+    hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, true, true, true>), dim3(nb), dim3(kBlock), 0, st, \
+                       tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out, coef);                       \
+    hipLaunchKernelGGL((grad_merge_kernel<FMT_SH, BB, 1024, 512, 4, true>), dim3(nb), dim3(256), 0, st, tr, rays, \
+                       grad_out, rec, coef, aux, grad, gstride, S);                                               \
+    return true;
+    if (xf) {
+        if (opt.format != FMT_SH) return false;
+        switch (opt.basis_dim) {
+            case 1: SVOXT_GATHER_XF(1)
+            case 4: SVOXT_GATHER_XF(4)
+            case 9: SVOXT_GATHER_XF(9)
+        }
+        return false;
+    }
     if (opt.format == FMT_RGBA) { SVOXT_GATHER(FMT_RGBA, 0) }
     if (opt.format == FMT_SH) {
         switch (opt.basis_dim) {
@@ -1539,6 +1585,7 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
         }
     }
 #undef SVOXT_GATHER
+#undef SVOXT_GATHER_XF
     return false;
 }
 
@@ -1602,9 +1649,16 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
     if (C > 0 && full_comp(opt) && xf && xform_special(tree, opt)) {
         int64_t S = (workspace != nullptr && workspace_bytes > 0) ? workspace_bytes / (8 * rays->Q) : 0;
         if (S > 4096) S = 4096;
-        if (lists != nullptr)
-            done = launch_bwd_xform<true>(tr, rd, od, C, grad_out, grad_features, gs, reinterpret_cast<uint2*>(lists->rec),
-                                          lists->max_samples, reinterpret_cast<const uint4*>(lists->aux), fwd_out, st);
+        if (lists != nullptr) {
+            const int64_t need = (int64_t)lists->max_samples * rays->Q * 32;
+            if (lists->coef != nullptr && tree->K <= 32 && lists->coef_bytes >= need)
+                done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, reinterpret_cast<uint2*>(lists->rec),
+                                         lists->max_samples, reinterpret_cast<const uint4*>(lists->aux), fwd_out,
+                                         reinterpret_cast<float4*>(lists->coef), true, st);
+            if (!done)
+                done = launch_bwd_xform<true>(tr, rd, od, C, grad_out, grad_features, gs, reinterpret_cast<uint2*>(lists->rec),
+                                              lists->max_samples, reinterpret_cast<const uint4*>(lists->aux), fwd_out, st);
+        }
         else
             done = launch_bwd_xform<false>(tr, rd, od, C, grad_out, grad_features, gs,
                                            S > 0 ? reinterpret_cast<uint2*>(workspace) : nullptr, (int)S, nullptr, nullptr, st);
@@ -1617,9 +1671,10 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
         if (lists != nullptr) {
             uint2* lrec = reinterpret_cast<uint2*>(lists->rec);
             const uint4* laux = reinterpret_cast<const uint4*>(lists->aux);
-            if (n2 && lists->coef != nullptr && tree->K <= 32)
+            if (n2 && lists->coef != nullptr && tree->K <= 32 &&
+                lists->coef_bytes >= (int64_t)lists->max_samples * rays->Q * 16)
                 done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux,
-                                         fwd_out, reinterpret_cast<float4*>(lists->coef), st);
+                                         fwd_out, reinterpret_cast<float4*>(lists->coef), false, st);
             if (!done) done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux, fwd_out, st)
                       : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux, fwd_out, st);
             if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no specialised kernel for this payload", fn);

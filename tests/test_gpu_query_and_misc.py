@@ -381,6 +381,8 @@ def test_acceleration_grid_never_goes_stale(gpu):
     ("SH9", 28, 5, "exact"),          # ... two list walks (SVOXT_BWD_EXACT)
     ("SH9", 28, 5, "standalone"),     # ... backward without forward lists (own workspace)
     ("SH4", 13, 5, "lists"),
+    ("SH9", 28, 5, "two_kernel"),     # ... list walk + per-tile merge (rotated directions travel with the records)
+    ("SH4", 13, 6, "two_kernel_overflow"),
     ("SH16", 49, 4, "lists"),
     ("SG6", 19, 4, "generic"),        # view-dependent format without a specialised kernel
 ])
@@ -400,8 +402,9 @@ def test_transformation_matrices(gpu, monkeypatch, fmt, K, depth, mode):
     g = torch.Generator().manual_seed(9)
     A = torch.randn(M, 3, 3, generator=g)
     Qm, _ = torch.linalg.qr(A)                                # random rotations
-    if mode == "overflow":
+    if mode in ("overflow", "two_kernel_overflow"):
         monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", 4)
+    monkeypatch.setattr(_C, "BWD_GATHER", 2 if mode.startswith("two_kernel") else 0)
     if mode == "exact":
         monkeypatch.setattr(_C, "BWD_EXACT", True)
     r = svox.VolumeRenderer(tree)
