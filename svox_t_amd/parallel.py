@@ -42,12 +42,24 @@ def shard_rays(rays, world: int, rank: int):
     return type(rays)(*(t[lo:hi].contiguous() for t in rays))
 
 
-def _gather_rows(local: torch.Tensor, Q: int, group) -> torch.Tensor:
-    """All-gather row shards of unequal length into the full [Q, ...] tensor."""
+def image_shard_bounds(height: int, width: int, world: int, rank: int) -> Tuple[int, int]:
+    """[lo, hi) ray range of `rank` when the rays are the row-major pixels of a
+    height x width image: whole bands of 8 rows per rank where the image allows it, so
+    that every shard is itself an image the kernels can walk in 8x8 tiles (and the
+    two-kernel backward can merge per tile)."""
+    if height % 8 == 0 and width % 8 == 0 and height // 8 >= world:
+        lo, hi = shard_bounds(height // 8, world, rank)
+        return lo * 8 * width, hi * 8 * width
+    return shard_bounds(height * width, world, rank)
+
+
+def _gather_shards(local: torch.Tensor, bounds, group) -> torch.Tensor:
+    """All-gather row shards of unequal length (bounds[r] = [lo, hi) of rank r, contiguous
+    and in rank order) into the full tensor."""
     world = dist.get_world_size(group)
     if world == 1:
         return local
-    cap = (Q + world - 1) // world                  # rows per rank, padded
+    cap = max(hi - lo for lo, hi in bounds)           # rows per rank, padded
     tail = local.shape[1:]
     if local.shape[0] != cap:
         pad = local.new_zeros((cap,) + tuple(tail))
@@ -55,13 +67,15 @@ def _gather_rows(local: torch.Tensor, Q: int, group) -> torch.Tensor:
         local = pad
     full = local.new_empty((world * cap,) + tuple(tail))
     dist.all_gather_into_tensor(full, local.contiguous(), group=group)
-    if Q == world * cap:
+    if all(hi - lo == cap for lo, hi in bounds):
         return full
-    parts = []
-    for r in range(world):
-        lo, hi = shard_bounds(Q, world, r)
-        parts.append(full[r * cap:r * cap + (hi - lo)])
-    return torch.cat(parts, dim=0)
+    return torch.cat([full[r * cap:r * cap + (hi - lo)] for r, (lo, hi) in enumerate(bounds)], dim=0)
+
+
+def _gather_rows(local: torch.Tensor, Q: int, group) -> torch.Tensor:
+    """All-gather balanced row shards (shard_bounds) into the full [Q, ...] tensor."""
+    world = dist.get_world_size(group)
+    return _gather_shards(local, [shard_bounds(Q, world, r) for r in range(world)], group)
 
 
 class _ShardedRender(autograd.Function):
@@ -70,16 +84,25 @@ class _ShardedRender(autograd.Function):
     that grad_out is identical on all ranks (data-parallel convention)."""
 
     @staticmethod
-    def forward(ctx, features, render_fn, rays, group):
+    def forward(ctx, features, render_fn, rays, group, image_shape):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         Q = rays.origins.shape[0]
-        local_rays = shard_rays(rays, world, rank)
+        if image_shape is not None and image_shape[0] * image_shape[1] == Q:
+            bounds = [image_shard_bounds(image_shape[0], image_shape[1], world, r) for r in range(world)]
+        else:
+            image_shape = None
+            bounds = [shard_bounds(Q, world, r) for r in range(world)]
+        lo, hi = bounds[rank]
+        local_rays = type(rays)(*(t[lo:hi].contiguous() for t in rays))
+        local_shape = None
+        if image_shape is not None and (hi - lo) % image_shape[1] == 0 and hi > lo:
+            local_shape = ((hi - lo) // image_shape[1], image_shape[1])
         with torch.enable_grad():
             feats = features.detach().requires_grad_(True)
-            local_out = render_fn(feats, local_rays)
+            local_out = render_fn(feats, local_rays, local_shape)
         ctx.feats, ctx.local_out, ctx.group = feats, local_out, group
-        ctx.bounds = shard_bounds(Q, world, rank)
-        return _gather_rows(local_out.detach(), Q, group)
+        ctx.bounds = (lo, hi)
+        return _gather_shards(local_out.detach(), bounds, group)
 
     @staticmethod
     def backward(ctx, grad_full):
@@ -91,20 +114,24 @@ class _ShardedRender(autograd.Function):
         g = g.contiguous()
         if dist.get_world_size(ctx.group) > 1:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-        return g, None, None, None
+        return g, None, None, None, None
 
 
 def render_sharded(renderer_or_fn, features: torch.Tensor, rays,
-                   group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+                   group: Optional[dist.ProcessGroup] = None, image_shape=None) -> torch.Tensor:
     """Render `rays` [Q, 3] cooperatively on all ranks of `group`.
 
     :param renderer_or_fn: a VolumeRenderer, or any callable (features, Rays) -> [q, C+1]
+    :param image_shape: optional (H, W): the rays are the row-major pixels of an image;
+           ranks then get whole bands of 8 rows and render them as images (8x8 tiles)
     :return: the full [Q, C+1] output on every rank; differentiable wrt
              `features` (gradient all-reduced over ranks).
     """
-    fn: Callable = renderer_or_fn if not hasattr(renderer_or_fn, "forward") \
-        else (lambda f, r: renderer_or_fn(f, r))
-    return _ShardedRender.apply(features, fn, rays, group)
+    if hasattr(renderer_or_fn, "forward"):
+        fn: Callable = lambda f, r, shape: renderer_or_fn(f, r, image_shape=shape)
+    else:
+        fn = lambda f, r, shape: renderer_or_fn(f, r)
+    return _ShardedRender.apply(features, fn, rays, group, image_shape)
 
 
 class _CameraSet(autograd.Function):

@@ -15,6 +15,14 @@ from svox_t_amd import parallel
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_image_shard_bounds_are_bands_of_eight_rows():
+    for H, W, world in ((800, 800, 8), (64, 40, 3), (24, 16, 2), (20, 16, 2), (16, 16, 4)):
+        b = [parallel.image_shard_bounds(H, W, world, r) for r in range(world)]
+        assert b[0][0] == 0 and b[-1][1] == H * W and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        if H % 8 == 0 and W % 8 == 0 and H // 8 >= world:
+            assert all(lo % (8 * W) == 0 and hi % (8 * W) == 0 for lo, hi in b)
+
+
 def test_shard_bounds_cover_exactly_once():
     for Q in (0, 1, 7, 64, 640000, 640001):
         for W in (1, 2, 3, 8):
@@ -48,7 +56,7 @@ def _worker(rank, world, port, Q, result_dir):
                                     features=features)
 
         feats = torch.from_numpy(ot.features).double().requires_grad_(True)
-        full = parallel.render_sharded(render_fn, feats, rays)
+        full = parallel.render_sharded(render_fn, feats, rays, image_shape=(16, Q // 16) if Q % 128 == 0 else None)
         gout = synth.grad_output(Q, 4).double()
         (full * gout).sum().backward()
         # single-process reference
@@ -62,7 +70,7 @@ def _worker(rank, world, port, Q, result_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("Q", [64, 37])          # even and ragged split
+@pytest.mark.parametrize("Q", [64, 37, 128])     # even split, ragged split, image bands of 8 rows
 def test_render_sharded_two_ranks(tmp_path, Q):
     port = 29500 + (os.getpid() + Q) % 2000
     mp.spawn(_worker, args=(2, port, Q, str(tmp_path)), nprocs=2, join=True)
