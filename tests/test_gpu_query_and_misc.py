@@ -435,3 +435,37 @@ def test_transformation_matrices(gpu, monkeypatch, fmt, K, depth, mode):
     with torch.no_grad():
         same = r(tree.features, rays, transformation_matrices=eye.to(gpu)).cpu().numpy()
     np.testing.assert_array_equal(same, plain)
+
+
+def test_render_sharded_and_render_cameras_single_rank_on_gpu(gpu):
+    """parallel.render_sharded / render_cameras with the real renderer (world size 1, gloo):
+    the same pixels and gradients as the direct calls."""
+    import os
+    import torch.distributed as dist
+    from svox_t_amd import parallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        c = Case(depth=5, K=28, data_format="SH9", width=48, height=40)
+        tree = c.tree(gpu)
+        r = svox.VolumeRenderer(tree)
+        rays = c.rays_gpu(gpu)
+        g = synth.grad_output(c.Q, 4).to(gpu)
+        f1 = tree.features.detach().clone().requires_grad_(True)
+        out1 = parallel.render_sharded(r, f1, rays, image_shape=(40, 48))
+        out1.backward(g)
+        f2 = tree.features.detach().clone().requires_grad_(True)
+        out2 = r(f2, rays, image_shape=(40, 48))
+        out2.backward(g)
+        assert torch.equal(out1, out2)
+        want, ab = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.cpu().numpy(), want_abs=True)
+        assert_grads_close(f1.grad.cpu().numpy(), want, ab)
+        assert_grads_close(f2.grad.cpu().numpy(), want, ab)
+        poses = torch.stack([torch.from_numpy(synth.camera_pose(azimuth_deg=a).astype(np.float32)) for a in (20.0, 110.0)])
+        imgs = parallel.render_cameras(r, f1, poses.to(gpu), width=32, height=24, fx=40.0)
+        assert imgs.shape == (2, 24, 32, 4)
+        with torch.no_grad():
+            assert torch.equal(imgs[1], r.render_persp(f1, poses[1].to(gpu), width=32, height=24, fx=40.0))
+    finally:
+        dist.destroy_process_group()
