@@ -680,6 +680,25 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
     constexpr int RPP = R / (64 * kRound);                   // rounds per pass
     static_assert(RPP >= 1 && RPP * 64 * kRound <= T, "a pass must fit the buffer and the table");
     typedef float v4f __attribute__((ext_vector_type(4)));
+    // the records of a round are requested one round ahead (across the sort / reduce of the
+    // pass in between as well), so their memory latency is not waited for
+    uint2 e_n[kGroup];
+    v4f c_n[kGroup], d_n[kGroup];
+    auto request = [&](int kb) {
+#pragma unroll
+        for (int u = 0; u < kGroup; ++u) {
+            e_n[u] = make_uint2(0u, 0u);
+            c_n[u] = v4f{0.f, 0.f, 0.f, 0.f};
+            d_n[u] = v4f{0.f, 0.f, 0.f, 0.f};
+            if (kb + u < nrec) {
+                e_n[u] = rec_get(rec + ((int64_t)(kb + u) * rays.Q + q));
+                c_n[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(kb + u) * rays.Q + q)));
+                if constexpr (XF)
+                    d_n[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(S + kb + u) * rays.Q + q)));
+            }
+        }
+    };
+    request(wave * kGroup);
     for (int k0 = 0; k0 < maxn; k0 += RPP * kRound) {
         // ---- load: fill the record buffer and the hash table
 #pragma unroll 1
@@ -689,17 +708,8 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
             uint2 e[kGroup];
             v4f c4[kGroup], d4[kGroup];
 #pragma unroll
-            for (int u = 0; u < kGroup; ++u) {
-                e[u] = make_uint2(0u, 0u);
-                c4[u] = v4f{0.f, 0.f, 0.f, 0.f};
-                d4[u] = v4f{0.f, 0.f, 0.f, 0.f};
-                if (kb + u < nrec) {
-                    e[u] = rec_get(rec + ((int64_t)(kb + u) * rays.Q + q));
-                    c4[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(kb + u) * rays.Q + q)));
-                    if constexpr (XF)
-                        d4[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(S + kb + u) * rays.Q + q)));
-                }
-            }
+            for (int u = 0; u < kGroup; ++u) { e[u] = e_n[u]; c4[u] = c_n[u]; d4[u] = d_n[u]; }
+            if (kb + kRound < maxn) request(kb + kRound);      // this wavefront's positions of the next round
 #pragma unroll
             for (int u = 0; u < kGroup; ++u) {
                 const bool active = kb + u < nrec;
