@@ -108,10 +108,12 @@ def test_random_tree_and_rays(gpu, seed, N, fmt, K, monkeypatch):
 
 
 @pytest.mark.parametrize("seed", [0, 1])
-def test_random_tree_view_rotations_and_motion(gpu, seed):
+def test_random_tree_view_rotations_and_motion(gpu, seed, monkeypatch):
     """The same adversarial trees and rays through the view-rotation kernels (arbitrary,
     not even orthonormal, 4x4 matrices; with and without thresholds) and the motion
     variants."""
+    import svox_t_amd.csrc as _C
+    monkeypatch.setattr(_C, "BWD_GATHER", 2 if seed % 2 else 1)     # seed 1: two-kernel backward with rotations
     t, feats = random_tree(seed, N=2, max_depth=6, data_format="SH4", K=13)
     n = t.n_internal
     M = feats.shape[0]
