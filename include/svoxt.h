@@ -217,6 +217,17 @@ int svoxt_opacity_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
                              const svoxt_options* opt, const float* grad_out,
                              float* grad_features, void* stream);
 
+/* The same pair with sample lists (both thresholds 0): the forward records each ray's
+ * samples, the backward walks the lists instead of marching twice and adds the
+ * contributions up per 8x8 tile before they go to memory (rec and aux are rewritten:
+ * the lists serve one backward).  Every contribution is the reference's
+ * delta_t * delta_scale * grad_output * T_ray (rt_kernel.cu:486-490 without colour terms). */
+int svoxt_opacity_render_fwd_record(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
+                                    float* out, const svoxt_sample_lists* lists, void* stream);
+int svoxt_opacity_render_bwd_replay(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
+                                    const float* grad_out, float* grad_features, int32_t grad_stride,
+                                    const svoxt_sample_lists* lists, void* stream);
+
 /* depth: device [Q, 1] = delta_scale * t of the first sample with
  * sigma > sigma_thresh, 0 if none. */
 int svoxt_render_depth(const svoxt_tree* tree, const svoxt_rays* rays,

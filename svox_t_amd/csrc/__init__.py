@@ -110,6 +110,9 @@ EXPORTS = {
     "svoxt_volume_render_bwd_replay": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _P(_CLists), _vp, _vp]),
     "svoxt_opacity_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
     "svoxt_opacity_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp]),
+    "svoxt_opacity_render_fwd_record": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _P(_CLists), _vp]),
+    "svoxt_opacity_render_bwd_replay": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp,
+                                                        ctypes.c_int32, _P(_CLists), _vp]),
     "svoxt_render_depth": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
     "svoxt_query_fwd": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "svoxt_query_bwd": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp, _vp, _vp]),
@@ -568,29 +571,48 @@ def render_depth(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Te
     return depth
 
 
-def opacity_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
-    """rt_kernel.cu:1574-1591."""
+def opacity_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bool = False):
+    """rt_kernel.cu:1574-1591.  `record=True` (not in the reference): also return the
+    sample lists opacity_render_backward can walk (None when thresholds are non-zero)."""
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
+    lists = None
     with torch.cuda.device(dev):
         out = torch.empty((cr.Q, 1), dtype=torch.float32, device=dev)
-        _call("svoxt_opacity_render_fwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
-              _ptr(out), _stream(dev))
-    return out
+        if record and BWD_LIST_SAMPLES > 0 and cr.Q > 0 and co.sigma_thresh == 0.0 and co.stop_thresh == 0.0:
+            lists = SampleLists(cr.Q, BWD_LIST_SAMPLES, dev)
+            cl = lists.c_struct()
+            _call("svoxt_opacity_render_fwd_record", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+                  _ptr(out), ctypes.byref(cl), _stream(dev))
+        else:
+            _call("svoxt_opacity_render_fwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+                  _ptr(out), _stream(dev))
+    return (out, lists) if record else out
 
 
 def opacity_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
-                            grad_output: torch.Tensor) -> torch.Tensor:
-    """rt_kernel.cu:1593-1616."""
+                            grad_output: torch.Tensor, lists: SampleLists = None) -> torch.Tensor:
+    """rt_kernel.cu:1593-1616.  `lists` (optional, not in the reference): what
+    opacity_render(..., record=True) returned for the same tree / rays / options."""
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     _check_input(grad_output, "grad_output")
     if grad_output.dtype != torch.float32 or grad_output.numel() != cr.Q:
         raise RuntimeError("grad_output must be float32 [Q, 1]")
     dev = tree.features.device
+    if lists is not None and lists.consumed:
+        lists = None
     with torch.cuda.device(dev):
         grad = torch.empty_like(tree.features)
-        _call("svoxt_opacity_render_bwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
-              _ptr(grad_output), _ptr(grad), _stream(dev))
+        if lists is not None:
+            if lists.aux.shape[0] != cr.Q or lists.aux.device != dev:
+                raise RuntimeError("sample lists do not belong to this ray batch")
+            lists.consumed = True
+            cl = lists.c_struct()
+            _call("svoxt_opacity_render_bwd_replay", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+                  _ptr(grad_output), _ptr(grad), 0, ctypes.byref(cl), _stream(dev))
+        else:
+            _call("svoxt_opacity_render_bwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+                  _ptr(grad_output), _ptr(grad), _stream(dev))
     return grad
 
 

@@ -18,7 +18,8 @@
 //                              stages gradient rows in LDS, flushes them as shaped atomics
 //   render_bwd_generic_kernel  fallback backward, per-lane atomics (opacity backward, K > 64)
 //   render_bwd_generic_staged_kernel  fallback backward with LDS-staged, shaped atomics
-//   opacity_fwd_kernel, depth_kernel, count_fwd_kernel
+//   opacity_fwd_kernel (+ opacity_walk_kernel, opacity_merge_kernel: backward from lists),
+//   depth_kernel, count_fwd_kernel
 //   query_fwd_kernel, query_bwd_kernel, leaves_count / scan / scatter kernels
 //   compact_rows_kernel, accel_build_kernel
 // Other translation units of the library: svoxt_build.hip (octree from a point
@@ -1080,28 +1081,171 @@ render_bwd_generic_staged_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
 // Opacity (rt_kernel.cu:500-560, :1110-1126) and depth (:782-834, :866-882)
 // ---------------------------------------------------------------------------
 
-template <bool N2>
+// REC (thresholds 0): also records each ray's samples with sigma > 0 as (feature row,
+// delta_t) in rec[k][q] and aux[q] = {count | overflow << 31, t of the first unrecorded
+// sample, final transmittance, -} for svoxt_opacity_render_bwd_replay.
+template <bool N2, bool REC = false>
 __global__ void __launch_bounds__(kBlock)
-opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out) {
+opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
+                   uint2* __restrict__ rec = nullptr, int S = 0, uint4* __restrict__ aux = nullptr) {
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     if (q >= rays.Q) return;
     Ray r;
-    if (!setup_ray(tr, rays, opt, q, r)) { out[q] = 0.f; return; }
+    if (!setup_ray(tr, rays, opt, q, r)) {
+        out[q] = 0.f;
+        if constexpr (REC) aux[q] = make_uint4(0u, 0u, __float_as_uint(1.f), 0u);
+        return;
+    }
     const int K = tr.K;
     float light = 1.f, t = r.tmin;
+    int nrec = 0;
+    bool over = false;
+    float t_resume = 0.f;
     while (t < r.tmax) {
         Sample s;
         march_step<N2>(tr, r, opt.step_size, t, s);
         if (s.valid) {
             const float sigma = tr.features[(int64_t)s.idx * K + (K - 1)];
             if (sigma > opt.sigma_thresh) {
+                if constexpr (REC) {
+                    if (nrec < S) {
+                        rec_put(rec + ((int64_t)nrec * rays.Q + q), (uint32_t)s.idx, s.delta_t);
+                        ++nrec;
+                    } else if (!over) {
+                        over = true;
+                        t_resume = t;
+                    }
+                }
                 light *= pexpf(-s.delta_t * r.delta_scale * sigma);
-                if (light <= opt.stop_thresh) break;
+                if constexpr (!REC) {
+                    if (light <= opt.stop_thresh) break;
+                }
             }
         }
         t = march_advance(t, s.delta_t);
     }
     out[q] = 1.f - light;
+    if constexpr (REC)
+        aux[q] = make_uint4((uint32_t)nrec | (over ? kRecOverflow : 0u), __float_as_uint(t_resume),
+                            __float_as_uint(light), 0u);
+}
+
+// opacity_render_backward from recorded lists (C = 0 of trace_ray_backward,
+// rt_kernel.cu:331-496, 1593-1616): the only gradient is the sigma entry
+//     delta_t * delta_scale * grad_output * T_ray            (:486-490 with no colour terms)
+// with T_ray the final transmittance as the reference's backward computes it
+// (exponent associated as in :397).  One walk: rec[k][q] <- (row, (delta_t * delta_scale) *
+// grad_output) and aux[q].w <- T_ray; opacity_merge_kernel multiplies by T_ray and adds
+// up per tile.  Rays whose list overflowed march their tail here (twice: T_ray must be
+// complete before their tail samples can be sent) with per-lane atomics.
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+opacity_walk_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
+                    float* __restrict__ grad, int gstride, uint2* __restrict__ rec, uint4* __restrict__ aux) {
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+    if (q >= rays.Q) return;
+    const uint4 a = aux[q];
+    const int nrec = (int)(a.x & ~kRecOverflow);
+    const bool over = (a.x & kRecOverflow) != 0u;
+    if (nrec == 0 && !over) return;
+    Ray r;
+    if (!setup_ray(tr, rays, opt, q, r)) return;
+    const int K = tr.K;
+    const float g = grad_out[q];
+    float light = 1.f;
+    for (int k = 0; k < nrec; ++k) {
+        uint2* slot = rec + ((int64_t)k * rays.Q + q);
+        const uint2 e = rec_get(slot);
+        const float delta_t = __uint_as_float(e.y);
+        const float sigma = tr.features[(int64_t)(int32_t)e.x * K + (K - 1)];
+        light *= pexpf(-delta_t * sigma * r.delta_scale);
+        rec_put(slot, e.x, delta_t * r.delta_scale * g);
+    }
+    if (over) {
+        const float t0 = __uint_as_float(a.y);
+        for (int pass = 0; pass < 2; ++pass) {
+            const float light_ray = light;                  // complete only in the second pass
+            float t = t0;
+            while (t < r.tmax) {
+                Sample s;
+                march_step<N2>(tr, r, opt.step_size, t, s);
+                if (s.valid) {
+                    const float sigma = tr.features[(int64_t)s.idx * K + (K - 1)];
+                    if (sigma > 0.f) {
+                        if (pass == 0) light *= pexpf(-s.delta_t * sigma * r.delta_scale);
+                        else atomicAdd(grad + (int64_t)s.idx * gstride + (K - 1), s.delta_t * r.delta_scale * g * light_ray);
+                    }
+                }
+                t = march_advance(t, s.delta_t);
+            }
+        }
+    }
+    aux[q].w = __float_as_uint(light);
+}
+
+// Per-tile sum of the walk's records: W wavefronts share a hash table of T feature rows
+// (atomicCAS on the key, ds_add_f32 on the one value per row: 1 LDS float atomic per
+// record is cheap, 28 were not), flushed after every pass of at most T records.
+template <int T, int W>
+__global__ void __launch_bounds__(64 * W)
+opacity_merge_kernel(RaysDev rays, const uint2* __restrict__ rec, const uint4* __restrict__ aux,
+                     float* __restrict__ grad, int gstride, int col) {
+    constexpr int NT = 64 * W;
+    constexpr int kGroup = 2, kRound = kGroup * W, RPP = T / (64 * kRound);
+    static_assert((T & (T - 1)) == 0 && RPP >= 1, "a pass of RPP rounds must fit the table");
+    __shared__ int32_t keys[T];
+    __shared__ float vals[T];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * 64 + lane);
+    int nrec = 0;
+    float t_ray = 0.f;
+    if (q < rays.Q) {
+        const uint4 a = aux[q];
+        nrec = (int)(a.x & ~kRecOverflow);
+        t_ray = __uint_as_float(a.w);
+    }
+    int maxn = nrec;
+    for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
+    maxn = __builtin_amdgcn_readfirstlane(maxn);
+    if (maxn == 0) return;
+    for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; vals[i] = 0.f; }
+    __syncthreads();
+    for (int k0 = 0; k0 < maxn; k0 += RPP * kRound) {
+#pragma unroll 1
+        for (int rd = 0; rd < RPP; ++rd) {
+            const int kb = k0 + rd * kRound + wave * kGroup;
+            if (kb >= maxn) break;
+            uint2 e[kGroup];
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u) {
+                e[u] = make_uint2(0u, 0u);
+                if (kb + u < nrec) e[u] = rec_get(rec + ((int64_t)(kb + u) * rays.Q + q));
+            }
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u) {
+                if (kb + u < nrec) {
+                    const int32_t idx = (int32_t)e[u].x;
+                    uint32_t h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
+                    while (true) {
+                        const int32_t old = atomicCAS(keys + h, -1, idx);
+                        if (old == -1 || old == idx) break;
+                        h = (h + 1u) & (uint32_t)(T - 1);
+                    }
+                    atomicAdd(vals + h, __uint_as_float(e[u].y) * t_ray);     // ((delta_t * ds) * g) * T_ray
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < T; i += NT) {
+            const int32_t key = keys[i];
+            if (key >= 0) {
+                atomicAdd(grad + (int64_t)key * gstride + col, vals[i]);
+                keys[i] = -1;
+                vals[i] = 0.f;
+            }
+        }
+        __syncthreads();
+    }
 }
 
 template <bool N2>
@@ -1856,6 +2000,50 @@ int svoxt_opacity_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
                              float* grad_features, void* stream) {
     return bwd_common(tree, rays, opt, grad_out, 1, grad_features, 0, nullptr, 0, nullptr, nullptr, stream,
                       "svoxt_opacity_render_bwd");
+}
+
+int svoxt_opacity_render_fwd_record(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
+                                    float* out, const svoxt_sample_lists* lists, void* stream) {
+    const char* fn = "svoxt_opacity_render_fwd_record";
+    int rc;
+    if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) || (rc = check_opts(opt, tree, fn, false)) ||
+        (rc = check_lists(lists, opt, fn))) return rc;
+    if (rays->Q == 0) return SVOXT_OK;
+    if (out == nullptr) return fail(SVOXT_ERR_INVALID, "%s: out is NULL", fn);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = nblocks(rays->Q);
+    uint2* rec = reinterpret_cast<uint2*>(lists->rec);
+    uint4* aux = reinterpret_cast<uint4*>(lists->aux);
+    if (tree->N == 2) hipLaunchKernelGGL((opacity_fwd_kernel<true, true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), out, rec, lists->max_samples, aux);
+    else hipLaunchKernelGGL((opacity_fwd_kernel<false, true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), out, rec, lists->max_samples, aux);
+    return check_launch(fn);
+}
+
+int svoxt_opacity_render_bwd_replay(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
+                                    const float* grad_out, float* grad_features, int32_t grad_stride,
+                                    const svoxt_sample_lists* lists, void* stream) {
+    const char* fn = "svoxt_opacity_render_bwd_replay";
+    int rc;
+    if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) || (rc = check_opts(opt, tree, fn, false)) ||
+        (rc = check_lists(lists, opt, fn))) return rc;
+    if (grad_features == nullptr && tree->M > 0) return fail(SVOXT_ERR_INVALID, "%s: grad_features is NULL", fn);
+    if (rays->Q > 0 && grad_out == nullptr) return fail(SVOXT_ERR_INVALID, "%s: grad_out is NULL", fn);
+    const int gs = grad_stride > 0 ? grad_stride : tree->K;
+    if (gs < tree->K) return fail(SVOXT_ERR_INVALID, "%s: grad_stride smaller than data_dim", fn);
+    hipStream_t st = (hipStream_t)stream;
+    if (tree->M > 0) {
+        const hipError_t e = hipMemsetAsync(grad_features, 0, sizeof(float) * (size_t)tree->M * gs, st);
+        if (e != hipSuccess) return fail(SVOXT_ERR_HIP, "%s: hipMemsetAsync: %s", fn, hipGetErrorString(e));
+    }
+    if (rays->Q == 0 || tree->M == 0) return SVOXT_OK;
+    const unsigned nb = nblocks(rays->Q);
+    const RaysDev rd = to_dev(rays);
+    uint2* rec = reinterpret_cast<uint2*>(lists->rec);
+    uint4* aux = reinterpret_cast<uint4*>(lists->aux);
+    if (tree->N == 2) hipLaunchKernelGGL((opacity_walk_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), rd, to_dev(opt), grad_out, grad_features, gs, rec, aux);
+    else hipLaunchKernelGGL((opacity_walk_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), rd, to_dev(opt), grad_out, grad_features, gs, rec, aux);
+    hipLaunchKernelGGL((opacity_merge_kernel<1024, 4>), dim3(nb), dim3(256), 0, st, rd, rec, aux, grad_features, gs, (int)tree->K - 1);
+    return check_launch(fn);
 }
 
 int svoxt_render_depth(const svoxt_tree* tree, const svoxt_rays* rays,

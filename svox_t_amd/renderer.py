@@ -165,7 +165,10 @@ class _OpacityRenderFunction(autograd.Function):
 
     @staticmethod
     def forward(ctx, data, tree, rays, opt):
-        out = _C.opacity_render(tree, rays, opt)
+        if ctx.needs_input_grad[0]:
+            out, ctx.lists = _C.opacity_render(tree, rays, opt, record=True)
+        else:
+            out, ctx.lists = _C.opacity_render(tree, rays, opt), None
         ctx.tree = tree
         ctx.rays = rays
         ctx.opt = opt
@@ -174,8 +177,8 @@ class _OpacityRenderFunction(autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         if ctx.needs_input_grad[0]:
-            return _C.opacity_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out.contiguous()), \
-                None, None, None
+            return _C.opacity_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out.contiguous(),
+                                              lists=ctx.lists), None, None, None
         return None, None, None, None
 
 

@@ -85,6 +85,33 @@ def test_opacity_backward(case, gpu):
     assert np.all(got[:, :-1] == 0)          # only the sigma column receives gradient
 
 
+@pytest.mark.parametrize("list_samples", [0, 1, 3, 64])
+@pytest.mark.parametrize("tiled", [False, True])
+def test_opacity_backward_from_sample_lists(gpu, list_samples, tiled, monkeypatch):
+    """opacity_render records sample lists when a backward will follow; the backward walks
+    them and sums per tile (rays with more samples than the list holds march their tail).
+    Any capacity, tiled or not, gives the reference's gradient; the forward stays bit-exact;
+    a second backward over the same graph (lists already rewritten) marches instead."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd import synth
+    monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", list_samples)
+    c = Case(depth=6, K=28, data_format="SH9", width=96, height=96)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    g = synth.grad_output(c.Q, 1, seed=5)
+    out = r.opacity_render(tree.features, c.rays_gpu(gpu), image_shape=(96, 96) if tiled else None)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(),
+                                  O.opacity_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts()))
+    want, abs_sum = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.numpy(),
+                                             want_abs=True)
+    for _ in range(2):
+        tree.features.grad = None
+        out.backward(g.to(gpu), retain_graph=True)
+        got = tree.features.grad.cpu().numpy()
+        assert_grads_close(got, want, abs_sum)
+        assert np.all(got[:, :-1] == 0)
+
+
 def test_counters_match_oracle(case, gpu):
     """The march is bit-identical, so the step / level / sample counts are."""
     import svox_t_amd.csrc as _C
