@@ -346,12 +346,19 @@ __device__ __forceinline__ void march_step(const TreeDev& tr, const Ray& r, floa
     const float px = r.ox + t * r.dx;
     const float py = r.oy + t * r.dy;
     const float pz = r.oz + t * r.dz;
+    // Locals, assigned to `s` once after the branches join: with the two branches storing
+    // straight into different members of `s`, the compiler merges the stores into one through
+    // a pointer phi, which pins slot and idx in scratch memory (a scratch round trip per step).
+    Leaf lf;
+    int32_t idx;
     if (N2 && tr.accel != nullptr) {
-        locate_accel(tr, px, py, pz, s.leaf, s.idx);   // leaf.slot / leaf.levels are not reference-accurate here
+        locate_accel(tr, px, py, pz, lf, idx);   // leaf.slot / leaf.levels are not reference-accurate here
     } else {
-        locate<N2>(tr, px, py, pz, s.leaf);
-        s.idx = tr.data[s.leaf.slot];
+        locate<N2>(tr, px, py, pz, lf);
+        idx = tr.data[lf.slot];
     }
+    s.leaf = lf;
+    s.idx = idx;
     // `*data_idx_ptr >= features.size(0)` compares int32 with int64 (:269); a
     // negative index is therefore "valid" for the reference (and reads out of
     // bounds).  Treat it as empty instead of faulting.
