@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
     // optional: the acceleration grid (a cache of the descent; results do not depend on it)
     const int g = 5;
     void* cells = nullptr;
-    HIP_OK(hipMalloc(&cells, svoxt_accel_bytes(g)));
+    HIP_OK(hipMalloc(&cells, svoxt_accel_bytes(g, tree.n_internal)));
     SVOXT_OK_(svoxt_accel_build(&tree, g, cells, st));
     tree.accel = cells; tree.accel_log2 = g;
 

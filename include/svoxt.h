@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 8
+#define SVOXT_ABI_VERSION 9
 
 enum {
     SVOXT_OK = 0,
@@ -270,10 +270,13 @@ int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
  * that caches, per cell, where the root->leaf descent of common.cuh:63-100
  * stands after g levels (the leaf and its data word if it ended earlier), so a
  * march step costs one 8-byte load plus the levels below g instead of a
- * dependent load per level.  svoxt_accel_bytes returns the buffer size for a
- * resolution (8 bytes per cell), -1 if log2_res is outside [1, 8];
- * svoxt_accel_build fills `cells` from tree->child / tree->data. */
-int64_t svoxt_accel_bytes(int32_t log2_res);
+ * dependent load per level.  Behind the cells the buffer holds one (child word,
+ * data word) pair per tree slot, so that the levels below g cost one 8-byte load
+ * each and the leaf's data word none.  svoxt_accel_bytes returns the buffer size
+ * for a resolution and a tree (8 bytes per cell + 64 bytes per internal node), -1
+ * if log2_res is outside [1, 8]; svoxt_accel_build fills `cells` from
+ * tree->child / tree->data. */
+int64_t svoxt_accel_bytes(int32_t log2_res, int64_t n_internal);
 int     svoxt_accel_build(const svoxt_tree* tree, int32_t log2_res, void* cells, void* stream);
 
 /* ---- Octree construction from a point cloud -------------

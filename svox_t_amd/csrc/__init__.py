@@ -43,7 +43,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -117,7 +117,7 @@ EXPORTS = {
     "svoxt_query_fwd": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "svoxt_query_bwd": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp, _vp, _vp]),
     "svoxt_count_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
-    "svoxt_accel_bytes": (ctypes.c_int64, [_i32]),
+    "svoxt_accel_bytes": (ctypes.c_int64, [_i32, ctypes.c_int64]),
     "svoxt_accel_build": (ctypes.c_int, [_P(_CTree), _i32, _vp, _vp]),
     "svoxt_build_workspace_bytes": (ctypes.c_int64, [_i32]),
     "svoxt_build_count": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp]),
@@ -319,8 +319,8 @@ def _accel_for(tree: TreeSpec, ct: _CTree):
             return cells, g
     dev = tree.child.device
     with torch.cuda.device(dev):
-        cells = torch.empty((1 << (3 * g), 2), dtype=torch.int32, device=dev)
-        assert cells.numel() * 4 == _lib.svoxt_accel_bytes(g)
+        nbytes = _lib.svoxt_accel_bytes(g, ct.n_internal)       # grid cells + (child, data) pairs
+        cells = torch.empty((nbytes // 8, 2), dtype=torch.int32, device=dev)
         _call("svoxt_accel_build", ctypes.byref(ct), g, _ptr(cells), _stream(dev))
     _ACCEL_CACHE[key] = (weakref.ref(tree.child, lambda _r, _k=key: _ACCEL_CACHE.pop(_k, None)),
                          tree.child._version, weakref.ref(tree.data), tree.data._version,

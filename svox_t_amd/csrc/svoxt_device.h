@@ -279,8 +279,10 @@ __device__ __forceinline__ void locate(const TreeDev& tr, float px, float py, fl
 //   .y bit 31 set : the descent ended in a leaf at depth (.y & 0xff) <= G whose
 //                   data word (feature row index) is .x
 //   .y bit 31 clear: the descent is at internal node .x after G levels
-// Built by accel_build_kernel from child/data; the march then needs one 8-byte
-// load instead of up to G dependent 4-byte loads (plus the data word) per step.
+// The 2^(3G) cells are followed by one (child word, data word) pair per tree slot.
+// Built by accel_build_kernel / accel_nodes_kernel from child/data; the march then needs
+// one 8-byte load instead of up to G dependent 4-byte loads per step, plus one 8-byte load
+// per level below the grid (none for the data word).
 constexpr uint32_t kAccelLeaf = 0x80000000u;
 
 __device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float py, float pz,
@@ -302,15 +304,20 @@ __device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float 
         k = (int)(cell.y & 0xffu);
         idx = (int32_t)cell.x;
     } else {
+        // below the grid: (child word, data word) pairs, so that reaching a leaf costs no
+        // further dependent load for its data word
+        const uint2* __restrict__ nodes = tr.accel + ((size_t)1 << (3 * G));
         int32_t node = (int32_t)cell.x;
         int32_t skip;
+        uint2 cd;
         k = G + 1;
 #pragma unroll 1
         for (;; ++k) {
             const int sh = kFixBits - k;
             const uint32_t c3 = (((ux >> sh) & 1u) << 2) | (((uy >> sh) & 1u) << 1) | ((uz >> sh) & 1u);
             slot = ((uint32_t)node << 3) + c3;
-            skip = tr.child[slot];
+            cd = nodes[slot];
+            skip = (int32_t)cd.x;
             if (skip == 0 || k == kFixBits) break;
             node += skip;
         }
@@ -322,7 +329,7 @@ __device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float 
             idx = tr.data[lf.slot];
             return;
         }
-        idx = tr.data[slot];
+        idx = (int32_t)cd.y;
     }
     const float sc = __int_as_float((127 + k) << 23);   // 2^k
     const float fx = px * sc, fy = py * sc, fz = pz * sc;

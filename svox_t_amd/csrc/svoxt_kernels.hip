@@ -21,7 +21,7 @@
 //   opacity_fwd_kernel (+ opacity_walk_kernel, opacity_merge_kernel: backward from lists),
 //   depth_kernel, count_fwd_kernel
 //   query_fwd_kernel, query_bwd_kernel, leaves_count / scan / scatter kernels
-//   compact_rows_kernel, accel_build_kernel
+//   compact_rows_kernel, accel_build_kernel, accel_nodes_kernel
 // Other translation units of the library: svoxt_build.hip (octree from a point
 // cloud, construct_tree), svoxt_motion.hip (motion variants, point skinning).
 // The design rationale and the measurements behind each choice are in DESIGN.md 5.
@@ -1488,6 +1488,14 @@ accel_build_kernel(TreeDev tr, int G, uint2* __restrict__ cells) {
     cells[c] = make_uint2((uint32_t)node, 0u);
 }
 
+// ... and the (child, data) pairs the descent below the grid reads
+__global__ void __launch_bounds__(kBlock)
+accel_nodes_kernel(const int32_t* __restrict__ child, const int32_t* __restrict__ data, int64_t n,
+                   uint2* __restrict__ nodes) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) nodes[i] = make_uint2((uint32_t)child[i], (uint32_t)data[i]);
+}
+
 }  // namespace svoxt
 
 // ===========================================================================
@@ -2166,9 +2174,9 @@ int svoxt_compact_rows(const float* src, int64_t M, int32_t K, int32_t stride, f
     return check_launch(fn);
 }
 
-int64_t svoxt_accel_bytes(int32_t log2_res) {
-    if (log2_res < 1 || log2_res > 8) return -1;
-    return (int64_t)sizeof(uint2) << (3 * log2_res);
+int64_t svoxt_accel_bytes(int32_t log2_res, int64_t n_internal) {
+    if (log2_res < 1 || log2_res > 8 || n_internal < 0) return -1;
+    return ((int64_t)sizeof(uint2) << (3 * log2_res)) + (int64_t)sizeof(uint2) * 8 * n_internal;
 }
 
 int svoxt_accel_build(const svoxt_tree* tree, int32_t log2_res, void* cells, void* stream) {
@@ -2183,6 +2191,10 @@ int svoxt_accel_build(const svoxt_tree* tree, int32_t log2_res, void* cells, voi
     const unsigned n = 1u << (3 * log2_res);
     hipLaunchKernelGGL(accel_build_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0,
                        (hipStream_t)stream, tr, (int)log2_res, reinterpret_cast<uint2*>(cells));
+    const int64_t slots = tree->n_internal * 8;
+    if (slots > 0)
+        hipLaunchKernelGGL(accel_nodes_kernel, dim3((unsigned)((slots + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           (hipStream_t)stream, tr.child, tr.data, slots, reinterpret_cast<uint2*>(cells) + n);
     return check_launch(fn);
 }
 
