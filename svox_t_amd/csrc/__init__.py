@@ -415,7 +415,7 @@ def get_out_data_dim(opt: RenderOptions, K: int) -> int:
 # Samples kept per ray for the backward (8 bytes each; rays with more composited
 # samples march the remainder, so this only trades memory for speed).
 # 0 = never record: the backward then traverses the tree itself.
-BWD_LIST_SAMPLES = int(os.environ.get("SVOXT_BWD_LIST", "64"))
+BWD_LIST_SAMPLES = int(os.environ.get("SVOXT_BWD_LIST", "96"))
 
 
 class SampleLists:

@@ -630,9 +630,7 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
     constexpr int NT = 64 * W;
     static_assert(K <= 32 && (T & (T - 1)) == 0 && T >= 128 && T <= 1024 && R >= 128 && R <= 1024 && T * 64 <= 65536, "sizes");
     __shared__ int32_t keys[T];
-    __shared__ int32_t cnt[T];
-    __shared__ int32_t start[T];
-    __shared__ int32_t fill[T];
+    __shared__ int32_t cnt[T];                   // records per slot; after the scan: where the slot's next record goes
     __shared__ uint16_t order[R];
     __shared__ uint16_t r_sl[R];                 // slot << 6 | lane
     __shared__ float r_sg[R], r_w[R], r_c[3 * R];
@@ -667,7 +665,7 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
 #pragma unroll
         for (int c = 0; c < C; ++c) gl[lane * 3 + c] = grad_out[q * (C + 1) + c];
     }
-    for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; fill[i] = 0; }
+    for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
     if (threadIdx.x == 0) s_nb = 0;
     __syncthreads();
 
@@ -754,12 +752,12 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
             }
             int run = incl - sum;
 #pragma unroll
-            for (int j2 = 0; j2 < PER; ++j2) { start[lane * PER + j2] = run; run += mine[j2]; }
+            for (int j2 = 0; j2 < PER; ++j2) { cnt[lane * PER + j2] = run; run += mine[j2]; }
         }
         __syncthreads();
         for (int rr = threadIdx.x; rr < nb; rr += NT) {
             const int sl = (int)r_sl[rr] >> 6;
-            const int pos = start[sl] + atomicAdd(fill + sl, 1);
+            const int pos = atomicAdd(cnt + sl, 1);
             order[pos] = (uint16_t)rr;
         }
         __syncthreads();
@@ -836,7 +834,7 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
         }
         if (k0 + RPP * kRound >= maxn) break;            // last pass (scalar condition)
         __syncthreads();
-        for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; fill[i] = 0; }
+        for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
         if (threadIdx.x == 0) s_nb = 0;
         __syncthreads();
     }
