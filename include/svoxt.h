@@ -19,6 +19,7 @@
  * Entry points without a counterpart in the reference, all optional and
  * result-neutral (a caller that ignores them gets the same numbers, slower):
  *   svoxt_accel_build / svoxt_accel_bytes            cached prefix of the root descent
+ *   svoxt_ray_order                                  coherent order for ray batches that are not images
  *   svoxt_volume_render_fwd_record / _bwd_replay     backward without tree traversal
  *   svoxt_can_record, svoxt_bwd_workspace_bytes, svoxt_compact_rows, svoxt_count_fwd,
  *   svoxt_query_leaves (the reference's mask compaction, made deterministic)
@@ -278,6 +279,20 @@ int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
  * tree->child / tree->data. */
 int64_t svoxt_accel_bytes(int32_t log2_res, int64_t n_internal);
 int     svoxt_accel_build(const svoxt_tree* tree, int32_t log2_res, void* cells, void* stream);
+
+/* Ray ordering for batches that are not images (no counterpart in the reference).  The
+ * marching kernels put 64 consecutive rays on one wavefront; a batch in arbitrary order
+ * (rays drawn at random from many cameras) then diverges at every step.  svoxt_ray_order
+ * writes to perm [Q] (device, int32) the permutation that sorts the batch by the Morton
+ * code of the point where each ray enters the tree's cube (rays that miss it last): gather
+ * origins / dirs / vdirs with it, render the sorted batch through any entry point above and
+ * scatter the output rows back -- results are per ray and do not depend on the order.
+ * workspace: device, svoxt_ray_order_workspace_bytes(Q) bytes (-1: Q out of range or no
+ * device).  Batches declared as images (image_width > 0, camera mode) are refused: they are
+ * walked in 8x8 tiles already. */
+int64_t svoxt_ray_order_workspace_bytes(int64_t Q);
+int     svoxt_ray_order(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
+                        int32_t* perm, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- Octree construction from a point cloud -------------
  *

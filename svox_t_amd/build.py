@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_NAME = "libsvoxt_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ["svoxt_kernels.hip", "svoxt_build.hip", "svoxt_motion.hip"]
+SOURCES = ["svoxt_kernels.hip", "svoxt_build.hip", "svoxt_motion.hip", "svoxt_order.hip"]
 HEADERS = ["svoxt_device.h", "svoxt_host.h", os.path.join("..", "..", "include", "svoxt.h")]
 
 # -ffp-contract=off is part of the numerical contract (svoxt_device.h): the

@@ -117,6 +117,8 @@ EXPORTS = {
     "svoxt_query_fwd": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "svoxt_query_bwd": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp, _vp, _vp]),
     "svoxt_count_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
+    "svoxt_ray_order_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64]),
+    "svoxt_ray_order": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, ctypes.c_int64, _vp]),
     "svoxt_accel_bytes": (ctypes.c_int64, [_i32, ctypes.c_int64]),
     "svoxt_accel_build": (ctypes.c_int, [_P(_CTree), _i32, _vp, _vp]),
     "svoxt_build_workspace_bytes": (ctypes.c_int64, [_i32]),
@@ -153,6 +155,10 @@ class RaysSpec:
         # size; the kernels then walk it in 8x8 tiles.  0 = unknown.
         self.image_width = 0
         self.image_height = 0
+        # optional (not in the reference): ask the renderer to sort the batch (svoxt_ray_order) /
+        # the batch is in such an order
+        self.sort = False
+        self.coherent = False
 
 
 class TreeSpec:
@@ -443,6 +449,23 @@ def can_record(tree: TreeSpec, opt: RenderOptions) -> bool:
     return bool(_lib.svoxt_can_record(ctypes.byref(ct), ctypes.byref(co)))
 
 
+def ray_order(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
+    """Permutation (int64 [Q], for torch indexing) that sorts a ray batch by the Morton code of
+    each ray's entry point into the tree's cube (include/svoxt.h, svoxt_ray_order): 64
+    consecutive rays of the sorted batch cross the same leaves.  Not in the reference."""
+    ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
+    dev = tree.features.device
+    with torch.cuda.device(dev):
+        perm = torch.empty((cr.Q,), dtype=torch.int32, device=dev)
+        nbytes = _lib.svoxt_ray_order_workspace_bytes(cr.Q)
+        if nbytes < 0:
+            raise RuntimeError("svoxt_ray_order_workspace_bytes failed")
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+        _call("svoxt_ray_order", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co), _ptr(perm), _ptr(ws),
+              nbytes, _stream(dev))
+    return perm.long()
+
+
 def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bool = False):
     """rt_kernel.cu:1362-1379.
 
@@ -500,8 +523,9 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
     # i.e. for image batches walked in 8x8 tiles (0.94 -> 0.54 ms on the headline workload);
     # on shuffled rays it loses to the one-kernel backward (2.4 vs 1.65 ms)
     tiled = cr.image_width > 0 and cr.image_width % 8 == 0 and cr.image_height % 8 == 0
+    coherent = tiled or bool(getattr(rays, "coherent", False))      # or sorted by svoxt_ray_order
     gather = lists is not None and K <= 32 and grad_output.shape[1] == 4 and ct.N == 2 and \
-        (BWD_GATHER == 2 or (BWD_GATHER == 1 and tiled))
+        (BWD_GATHER == 2 or (BWD_GATHER == 1 and coherent))
     if gather:
         stride = K                # ~5x fewer row updates: aligned rows no longer pay for the extra copy
     with torch.cuda.device(dev):

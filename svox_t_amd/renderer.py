@@ -15,6 +15,8 @@ from __future__ import annotations
 from collections import namedtuple
 from warnings import warn
 
+import os
+
 import torch
 from torch import autograd, nn
 
@@ -26,14 +28,46 @@ Rays = namedtuple("Rays", ["origins", "dirs", "viewdirs"])
 _C = _get_c_extension()
 
 
-def _rays_spec_from_rays(rays, image_shape=None):
+# sort_rays=True (or SVOXT_SORT_RAYS=1 for every batch that is not declared an image): render
+# the batch in a coherent order (svoxt_ray_order, include/svoxt.h).  Off by default: the sort,
+# three gathers and a scatter cost ~0.3 ms per 640 000 rays, which rays shuffled within one
+# camera earn back (forward+backward 1.47 -> 1.11 ms) and rays drawn from many cameras do not.
+SORT_RAYS = os.environ.get("SVOXT_SORT_RAYS", "0")
+
+
+def _rays_spec_from_rays(rays, image_shape=None, sort_rays=None):
     spec = _C.RaysSpec()
     spec.origins = rays.origins
     spec.dirs = rays.dirs
     spec.vdirs = rays.viewdirs
     if image_shape is not None:
         spec.image_height, spec.image_width = int(image_shape[0]), int(image_shape[1])
+    if sort_rays is None:
+        sort_rays = SORT_RAYS == "1"
+    spec.sort = bool(sort_rays) and image_shape is None
     return spec
+
+
+def _in_coherent_order(tree, rays, opt):
+    """(rays spec to render, perm): the batch gathered into svoxt_ray_order's order when its
+    spec asks for that (perm: sorted position -> position in the caller's batch), else as is."""
+    if not getattr(rays, "sort", False) or rays.origins.shape[0] == 0:
+        return rays, None
+    perm = _C.ray_order(tree, rays, opt)
+    s = _C.RaysSpec()
+    s.origins = rays.origins.index_select(0, perm)
+    s.dirs = rays.dirs.index_select(0, perm)
+    s.vdirs = rays.vdirs.index_select(0, perm)
+    s.coherent = True           # neighbouring rays revisit the same leaves: the two-kernel backward pays
+    return s, perm
+
+
+def _to_caller_order(out_sorted, perm):
+    if perm is None:
+        return out_sorted
+    out = torch.empty_like(out_sorted)
+    out[perm] = out_sorted
+    return out
 
 
 def _make_camera_spec(c2w, width, height, fx, fy):
@@ -93,6 +127,8 @@ class _VolumeRenderFunction(autograd.Function):
 
     @staticmethod
     def forward(ctx, data, tree, rays, opt):
+        # A batch that is not an image is rendered in a coherent order (results are per ray)
+        rays, ctx.perm = _in_coherent_order(tree, rays, opt)
         # When a backward will follow, the forward also records which samples
         # each ray composited so that the backward need not traverse the tree.
         if ctx.needs_input_grad[0]:
@@ -104,13 +140,14 @@ class _VolumeRenderFunction(autograd.Function):
         ctx.opt = opt
         if ctx.lists is not None:
             ctx.save_for_backward(out)      # with the lists it spares the backward its first pass
-        return out
+        return _to_caller_order(out, ctx.perm)
 
     @staticmethod
     def backward(ctx, grad_out):
         if ctx.needs_input_grad[0]:
             fwd_out = ctx.saved_tensors[0] if ctx.lists is not None else None
-            return _C.volume_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out.contiguous(),
+            grad_out = grad_out.contiguous() if ctx.perm is None else grad_out.index_select(0, ctx.perm)
+            return _C.volume_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out,
                                              lists=ctx.lists, fwd_output=fwd_out), None, None, None
         return None, None, None, None
 
@@ -165,6 +202,7 @@ class _OpacityRenderFunction(autograd.Function):
 
     @staticmethod
     def forward(ctx, data, tree, rays, opt):
+        rays, ctx.perm = _in_coherent_order(tree, rays, opt)
         if ctx.needs_input_grad[0]:
             out, ctx.lists = _C.opacity_render(tree, rays, opt, record=True)
         else:
@@ -172,12 +210,13 @@ class _OpacityRenderFunction(autograd.Function):
         ctx.tree = tree
         ctx.rays = rays
         ctx.opt = opt
-        return out
+        return _to_caller_order(out, ctx.perm)
 
     @staticmethod
     def backward(ctx, grad_out):
         if ctx.needs_input_grad[0]:
-            return _C.opacity_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out.contiguous(),
+            grad_out = grad_out.contiguous() if ctx.perm is None else grad_out.index_select(0, ctx.perm)
+            return _C.opacity_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out,
                                               lists=ctx.lists), None, None, None
         return None, None, None, None
 
@@ -217,7 +256,7 @@ class VolumeRenderer(nn.Module):
                                "(the reference asserts on its non-CUDA branch too)")
 
     def forward(self, features, rays: Rays, transformation_matrices=None, cuda=True, fast=False,
-                image_shape=None):
+                image_shape=None, sort_rays=None):
         """Render a ray batch; differentiable wrt `features`.
 
         :param features: float32 [M, data_dim] leaf feature table (on the GPU)
@@ -226,13 +265,18 @@ class VolumeRenderer(nn.Module):
         :param image_shape: optional (H, W) (not in the reference): states that the
                rays are the row-major pixels of an H x W image, which lets the kernels
                walk them in 8x8 tiles; results are unchanged
+        :param sort_rays: (not in the reference) render a batch that is not an image in the
+               order of its rays' entry points into the tree's cube, so that the 64 rays of
+               a wavefront cross the same leaves; every ray's result is unchanged and comes
+               back at the ray's own position.  Pays for rays shuffled within few cameras
+               (see SORT_RAYS above); None: SVOXT_SORT_RAYS (default off)
         :return: [Q, C+1]: C colour/feature channels then accumulated alpha
         """
         self._require_gpu(cuda, "forward")
         return _VolumeRenderFunction.apply(
             features,
             self.tree._spec(features, transformation_matrices=transformation_matrices),
-            _rays_spec_from_rays(rays, image_shape),
+            _rays_spec_from_rays(rays, image_shape, sort_rays),
             self._get_options(fast))
 
     def render_persp(self, features, c2w, width=800, height=800, fx=1111.111, fy=None,
@@ -284,11 +328,11 @@ class VolumeRenderer(nn.Module):
         return _C.render_depth(self.tree._spec(features), _rays_spec_from_rays(rays, image_shape),
                                self._get_options(fast))
 
-    def opacity_render(self, features, rays: Rays, cuda=True, fast=False, image_shape=None):
-        """[Q, 1] accumulated alpha only; differentiable wrt `features`."""
+    def opacity_render(self, features, rays: Rays, cuda=True, fast=False, image_shape=None, sort_rays=None):
+        """[Q, 1] accumulated alpha only; differentiable wrt `features` (sort_rays: see forward)."""
         self._require_gpu(cuda, "opacity_render")
         return _OpacityRenderFunction.apply(
-            features, self.tree._spec(features), _rays_spec_from_rays(rays, image_shape),
+            features, self.tree._spec(features), _rays_spec_from_rays(rays, image_shape, sort_rays),
             self._get_options(fast))
 
     def _get_options(self, fast=False):
