@@ -51,7 +51,8 @@ open(tmp, "w").write(src)
 out = os.path.join(ROOT, "exp", "libsvoxt_trace.so")
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
        "-fno-fast-math", "-Wno-unused-function", "-Wno-unused-value", "-o", out, tmp,
-       os.path.join(CSRC, "svoxt_build.hip"), os.path.join(CSRC, "svoxt_motion.hip")]
+       os.path.join(CSRC, "svoxt_build.hip"), os.path.join(CSRC, "svoxt_motion.hip"),
+       os.path.join(CSRC, "svoxt_order.hip")]
 try:
     subprocess.check_call(cmd)
 finally:
