@@ -498,6 +498,7 @@ BWD_EXACT = os.environ.get("SVOXT_BWD_EXACT", "0") not in ("", "0")
 # shaped atomics); 1 (default): the two-kernel one (list walk -> factored records -> per-tile
 # merge in LDS -> one atomic row per tile and feature row, include/svoxt.h
 # svoxt_sample_lists.coef) for batches declared as images; 2: whenever the payload allows
+GATHER_ALIGNED = os.environ.get("SVOXT_GATHER_ALIGNED", "1") not in ("", "0")   # 64-byte-aligned rows for the merge kernel too
 BWD_GATHER = int(os.environ.get("SVOXT_BWD_GATHER", "1") or 0)     # 0 never, 1 for image batches, 2 whenever possible
 
 
@@ -526,8 +527,8 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
     coherent = tiled or bool(getattr(rays, "coherent", False))      # or sorted by svoxt_ray_order
     gather = lists is not None and K <= 32 and grad_output.shape[1] == 4 and ct.N == 2 and \
         (BWD_GATHER == 2 or (BWD_GATHER == 1 and coherent))
-    if gather:
-        stride = K                # ~5x fewer row updates: aligned rows no longer pay for the extra copy
+    if gather and not GATHER_ALIGNED:
+        stride = K
     with torch.cuda.device(dev):
         buf = torch.empty((M, stride), dtype=torch.float32, device=dev)
         if lists is not None:

@@ -763,8 +763,8 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
         __syncthreads();
         // ---- reduce: 64 sorted records at a time per wavefront.  lane = record expands it into
         // its K gradient values (staged in LDS); then four groups of 16 lanes each walk 16 staged
-        // rows, a lane owning two columns (sub and sub + HALF), and send a sum out whenever the
-        // feature row changes: a row leaves as two atomic instructions of HALF floats.
+        // rows, a lane owning two columns (sub and sub + 16), and send a sum out whenever the
+        // feature row changes: a row leaves as two atomic instructions (columns 0-15, 16-K).
         for (int base = wave * 64; base < nb; base += NT) {
             const int p = base + lane;
             int my_sl = -1;
@@ -796,7 +796,10 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
             seg[lane] = my_sl >= 0 ? keys[my_sl] : -1;          // the feature row staged row `lane` belongs to
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            constexpr int HALF = (K + 1) / 2;
+            // columns 0-15 and 16-K: with rows that start on 128-byte boundaries (grad_stride 32
+            // for K = 28) each of the two atomic instructions of a row touches one 64-byte line --
+            // the kernel runs at the rate at which the memory side takes such requests
+            constexpr int HALF = K < 16 ? K : 16;
             const int grp = lane >> 4, sub = lane & 15;
             const bool has0 = sub < HALF, has1 = sub + HALF < K;
             int cur = -1;
