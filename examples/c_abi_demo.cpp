@@ -82,6 +82,11 @@ int main(int argc, char** argv) {
     HIP_OK(hipMalloc(&d_out, sizeof(float) * Q * cols));
     HIP_OK(hipMalloc(&d_depth, sizeof(float) * Q));
     HIP_OK(hipMalloc(&d_grad, sizeof(float) * M * K));
+    // the backward accumulates into rows that start on 64-byte boundaries (every atomic
+    // instruction then touches one line); svoxt_compact_rows gives the dense [M, K] back
+    const int32_t gs = (K <= 8 || K % 16 == 0) ? (int32_t)K : (int32_t)((K + 15) / 16 * 16);
+    float* d_grad_rows = nullptr;
+    HIP_OK(hipMalloc(&d_grad_rows, sizeof(float) * M * gs));
 
     // forward that records sample lists, backward that replays them (two-kernel route when
     // a coef buffer is given and the payload allows; the library ignores it otherwise)
@@ -93,11 +98,12 @@ int main(int argc, char** argv) {
     HIP_OK(hipMalloc(&lists.coef, (size_t)lists.coef_bytes));
     if (svoxt_can_record(&tree, &opt)) {
         SVOXT_OK_(svoxt_volume_render_fwd_record(&tree, &rays, &opt, d_out, &lists, st));
-        SVOXT_OK_(svoxt_volume_render_bwd_replay(&tree, &rays, &opt, d_gout, cols, d_grad, 0, &lists, d_out, st));
+        SVOXT_OK_(svoxt_volume_render_bwd_replay(&tree, &rays, &opt, d_gout, cols, d_grad_rows, gs, &lists, d_out, st));
     } else {
         SVOXT_OK_(svoxt_volume_render_fwd(&tree, &rays, &opt, d_out, st));
-        SVOXT_OK_(svoxt_volume_render_bwd(&tree, &rays, &opt, d_gout, cols, d_grad, 0, nullptr, 0, st));
+        SVOXT_OK_(svoxt_volume_render_bwd(&tree, &rays, &opt, d_gout, cols, d_grad_rows, gs, nullptr, 0, st));
     }
+    SVOXT_OK_(svoxt_compact_rows(d_grad_rows, M, (int32_t)K, gs, d_grad, st));
     SVOXT_OK_(svoxt_render_depth(&tree, &rays, &opt, d_depth, st));
     HIP_OK(hipStreamSynchronize(st));
 

@@ -145,9 +145,12 @@ int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
  *           float atomics (as the reference: zeros_like + atomicAdd,
  *           rt_kernel.cu:1415,413,486).  grad_stride = 0 or K is the
  *           reference's dense [M, K]; a stride that makes rows start on 64-byte
- *           boundaries (e.g. 32 for K = 28) lets each row's atomics hit two
- *           memory-side requests instead of 2.75 on average (measured: the
- *           atomic-bound part of the backward is 19 % faster).
+ *           boundaries (e.g. 32 for K = 28: rows of 128 bytes) lets each row's
+ *           atomics hit two memory-side requests (the rate those are taken at is
+ *           what bounds the backward): 2 instead of 2.75 on average for the
+ *           one-kernel backward, 2 instead of 3.7 for the two-kernel one (its second
+ *           kernel 0.30 -> 0.20 ms); svoxt_compact_rows turns the result into the
+ *           dense table (0.03 ms for 75 MB).
  * workspace: device scratch of `workspace_bytes` bytes, or NULL.  With
  *           svoxt_bwd_workspace_bytes(Q, S) bytes the first pass records up to
  *           S composited samples per ray (8 bytes each) and the second pass
