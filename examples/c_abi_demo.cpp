@@ -91,7 +91,7 @@ int main(int argc, char** argv) {
     // forward that records sample lists, backward that replays them (two-kernel route when
     // a coef buffer is given and the payload allows; the library ignores it otherwise)
     svoxt_sample_lists lists = {};
-    lists.max_samples = 64;
+    lists.max_samples = 96;
     lists.coef_bytes = (int64_t)lists.max_samples * Q * 16;
     HIP_OK(hipMalloc(&lists.rec, (size_t)lists.max_samples * Q * 8));
     HIP_OK(hipMalloc(&lists.aux, (size_t)Q * 16));
