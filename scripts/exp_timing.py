@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Ad-hoc kernel timing on the headline workload (GPU box)."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import svox_t_amd as svox

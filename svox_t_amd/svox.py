@@ -14,12 +14,11 @@ Layout (identical to the reference so trees interchange):
 """
 from __future__ import annotations
 
-from typing import Optional
 
 import torch
 from torch import autograd, nn
 
-from svox_t_amd.helpers import DataFormat, LocalIndex, N3TreeView, _get_c_extension
+from svox_t_amd.helpers import DataFormat, N3TreeView, _get_c_extension
 
 _C = _get_c_extension()
 

@@ -11,7 +11,6 @@ import pytest
 import torch
 
 import svox_t_amd as svox
-import svox_t_amd.csrc as _C
 from oracle import builder as ob
 
 pytestmark = pytest.mark.gpu

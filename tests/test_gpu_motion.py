@@ -7,7 +7,6 @@ import pytest
 import torch
 
 import svox_t_amd as svox
-import svox_t_amd.csrc as _C
 from oracle import oracle as O
 from svox_t_amd import synth
 from tests.util import Case, assert_grads_close

@@ -3,7 +3,6 @@ CPU oracle (numpy) and through the HIP path (torch tensors on the GPU)."""
 from __future__ import annotations
 
 import numpy as np
-import torch
 
 import svox_t_amd as svox
 from oracle import oracle as O
