@@ -401,6 +401,12 @@ __device__ __forceinline__ void march_step(const TreeDev& tr, const Ray& r, floa
 // rather than to within "some ulps of some libm".  Accuracy ~1 ulp (the
 // reference's CUDA expf is specified to 2 ulp).  Results below 2^-126
 // (x < -87) are returned as 0, above FLT_MAX as +inf.
+// PIN: keep the polynomial evaluation unconditional.  Left alone, the compiler sinks it under
+// the selects at the end as a branch; the basic-block boundaries then stop the scheduler from
+// overlapping the independent exponentials and double-precision sigmoids of one sample (a
+// wavefront alone on its SIMD -- the tail of the list walk -- retires one dependent
+// instruction every ~11 clocks).  Costs registers, so only where a kernel's tail pays for it.
+template <bool PIN = false>
 __device__ __forceinline__ float pexpf(float x) {
     // Branch-free: evaluate on a clamped argument, then select the special
     // cases (identical results to the early-return form in oracle/).
@@ -420,6 +426,7 @@ __device__ __forceinline__ float pexpf(float x) {
     const int n1 = ni >> 1, n2 = ni - n1;
     y = y * __int_as_float((n1 + 127) << 23);
     y = y * __int_as_float((n2 + 127) << 23);
+    if constexpr (PIN) asm volatile("" : "+v"(y));
     y = (x > 88.72283905206835f) ? __int_as_float(0x7f800000) : y;
     y = (x < -87.0f) ? 0.0f : y;
     return (x != x) ? x : y;
@@ -547,8 +554,9 @@ __device__ __forceinline__ void rotated_sh_basis(const TreeDev& tr, int32_t idx,
 
 // The reference's `w / (1.0 + expf(-x))` family is evaluated in double
 // (rt_kernel.cu:300,304,408,420,472,476).
+template <bool PIN = false>
 __device__ __forceinline__ double sigmoid_d(float x) {
-    return 1.0 / (1.0 + (double)pexpf(-x));
+    return 1.0 / (1.0 + (double)pexpf<PIN>(-x));
 }
 
 // Feature row -> registers.  16-byte loads when the row stride allows it

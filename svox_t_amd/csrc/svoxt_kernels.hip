@@ -345,13 +345,13 @@ __device__ __forceinline__ void accum_sample(const float (&row)[K], const float*
 // A sample's contribution in factored form, for the two-kernel backward: the colour
 // entry (c, i) is ((weight * basis_i) * coef_c) * g_c with coef_c = sigmoid'(.) for SH,
 // or coef_c itself for RGBA; `sg` is the sigma entry.  Same operations as stage_sample.
-template <int FMT, int C, int BD, int K, bool XF = false>
+template <int FMT, int C, int BD, int K, bool XF = false, bool ILP = false>
 __device__ __forceinline__ void coef_sample(const float (&row)[K], const float* basis, const float* g,
                                             float delta_t, float delta_scale, float light_ray,
                                             float& light, float& accum, float& weight_out,
                                             float (&coef)[C], float& sg, const float* basis_sig = nullptr) {
     const float sigma = row[K - 1];
-    const float att = pexpf(-delta_t * sigma * delta_scale);
+    const float att = pexpf<ILP>(-delta_t * sigma * delta_scale);
     const float weight = light * (1.f - att);
     float total_color = 0.f;
     if constexpr (FMT == FMT_SH) {
@@ -360,14 +360,14 @@ __device__ __forceinline__ void coef_sample(const float (&row)[K], const float* 
             float tmp = 0.f;
 #pragma unroll
             for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
-            const double sd = sigmoid_d(tmp);
+            const double sd = sigmoid_d<ILP>(tmp);
             const float sig = (float)sd;
             coef[c] = (float)((double)sig * (1.0 - (double)sig));
             if constexpr (XF) {      // pass 2 of the reference evaluates total_color with the stale basis
                 float tmp2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < BD; ++i) tmp2 += basis_sig[i] * row[c * BD + i];
-                total_color = (float)((double)total_color + sigmoid_d(tmp2) * (double)g[c]);
+                total_color = (float)((double)total_color + sigmoid_d<ILP>(tmp2) * (double)g[c]);
             } else {
                 total_color = (float)((double)total_color + sd * (double)g[c]);
             }
@@ -375,7 +375,7 @@ __device__ __forceinline__ void coef_sample(const float (&row)[K], const float* 
     } else {
 #pragma unroll
         for (int j = 0; j < C; ++j) {
-            const double sd = sigmoid_d(row[j]);
+            const double sd = sigmoid_d<ILP>(row[j]);
             const float sig = (float)sd;
             coef[j] = weight * sig * (1.f - sig) * g[j];
             total_color = (float)((double)total_color + sd * (double)g[j]);
@@ -395,7 +395,7 @@ __device__ __forceinline__ void coef_sample(const float (&row)[K], const float* 
 // entry), coef[k][q] = (weight, c0, c1, c2) -- and grad_merge_kernel adds them up per
 // 8x8 tile.  Samples past the list (overflowed rays) still go out as shaped atomics.
 template <int FMT, int C, int BD, bool N2, bool REPLAY, bool XF = false, bool GATHER = false>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, (GATHER && !XF) ? 4 : 1)
 render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                   float* __restrict__ grad, int gstride, uint2* __restrict__ rec, int S,
                   const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
@@ -542,8 +542,8 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                     __builtin_nontemporal_store(v4f{rd[0], rd[1], rd[2], 0.f},
                                                 reinterpret_cast<v4f*>(coef_out + ((int64_t)(S + k) * rays.Q + q)));
                 } else {
-                    coef_sample<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, light_ray,
-                                               light, accum, w, cf, sg);
+                    coef_sample<FMT, C, BD, K, false, true>(row, basis, g, __uint_as_float(e.y), r.delta_scale,
+                                                            light_ray, light, accum, w, cf, sg);
                 }
                 rec_put(slot, e.x, sg);
                 __builtin_nontemporal_store(v4f{w, cf[0], cf[1], cf[2]},
