@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0
 # Memory-side traffic of the two hot kernels, from separate rocprofv3 --pmc passes
 # of this same command (scripts/pmc_passes.sh -> scripts/pmc_summary.py), committed
 # under profiles/.  FETCH_SIZE / WRITE_SIZE are KiB per dispatch.
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_q_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_r_pmc.json")
 
 
 def pmc_traffic(which):
