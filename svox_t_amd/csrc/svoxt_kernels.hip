@@ -1710,19 +1710,13 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
                        const float* fwd_out, float4* coef, bool xf, hipStream_t st) {
     if (C != 3) return false;
     const unsigned nb = nblocks(rays.Q);
-    static const int mw = [] { const char* e = getenv("SVOXT_MERGE_WAVES"); return e ? atoi(e) : 4; }();
+    // four wavefronts per tile and tables of 1024 (measured: one wavefront per tile 0.41 ms,
+    // two 0.33, four 0.30 before step 15; tables of 512 / 256 cost more passes than they buy)
 #define SVOXT_GATHER(F, BB)                                                                                   \
     hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
                        tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out, coef);                   \
-    if (mw == 4)                                                                                              \
-        hipLaunchKernelGGL((grad_merge_kernel<F, BB, 1024, 1024, 4>), dim3(nb), dim3(256), 0, st, tr, rays,  \
-                           grad_out, rec, coef, aux, grad, gstride);                                          \
-    else if (mw == 2)                                                                                         \
-        hipLaunchKernelGGL((grad_merge_kernel<F, BB, 512, 512, 2>), dim3(nb), dim3(128), 0, st, tr, rays,    \
-                           grad_out, rec, coef, aux, grad, gstride);                                          \
-    else                                                                                                      \
-        hipLaunchKernelGGL((grad_merge_kernel<F, BB, 512, 512, 1>), dim3(nb), dim3(64), 0, st, tr, rays,     \
-                           grad_out, rec, coef, aux, grad, gstride);                                          \
+    hipLaunchKernelGGL((grad_merge_kernel<F, BB, 1024, 1024, 4>), dim3(nb), dim3(256), 0, st, tr, rays,      \
+                       grad_out, rec, coef, aux, grad, gstride);                                              \
     return true;
 #define SVOXT_GATHER_XF(BB)                                                                                       \
     hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, true, true, true>), dim3(nb), dim3(kBlock), 0, st, \
