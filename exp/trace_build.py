@@ -33,7 +33,7 @@ assert marker in src
 src = src.replace(marker, pre + marker, 1)
 for slot, head in enumerate(("render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,",
                              "render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,",
-                             "grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, const uint2* __restrict__ rec,")):
+                             "grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,")):
     a = src.index(head)
     b = src.index(") {\n", a) + 4
     src = src[:b] + f"    TraceScope trace_scope({slot});\n" + src[b:]

@@ -52,5 +52,5 @@ for s in range(3):
 step()
 torch.cuda.synchronize()
 report("fwd", 0)
-report("walk", 1)
-report("merge", 2)
+report("tail", 1)
+report("fused", 2)

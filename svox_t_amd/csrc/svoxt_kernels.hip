@@ -388,6 +388,51 @@ __device__ __forceinline__ void coef_sample(const float (&row)[K], const float* 
     weight_out = weight;
 }
 
+// coef_sample() in two parts: what depends on the sample alone ...
+template <int FMT, int C, int BD, int K>
+__device__ __forceinline__ void sample_terms(const float (&row)[K], const float* basis, const float* g,
+                                             float delta_t, float delta_scale, float& att, float& total_color,
+                                             float (&coef)[C]) {
+    att = pexpf<true>(-delta_t * row[K - 1] * delta_scale);
+    total_color = 0.f;
+    if constexpr (FMT == FMT_SH) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float tmp = 0.f;
+#pragma unroll
+            for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
+            const double sd = sigmoid_d<true>(tmp);
+            const float sig = (float)sd;
+            coef[c] = (float)((double)sig * (1.0 - (double)sig));
+            total_color = (float)((double)total_color + sd * (double)g[c]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const double sd = sigmoid_d<true>(row[j]);
+            coef[j] = (float)sd;                     // sample_advance forms weight * sig * (1 - sig) * g_j
+            total_color = (float)((double)total_color + sd * (double)g[j]);
+        }
+    }
+}
+
+// ... and what runs from sample to sample along the ray (RGBA: coef_j <- weight * sig_j * (1 - sig_j) * g_j)
+template <int FMT, int C>
+__device__ __forceinline__ void sample_advance(float att, float total_color, float (&coef)[C], const float* g,
+                                               float delta_t, float delta_scale, float light_ray,
+                                               float& light, float& accum, float& weight_out, float& sg) {
+    const float weight = light * (1.f - att);
+    if constexpr (FMT == FMT_RGBA) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) coef[j] = weight * coef[j] * (1.f - coef[j]) * g[j];
+    }
+    light *= att;
+    accum -= weight * total_color;
+    sg = delta_t * delta_scale * (total_color * light - accum)
+       + delta_t * delta_scale * g[C] * light_ray;
+    weight_out = weight;
+}
+
 // REPLAY: rec / aux were filled by render_fwd_kernel<..., REC=true> for the
 // same tree, rays and options: pass 1 walks the list instead of the tree.
 // GATHER (C == 3, lists only): the listed samples are not sent to the gradient table
@@ -413,6 +458,10 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     Ray r;
     bool alive = q < rays.Q;
+    if constexpr (GATHER) {
+        // tail-only launch (coef_out == NULL): most wavefronts have no overflowed ray and leave here
+        if (coef_out == nullptr && !__any(alive && (aux[alive ? q : 0].x & kRecOverflow) != 0u)) return;
+    }
     if (alive) alive = setup_ray(tr, rays, opt, q, r);
     if (!__any(alive)) return;
 
@@ -449,6 +498,11 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             const uint4 a = aux[q];
             nrec = (int)(a.x & ~kRecOverflow);
             if (a.x & kRecOverflow) { t_resume = __uint_as_float(a.y); tmax2 = r.tmax; }
+            if constexpr (GATHER) {
+                // tail-only launch (coef_out == NULL, in front of grad_fused_kernel): nothing to
+                // do for a ray whose list holds all of its samples
+                if (coef_out == nullptr && tmax2 < 0.f) nrec = 0;
+            }
             if (fwd_out != nullptr) {
                 // Single march: what pass 1 would compute is already in the forward's
                 // output.  accum = sum_j w_j sum_c s_jc g_c + T bg sum_c g_c equals
@@ -523,6 +577,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     int k = 0;
     float t = t_resume;
     if constexpr (GATHER) {
+        if (coef_out == nullptr && !__any(tmax2 >= 0.f)) return;       // tail-only launch, no overflowed ray here
         // lane-independent: no wavefront-wide synchronisation while walking the list
         if (alive) {
             for (; k < nrec; ++k) {
@@ -539,15 +594,18 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                     precalc_basis<BD>(FMT_SH, BD, tr, rd[0], rd[1], rd[2], basis);
                     coef_sample<FMT, C, BD, K, true>(row, basis, g, __uint_as_float(e.y), r.delta_scale, light_ray,
                                                      light, accum, w, cf, sg, basis_last);
-                    __builtin_nontemporal_store(v4f{rd[0], rd[1], rd[2], 0.f},
-                                                reinterpret_cast<v4f*>(coef_out + ((int64_t)(S + k) * rays.Q + q)));
+                    if (coef_out != nullptr)
+                        __builtin_nontemporal_store(v4f{rd[0], rd[1], rd[2], 0.f},
+                                                    reinterpret_cast<v4f*>(coef_out + ((int64_t)(S + k) * rays.Q + q)));
                 } else {
                     coef_sample<FMT, C, BD, K, false, true>(row, basis, g, __uint_as_float(e.y), r.delta_scale,
                                                             light_ray, light, accum, w, cf, sg);
                 }
-                rec_put(slot, e.x, sg);
-                __builtin_nontemporal_store(v4f{w, cf[0], cf[1], cf[2]},
-                                            reinterpret_cast<v4f*>(coef_out + ((int64_t)k * rays.Q + q)));
+                if (coef_out != nullptr) {               // (tail-only launch: the running values alone)
+                    rec_put(slot, e.x, sg);
+                    __builtin_nontemporal_store(v4f{w, cf[0], cf[1], cf[2]},
+                                                reinterpret_cast<v4f*>(coef_out + ((int64_t)k * rays.Q + q)));
+                }
             }
         }
         k = nrec;
@@ -839,6 +897,232 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
         __syncthreads();
         for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
         if (threadIdx.x == 0) s_nb = 0;
+        __syncthreads();
+    }
+}
+
+// The backward of an image in ONE kernel after the forward (3-channel payloads, K <= 32, N = 2,
+// no view rotations, lists and the forward's output at hand): list walk and per-tile merge
+// fused.  A workgroup of W = 8 wavefronts owns a tile (lane l of every wavefront = ray l).  Per
+// round, wavefront w forms the per-sample terms (sample_terms: row gather, exponential, three
+// double-precision sigmoids) of list position kb + w for the tile's 64 rays -- eight positions
+// of a list at once, where a list walked by one lane costs 1.7 us per position -- and puts
+// them, with the hash-table entry of their feature row, straight into the merge's record
+// arrays in LDS; wavefront 0 then advances the two values that run along each ray
+// (sample_advance: transmittance and accum, a dozen instructions per sample) through the
+// round's positions in order, which turns (att, total_color) into (weight, sigma entry).  Two
+// rounds fill a pass (16 positions, at most 1024 records, as grad_merge_kernel), which is
+// sorted by feature row and reduced as there.  No record goes through memory (rec keeps
+// (row, delta_t), coef is not used) and there is no separate list-walk kernel with its tail.
+// Operation for operation coef_sample(); rays whose list overflowed have their tail handled
+// by a tail-only launch of render_bwd_kernel<..., GATHER> in front.
+template <int FMT, int BD>
+__global__ void __launch_bounds__(512)
+grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
+                  const uint2* __restrict__ rec, const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
+                  float* __restrict__ grad, int gstride) {
+    constexpr int C = 3, W = 8, NT = 64 * W, T = 1024, R = 1024, RPP = R / (64 * W);
+    constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
+    constexpr int NB = (FMT == FMT_SH) ? BD : 0;
+    constexpr int BDS = (FMT == FMT_SH) ? (BD | 1) : 1;
+    constexpr int HALF = K < 16 ? K : 16;                    // columns 0-15 / 16-K: see grad_merge_kernel
+    constexpr int KS = HALF | 1;                             // staging row: one round of columns
+    static_assert(K <= 32 && RPP == 2, "sizes");
+    __shared__ int32_t keys[T];
+    __shared__ int32_t cnt[T];
+    __shared__ uint16_t order[R];
+    __shared__ uint32_t r_sl[R];                 // slot << 6 | lane; ~0: no record (16 bits are all in use)
+    __shared__ float r_sg[R], r_w[R], r_c[3 * R], r_dt[R];
+    __shared__ float bases[64 * BDS];
+    __shared__ float gl[64 * 3];
+    __shared__ float stage_all[W * 64 * KS];
+    __shared__ int32_t seg_all[W * 64];
+    __shared__ int32_t s_nb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* stage = stage_all + wave * 64 * KS;
+    int32_t* seg = seg_all + wave * 64;
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * 64 + lane);
+    uint4 a = make_uint4(0u, 0u, 0u, 0u);
+    if (q < rays.Q) a = aux[q];
+    const int nrec = (int)(a.x & ~kRecOverflow);
+    int maxn = nrec;
+    for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
+    maxn = __builtin_amdgcn_readfirstlane(maxn);             // everything that decides barriers is scalar
+    if (maxn == 0) return;                                   // the same in every wavefront of the workgroup
+
+    Ray r;
+    float basis[NB > 0 ? NB : 1], g[C + 1];
+    float accum = 0.f, light = 1.f;
+    const float light_ray = __uint_as_float(a.z);
+    r.delta_scale = 0.f;
+#pragma unroll
+    for (int j = 0; j <= C; ++j) g[j] = 0.f;
+    if (nrec > 0) {
+        setup_ray(tr, rays, opt, q, r);                      // for delta_scale (a ray with samples hits the cube)
+        if constexpr (FMT == FMT_SH) {
+            float vd[3];
+            load_vdir(rays, q, vd);
+            precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
+        }
+#pragma unroll
+        for (int j = 0; j <= C; ++j) g[j] = grad_out[q * (C + 1) + j];
+        if (wave == 0) {
+            const float* o = fwd_out + q * (C + 1);          // see render_bwd_kernel: single march
+#pragma unroll
+            for (int c = 0; c < C; ++c) accum += g[c] * o[c];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) bases[lane * BDS + i] = basis[i];
+#pragma unroll
+            for (int c = 0; c < C; ++c) gl[lane * 3 + c] = g[c];
+        }
+    }
+    for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
+    for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
+    __syncthreads();
+
+    for (int k0 = 0; k0 < maxn; k0 += RPP * W) {
+        // ---- terms + advance, RPP rounds of W list positions
+#pragma unroll 1
+        for (int rd = 0; rd < RPP; ++rd) {
+            const int kb = k0 + rd * W;                      // the same in every wavefront
+            if (kb >= maxn) break;
+            const int k = kb + wave;
+            const int slot = (rd * W + wave) * 64 + lane;
+            if (k < nrec) {
+                const uint2 e = rec_get(rec + ((int64_t)k * rays.Q + q));
+                float row[K];
+                load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
+                float att, tc, cf[C];
+                sample_terms<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, att, tc, cf);
+                const int32_t idx = (int32_t)e.x;
+                uint32_t h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
+                while (true) {
+                    const int32_t old = atomicCAS(keys + h, -1, idx);
+                    if (old == -1 || old == idx) break;
+                    h = (h + 1u) & (uint32_t)(T - 1);
+                }
+                atomicAdd(cnt + h, 1);
+                r_sl[slot] = (h << 6) | (uint32_t)lane;
+                r_w[slot] = att; r_sg[slot] = tc; r_dt[slot] = __uint_as_float(e.y);
+                r_c[slot] = cf[0]; r_c[R + slot] = cf[1]; r_c[2 * R + slot] = cf[2];
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    if (kb + j < nrec) {
+                        const int s2 = (rd * W + j) * 64 + lane;
+                        float cf[C] = {r_c[s2], r_c[R + s2], r_c[2 * R + s2]};
+                        float wgt, sg;
+                        sample_advance<FMT, C>(r_w[s2], r_sg[s2], cf, g, r_dt[s2], r.delta_scale, light_ray, light, accum, wgt, sg);
+                        r_w[s2] = wgt; r_sg[s2] = sg;
+                        if constexpr (FMT == FMT_RGBA) { r_c[s2] = cf[0]; r_c[R + s2] = cf[1]; r_c[2 * R + s2] = cf[2]; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- sort: exclusive scan of the counters (wavefront 0), counting sort of the record numbers
+        if (wave == 0) {
+            constexpr int PER = T / 64;
+            int mine[PER], sum = 0;
+#pragma unroll
+            for (int j2 = 0; j2 < PER; ++j2) { mine[j2] = cnt[lane * PER + j2]; sum += mine[j2]; }
+            int incl = sum;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += v;
+            }
+            int run = incl - sum;
+#pragma unroll
+            for (int j2 = 0; j2 < PER; ++j2) { cnt[lane * PER + j2] = run; run += mine[j2]; }
+            if (lane == 63) s_nb = incl;
+        }
+        __syncthreads();
+        const int nb = __builtin_amdgcn_readfirstlane(s_nb);
+        for (int rr = threadIdx.x; rr < R; rr += NT) {
+            const uint32_t v = r_sl[rr];
+            if (v != 0xffffffffu) order[atomicAdd(cnt + (v >> 6), 1)] = (uint16_t)rr;
+        }
+        __syncthreads();
+        // ---- reduce: 64 sorted records at a time per wavefront, the K columns in two rounds
+        // (0-15, 16-K: each atomic instruction of a row touches one 64-byte line of a row that
+        // starts on a 128-byte boundary)
+        for (int base = wave * 64; base < nb; base += NT) {
+            const int p = base + lane;
+            int my_sl = -1;
+            float w = 0.f, sgv = 0.f, cc[3] = {0.f, 0.f, 0.f}, gc[3] = {0.f, 0.f, 0.f};
+            float bx[NB > 0 ? NB : 1];
+            if (p < nb) {
+                const int rr = (int)order[p];
+                const int v = (int)r_sl[rr];
+                my_sl = v >> 6;
+                const int rl = v & 63;
+                sgv = r_sg[rr];
+#pragma unroll
+                for (int c3 = 0; c3 < C; ++c3) cc[c3] = r_c[c3 * R + rr];
+                if constexpr (FMT == FMT_SH) {
+                    w = r_w[rr];
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) bx[i] = bases[rl * BDS + i];
+#pragma unroll
+                    for (int c3 = 0; c3 < C; ++c3) gc[c3] = gl[rl * 3 + c3];
+                }
+            }
+            seg[lane] = my_sl >= 0 ? keys[my_sl] : -1;          // the feature row staged row `lane` belongs to
+            const int grp = lane >> 4, sub = lane & 15;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int c_lo = h2 * HALF;
+                const int ncol = (h2 == 0) ? HALF : K - HALF;
+                if (ncol > 0) {
+                    if (p < nb) {
+                        float* st = stage + lane * KS;
+#pragma unroll
+                        for (int j = 0; j < HALF; ++j) {
+                            const int col = c_lo + j;           // compile-time after unrolling
+                            if (col < K) {
+                                float val;
+                                if (col == K - 1) val = sgv;
+                                else if constexpr (FMT == FMT_SH) val = w * bx[col % (NB > 0 ? NB : 1)] * cc[col / (NB > 0 ? NB : 1)] * gc[col / (NB > 0 ? NB : 1)];
+                                else val = cc[col];
+                                st[j] = val;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const bool has = sub < ncol;
+                    int cur = -1;
+                    float acc = 0.f;
+                    int keyv[16];
+                    float xv[16];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int row = grp * 16 + t;
+                        keyv[t] = seg[row];
+                        xv[t] = stage[row * KS + (has ? sub : 0)];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int key = keyv[t];
+                        if (key != cur) {
+                            if (cur >= 0 && has) atomicAdd(grad + (int64_t)cur * gstride + c_lo + sub, acc);
+                            acc = 0.f;
+                            cur = key;
+                        }
+                        acc += xv[t];
+                    }
+                    if (cur >= 0 && has) atomicAdd(grad + (int64_t)cur * gstride + c_lo + sub, acc);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (k0 + RPP * W >= maxn) break;                 // last pass (scalar condition)
+        __syncthreads();
+        for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
+        for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
         __syncthreads();
     }
 }
@@ -1710,9 +1994,18 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
                        const float* fwd_out, float4* coef, bool xf, hipStream_t st) {
     if (C != 3) return false;
     const unsigned nb = nblocks(rays.Q);
+    static const bool fused_on = [] { const char* e = getenv("SVOXT_BWD_FUSED"); return e == nullptr || atoi(e) != 0; }();
+    const bool fused = fused_on && !xf && fwd_out != nullptr;
     // four wavefronts per tile and tables of 1024 (measured: one wavefront per tile 0.41 ms,
     // two 0.33, four 0.30 before step 15; tables of 512 / 256 cost more passes than they buy)
 #define SVOXT_GATHER(F, BB)                                                                                   \
+    if (fused) {   /* tails of overflowed rays (a tail-only launch), then list walk and merge in one kernel */ \
+        hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
+                           tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out, (float4*)nullptr);   \
+        hipLaunchKernelGGL((grad_fused_kernel<F, BB>), dim3(nb), dim3(512), 0, st,                            \
+                           tr, rays, opt, grad_out, rec, aux, fwd_out, grad, gstride);                        \
+        return true;                                                                                          \
+    }                                                                                                         \
     hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
                        tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out, coef);                   \
     hipLaunchKernelGGL((grad_merge_kernel<F, BB, 1024, 1024, 4>), dim3(nb), dim3(256), 0, st, tr, rays,      \
