@@ -499,6 +499,7 @@ BWD_EXACT = os.environ.get("SVOXT_BWD_EXACT", "0") not in ("", "0")
 # merge in LDS -> one atomic row per tile and feature row, include/svoxt.h
 # svoxt_sample_lists.coef) for batches declared as images; 2: whenever the payload allows
 GATHER_ALIGNED = os.environ.get("SVOXT_GATHER_ALIGNED", "1") not in ("", "0")   # 64-byte-aligned rows for the merge kernel too
+BWD_FUSED = os.environ.get("SVOXT_BWD_FUSED", "1") not in ("", "0")   # 0: list walk and merge as two kernels (read by the library too)
 BWD_GATHER = int(os.environ.get("SVOXT_BWD_GATHER", "1") or 0)     # 0 never, 1 for image batches, 2 whenever possible
 
 
@@ -534,18 +535,21 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
         if lists is not None:
             if lists.aux.shape[0] != cr.Q or lists.aux.device != dev:
                 raise RuntimeError("sample lists do not belong to this ray batch")
-            if gather:
-                # with view rotations a second plane holds each sample's rotated direction
-                planes = 2 if ct.xform is not None else 1
-                lists.coef = torch.empty((planes * lists.S, cr.Q, 4), dtype=torch.float32, device=dev)
-                lists.consumed = True
-            cl = lists.c_struct()
             fo = None
             if fwd_output is not None and not BWD_EXACT:
                 _check_input(fwd_output, "fwd_output")
                 if fwd_output.shape != grad_output.shape or fwd_output.dtype != torch.float32:
                     raise RuntimeError("fwd_output must match grad_output")
                 fo = fwd_output
+            fused = gather and BWD_FUSED and ct.xform is None and fo is not None
+            if gather and not fused:
+                # with view rotations a second plane holds each sample's rotated direction
+                planes = 2 if ct.xform is not None else 1
+                lists.coef = torch.empty((planes * lists.S, cr.Q, 4), dtype=torch.float32, device=dev)
+                lists.consumed = True         # the two-kernel form rewrites rec
+            cl = lists.c_struct()
+            if fused:
+                cl.coef_bytes = -1            # list walk and merge as one kernel: no buffer, rec stays as recorded
             _call("svoxt_volume_render_bwd_replay", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(grad_output), grad_output.shape[1], _ptr(buf), stride, ctypes.byref(cl), _ptr(fo),
                   _stream(dev))

@@ -1996,6 +1996,7 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
     const unsigned nb = nblocks(rays.Q);
     static const bool fused_on = [] { const char* e = getenv("SVOXT_BWD_FUSED"); return e == nullptr || atoi(e) != 0; }();
     const bool fused = fused_on && !xf && fwd_out != nullptr;
+    if (!fused && coef == nullptr) return false;            // the two-kernel form needs its buffer
     // four wavefronts per tile and tables of 1024 (measured: one wavefront per tile 0.41 ms,
     // two 0.33, four 0.30 before step 15; tables of 512 / 256 cost more passes than they buy)
 #define SVOXT_GATHER(F, BB)                                                                                   \
@@ -2121,10 +2122,12 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
         if (lists != nullptr) {
             uint2* lrec = reinterpret_cast<uint2*>(lists->rec);
             const uint4* laux = reinterpret_cast<const uint4*>(lists->aux);
-            if (n2 && lists->coef != nullptr && tree->K <= 32 &&
-                lists->coef_bytes >= (int64_t)lists->max_samples * rays->Q * 16)
+            // coef_bytes < 0 (and no coef): the per-tile route if it can run fused, which needs no buffer
+            const bool have_coef = lists->coef != nullptr &&
+                                   lists->coef_bytes >= (int64_t)lists->max_samples * rays->Q * 16;
+            if (n2 && tree->K <= 32 && (have_coef || lists->coef_bytes < 0))
                 done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux,
-                                         fwd_out, reinterpret_cast<float4*>(lists->coef), false, st);
+                                         fwd_out, have_coef ? reinterpret_cast<float4*>(lists->coef) : nullptr, false, st);
             if (!done) done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux, fwd_out, st)
                       : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux, fwd_out, st);
             if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no specialised kernel for this payload", fn);
