@@ -1021,9 +1021,10 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 }
             }
         }
-        __syncthreads();
-        // ---- sort: exclusive scan of the counters (wavefront 0), counting sort of the record numbers
-        if (wave == 0) {
+        // ---- sort: exclusive scan of the counters -- by wavefront 1, while wavefront 0 still advances
+        // the last round (the counters are complete since the round's barrier) -- then the
+        // counting sort of the record numbers
+        if (wave == 1) {
             constexpr int PER = T / 64;
             int mine[PER], sum = 0;
 #pragma unroll
