@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0
 # Memory-side traffic of the two hot kernels, from separate rocprofv3 --pmc passes
 # of this same command (scripts/pmc_passes.sh -> scripts/pmc_summary.py), committed
 # under profiles/.  FETCH_SIZE / WRITE_SIZE are KiB per dispatch.
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_r_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_s_pmc.json")
 
 
 def pmc_traffic(which):
@@ -50,7 +50,7 @@ def pmc_traffic(which):
         c = counters[which]
         raw = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
         if which == "bwd":                              # the backward is several kernels
-            for extra in ("merge", "compact"):
+            for extra in ("merge", "fused", "compact"):
                 if extra in counters:
                     raw += (counters[extra]["FETCH_SIZE"] + counters[extra]["WRITE_SIZE"]) * 1024.0
         return int(raw), ("(FETCH_SIZE + WRITE_SIZE) * 1024 from " + os.path.relpath(PMC_FILE, ROOT) +
@@ -197,7 +197,7 @@ def main():
         if args.forward_only or fwd_ms >= bwd_ms:
             dom, dom_ms, dom_bytes = "render_fwd_kernel", fwd_ms, bytes_fwd
         else:
-            dom, dom_ms, dom_bytes = "render_bwd_kernel + grad_merge_kernel (+ grad memset, row compaction)", bwd_ms, bytes_bwd
+            dom, dom_ms, dom_bytes = "grad_fused_kernel (+ tail-only render_bwd_kernel, grad memset, row compaction)", bwd_ms, bytes_bwd
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic, traffic_note = pmc_traffic("fwd" if dom.startswith("render_fwd") else "bwd") \
             if args.workload == "d8_sh9_800" and world == 1 else (None, "PMC profile exists for the default workload at N=1 only")

@@ -9,12 +9,12 @@ for f in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
         short = "bwd" if "render_bwd" in k else "fwd" if "render_fwd" in k else "merge" if "grad_merge" in k \
-            else "compact" if "compact_rows" in k else None
+            else "fused" if "grad_fused" in k else "compact" if "compact_rows" in k else None
         if short is None:
             continue
         acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
-for k in ("fwd", "bwd", "merge", "compact"):
+for k in ("fwd", "bwd", "merge", "fused", "compact"):
     if k not in acc:
         continue
     print(f"== {k}")
@@ -27,5 +27,6 @@ if len(sys.argv) > 2:
     json.dump({"tag": tag, "units": "mean counter value per dispatch; FETCH_SIZE / WRITE_SIZE in KiB",
                "kernels": {"fwd": "render_fwd_kernel<SH,3,9,N2,REC>", "bwd": "render_bwd_kernel<SH,3,9,N2,REPLAY[,GATHER]>",
                            "merge": "grad_merge_kernel<SH,9> (second kernel of the two-kernel backward)",
+                           "fused": "grad_fused_kernel<SH,9> (list walk + merge in one kernel; bwd is then the tail-only launch)",
                            "compact": "compact_rows_kernel (128-byte-aligned gradient rows -> dense [M, K])"},
                "counters": out}, open(sys.argv[2], "w"), indent=1)
