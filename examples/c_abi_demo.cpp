@@ -88,14 +88,16 @@ int main(int argc, char** argv) {
     float* d_grad_rows = nullptr;
     HIP_OK(hipMalloc(&d_grad_rows, sizeof(float) * M * gs));
 
-    // forward that records sample lists, backward that replays them (two-kernel route when
-    // a coef buffer is given and the payload allows; the library ignores it otherwise)
+    // forward that records sample lists, backward that replays them: coef NULL with coef_bytes -1
+    // asks for the per-tile route as one fused kernel (image batches without view rotations,
+    // the forward's output passed along); the library falls back to the one-kernel backward
+    // where that does not apply
     svoxt_sample_lists lists = {};
     lists.max_samples = 96;
-    lists.coef_bytes = (int64_t)lists.max_samples * Q * 16;
+    lists.coef = nullptr;
+    lists.coef_bytes = -1;
     HIP_OK(hipMalloc(&lists.rec, (size_t)lists.max_samples * Q * 8));
     HIP_OK(hipMalloc(&lists.aux, (size_t)Q * 16));
-    HIP_OK(hipMalloc(&lists.coef, (size_t)lists.coef_bytes));
     if (svoxt_can_record(&tree, &opt)) {
         SVOXT_OK_(svoxt_volume_render_fwd_record(&tree, &rays, &opt, d_out, &lists, st));
         SVOXT_OK_(svoxt_volume_render_bwd_replay(&tree, &rays, &opt, d_gout, cols, d_grad_rows, gs, &lists, d_out, st));

@@ -28,11 +28,14 @@ Rays = namedtuple("Rays", ["origins", "dirs", "viewdirs"])
 _C = _get_c_extension()
 
 
-# sort_rays=True (or SVOXT_SORT_RAYS=1 for every batch that is not declared an image): render
-# the batch in a coherent order (svoxt_ray_order, include/svoxt.h).  Off by default: the sort,
-# three gathers and a scatter cost ~0.3 ms per 640 000 rays, which rays shuffled within one
-# camera earn back (forward+backward 1.47 -> 1.11 ms) and rays drawn from many cameras do not.
-SORT_RAYS = os.environ.get("SVOXT_SORT_RAYS", "0")
+# Batches that are not declared images are rendered in a coherent order (svoxt_ray_order,
+# include/svoxt.h: sort by the rays' entry points into the cube, three gathers, a scatter --
+# ~0.3 ms per 640 000 rays) from SORT_RAYS_MIN rays on, and their backward then takes the
+# per-tile route: 640 000 rays forward+backward, shuffled within one camera 1.47 -> 0.93 ms,
+# drawn from 8 cameras 1.48 -> 1.29 ms, row-major but not declared an image 1.29 -> 0.92 ms
+# (profiles/r01_s_ray_order_timing.txt).  SVOXT_SORT_RAYS=0 never, =1 always; sort_rays= per call.
+SORT_RAYS = os.environ.get("SVOXT_SORT_RAYS", "auto")
+SORT_RAYS_MIN = 16384
 
 
 def _rays_spec_from_rays(rays, image_shape=None, sort_rays=None):
@@ -43,7 +46,7 @@ def _rays_spec_from_rays(rays, image_shape=None, sort_rays=None):
     if image_shape is not None:
         spec.image_height, spec.image_width = int(image_shape[0]), int(image_shape[1])
     if sort_rays is None:
-        sort_rays = SORT_RAYS == "1"
+        sort_rays = SORT_RAYS == "1" or (SORT_RAYS == "auto" and rays.origins.shape[0] >= SORT_RAYS_MIN)
     spec.sort = bool(sort_rays) and image_shape is None
     return spec
 
@@ -268,8 +271,8 @@ class VolumeRenderer(nn.Module):
         :param sort_rays: (not in the reference) render a batch that is not an image in the
                order of its rays' entry points into the tree's cube, so that the 64 rays of
                a wavefront cross the same leaves; every ray's result is unchanged and comes
-               back at the ray's own position.  Pays for rays shuffled within few cameras
-               (see SORT_RAYS above); None: SVOXT_SORT_RAYS (default off)
+               back at the ray's own position.  None: from 16 384 rays on (SORT_RAYS above;
+               SVOXT_SORT_RAYS=0/1 overrides)
         :return: [Q, C+1]: C colour/feature channels then accumulated alpha
         """
         self._require_gpu(cuda, "forward")
