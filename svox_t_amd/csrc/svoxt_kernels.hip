@@ -15,7 +15,10 @@
 //   render_fwd_kernel          trace_ray; optionally records each ray's composited samples
 //   render_fwd_generic_kernel  fallback forward
 //   render_bwd_kernel          trace_ray_backward: replays recorded samples (or marches),
-//                              stages gradient rows in LDS, flushes them as shaped atomics
+//                              stages gradient rows in LDS, flushes them as shaped atomics;
+//                              <..., GATHER>: list walk of the two-kernel backward / tail-only launch
+//   grad_merge_kernel          second kernel of the two-kernel backward (per-tile merge in LDS)
+//   grad_fused_kernel          list walk + per-tile merge as one kernel: the backward of an image
 //   render_bwd_generic_kernel  fallback backward, per-lane atomics (opacity backward, K > 64)
 //   render_bwd_generic_staged_kernel  fallback backward with LDS-staged, shaped atomics
 //   opacity_fwd_kernel (+ opacity_walk_kernel, opacity_merge_kernel: backward from lists),
@@ -23,7 +26,8 @@
 //   query_fwd_kernel, query_bwd_kernel, leaves_count / scan / scatter kernels
 //   compact_rows_kernel, accel_build_kernel, accel_nodes_kernel
 // Other translation units of the library: svoxt_build.hip (octree from a point
-// cloud, construct_tree), svoxt_motion.hip (motion variants, point skinning).
+// cloud, construct_tree), svoxt_motion.hip (motion variants, point skinning), svoxt_order.hip
+// (coherent order for ray batches that are not images).
 // The design rationale and the measurements behind each choice are in DESIGN.md 5.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
