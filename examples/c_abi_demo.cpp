@@ -96,7 +96,7 @@ int main(int argc, char** argv) {
     lists.max_samples = 96;
     lists.coef = nullptr;
     lists.coef_bytes = -1;
-    HIP_OK(hipMalloc(&lists.rec, (size_t)lists.max_samples * Q * 8));
+    HIP_OK(hipMalloc(&lists.rec, (size_t)lists.max_samples * ((Q + 63) / 64 * 64) * 8));   // whole 64-ray tiles
     HIP_OK(hipMalloc(&lists.aux, (size_t)Q * 16));
     if (svoxt_can_record(&tree, &opt)) {
         SVOXT_OK_(svoxt_volume_render_fwd_record(&tree, &rays, &opt, d_out, &lists, st));

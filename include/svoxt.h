@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 9
+#define SVOXT_ABI_VERSION 10
 
 enum {
     SVOXT_OK = 0,
@@ -139,6 +139,19 @@ int svoxt_out_data_dim(const svoxt_options* opt, int32_t K);
 int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
                             const svoxt_options* opt, float* out, void* stream);
 
+/* The same result (bit for bit) with device scratch: with svoxt_fwd_workspace_bytes(Q, S)
+ * bytes (S >= 1, 96 is a good value) the 3-channel payloads run as two kernels -- one that
+ * only steps the rays through the tree and lists each ray's samples (up to S; longer rays
+ * finish in a tail launch), one that shades the lists per 64-ray tile with eight wavefronts
+ * sharing the work -- instead of one kernel as long as its longest ray (800x800, depth-8 SH9:
+ * see DESIGN.md 5).  Other payloads, tree->weight_accum, a NULL or too small workspace:
+ * exactly svoxt_volume_render_fwd.  Contents of the workspace on return are unspecified.
+ * (Reference: volume_render, rt_kernel.cu:1362-1379; trace_ray :222-328.) */
+int64_t svoxt_fwd_workspace_bytes(int64_t Q, int32_t max_samples);
+int svoxt_volume_render_fwd_ws(const svoxt_tree* tree, const svoxt_rays* rays,
+                               const svoxt_options* opt, float* out,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+
 /* grad_out: device [Q, grad_cols] with grad_cols = C+1.
  * grad_features: device [M, grad_stride] floats of which columns 0..K-1 are the
  *           gradient; zeroed by this call on `stream`, then accumulated with
@@ -175,9 +188,11 @@ int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
  * set: SH payloads on N = 2 trees); the lists are valid for the tree, features'
  * sign of sigma, rays and options they were recorded with. */
 typedef struct svoxt_sample_lists {
-    void*   rec;           /* device, max_samples * Q * 8 bytes */
+    void*   rec;           /* device, 64-byte aligned, max_samples * ceil(Q / 64) * 64 * 8 bytes: record k of the
+                              ray handled by launch thread t lives at rec[t / 64][k / 8][t % 64][k % 8] (8 bytes
+                              each): a lane's 8 consecutive records are one 64-byte line, written at once */
     void*   aux;           /* device, Q * 16 bytes: count | overflow, resume point, final transmittance, pad */
-    int32_t max_samples;   /* S, 1..4096 */
+    int32_t max_samples;   /* S: a multiple of 8 in [8, 4096] */
     void*   coef;          /* device, coef_bytes >= max_samples * Q * 16 bytes (twice that with tree->xform:
                               the second half takes each sample's rotated view direction), 16-byte
                               aligned, or NULL.  Only read by

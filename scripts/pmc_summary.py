@@ -1,32 +1,31 @@
 #!/usr/bin/env python3
 """Summarise gpurun_out/pmc_<tag>/*/.../*_counter_collection.csv: per kernel and
-counter, the mean value per dispatch."""
-import csv, glob, os, sys, collections
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+counter, the mean value per dispatch.   pmc_summary.py <tag> [out.json]"""
+import csv, glob, os, sys, collections, json, re
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.join("gpurun_out", f"pmc_{tag}")
+SHORT = [("march_rec", "march"), ("shade_tile", "shade"), ("shade_chan", "shade"), ("render_bwd", "bwd"), ("render_fwd", "fwd"),
+         ("grad_merge", "merge"), ("grad_fused", "fused"), ("grad_wide", "wide"), ("compact_rows", "compact"), ("depth_kernel", "depth")]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
+names = {}
 for f in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        short = "bwd" if "render_bwd" in k else "fwd" if "render_fwd" in k else "merge" if "grad_merge" in k \
-            else "fused" if "grad_fused" in k else "compact" if "compact_rows" in k else None
+        short = next((s for pat, s in SHORT if pat in k), None)
         if short is None:
             continue
+        m = re.search(r"svoxt::(\w+<[^>]*>|\w+)", k)
+        names.setdefault(short, set()).add(m.group(1) if m else k[:60])
         acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
-for k in ("fwd", "bwd", "merge", "fused", "compact"):
-    if k not in acc:
-        continue
-    print(f"== {k}")
+for k in sorted(acc):
+    print(f"== {k}  ({', '.join(sorted(names[k]))})")
     out[k] = {}
     for c, v in sorted(acc[k].items()):
         print(f"  {c:40s} {sum(v)/len(v):18.1f}   (n={len(v)})")
         out[k][c] = sum(v) / len(v)
 if len(sys.argv) > 2:
-    import json
-    json.dump({"tag": tag, "units": "mean counter value per dispatch; FETCH_SIZE / WRITE_SIZE in KiB",
-               "kernels": {"fwd": "render_fwd_kernel<SH,3,9,N2,REC>", "bwd": "render_bwd_kernel<SH,3,9,N2,REPLAY[,GATHER]>",
-                           "merge": "grad_merge_kernel<SH,9> (second kernel of the two-kernel backward)",
-                           "fused": "grad_fused_kernel<SH,9> (list walk + merge in one kernel; bwd is then the tail-only launch)",
-                           "compact": "compact_rows_kernel (128-byte-aligned gradient rows -> dense [M, K])"},
-               "counters": out}, open(sys.argv[2], "w"), indent=1)
+    json.dump({"tag": tag, "units": "mean counter value per dispatch; FETCH_SIZE / WRITE_SIZE in KiB; SQ_WAVE_CYCLES, "
+               "SQ_WAIT_*, SQ_ACTIVE_INST_* in quad-cycles (MI355X_MICROARCH.md)",
+               "kernels": {k: sorted(v) for k, v in names.items()}, "counters": out}, open(sys.argv[2], "w"), indent=1)

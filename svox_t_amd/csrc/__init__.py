@@ -43,7 +43,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -100,6 +100,8 @@ EXPORTS = {
     "svoxt_last_error": (ctypes.c_char_p, []),
     "svoxt_out_data_dim": (ctypes.c_int, [_P(_COptions), _i32]),
     "svoxt_volume_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
+    "svoxt_fwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
+    "svoxt_volume_render_fwd_ws": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _i64, _vp]),
     "svoxt_volume_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _vp, _i64, _vp]),
     "svoxt_bwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
     "svoxt_can_record": (ctypes.c_int, [_P(_CTree), _P(_COptions)]),
@@ -422,6 +424,9 @@ def get_out_data_dim(opt: RenderOptions, K: int) -> int:
 # samples march the remainder, so this only trades memory for speed).
 # 0 = never record: the backward then traverses the tree itself.
 BWD_LIST_SAMPLES = int(os.environ.get("SVOXT_BWD_LIST", "96"))
+# The same for a forward nobody differentiates: scratch lists for the two-kernel forward
+# (0 = always the one-kernel forward, svoxt_volume_render_fwd).
+FWD_LIST_SAMPLES = int(os.environ.get("SVOXT_FWD_LIST", "96"))
 
 
 class SampleLists:
@@ -430,7 +435,9 @@ class SampleLists:
     volume_render_backward."""
 
     def __init__(self, Q, S, device):
-        self.rec = torch.empty((S, Q, 2), dtype=torch.int32, device=device)
+        S = (S + 7) // 8 * 8                                 # whole 64-byte lines of 8 records per lane
+        # rec[tile][block][lane][8] (include/svoxt.h): rays padded to whole 64-ray tiles
+        self.rec = torch.empty(((Q + 63) // 64 * S * 64, 2), dtype=torch.int32, device=device)
         self.aux = torch.empty((Q, 4), dtype=torch.int32, device=device)
         self.S = S
         self.coef = None        # allocated by the backward when it takes the two-kernel route,
@@ -484,6 +491,13 @@ def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bo
             cl = lists.c_struct()
             _call("svoxt_volume_render_fwd_record", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(out), ctypes.byref(cl), _stream(dev))
+        elif FWD_LIST_SAMPLES > 0 and cr.Q > 0:
+            # scratch for the two-kernel forward (march, then shade per tile; the library falls
+            # back to the one-kernel forward for payloads it does not cover)
+            nbytes = _lib.svoxt_fwd_workspace_bytes(cr.Q, FWD_LIST_SAMPLES)
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            _call("svoxt_volume_render_fwd_ws", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+                  _ptr(out), _ptr(ws), nbytes, _stream(dev))
         else:
             _call("svoxt_volume_render_fwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(out), _stream(dev))

@@ -316,7 +316,14 @@ __device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float 
             const int sh = kFixBits - k;
             const uint32_t c3 = (((ux >> sh) & 1u) << 2) | (((uy >> sh) & 1u) << 1) | ((uz >> sh) & 1u);
             slot = ((uint32_t)node << 3) + c3;
-            cd = nodes[slot];
+            // ONE 8-byte load.  Written as `cd = nodes[slot]` the compiler splits it into two dword
+            // loads and sinks the data word's out of the loop: a second dependent round trip per
+            // leaf crossing, which is what the pairs exist to avoid (seen in the ISA: a
+            // `global_load_dword ... offset:4` after the loop).  A relaxed wavefront-scope atomic
+            // load is an ordinary global_load_dwordx2 that may not be split.
+            const unsigned long long w64 = __hip_atomic_load(
+                reinterpret_cast<const unsigned long long*>(nodes + slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            cd = make_uint2((uint32_t)w64, (uint32_t)(w64 >> 32));
             skip = (int32_t)cd.x;
             if (skip == 0 || k == kFixBits) break;
             node += skip;
@@ -347,7 +354,10 @@ struct Sample {
 };
 
 // One leaf crossing: rt_kernel.cu:261-277.
-template <bool N2>
+// ACC: -1 = look at tr.accel at run time; 1 / 0 = the caller knows the acceleration grid is
+// there / is not (a kernel instance without the other descent: fewer registers, and no false
+// register hazards between the two paths' loads for the wait-count placement to trip over).
+template <bool N2, int ACC = -1>
 __device__ __forceinline__ void march_step(const TreeDev& tr, const Ray& r, float step_size,
                                            float t, Sample& s) {
     const float px = r.ox + t * r.dx;
@@ -358,7 +368,7 @@ __device__ __forceinline__ void march_step(const TreeDev& tr, const Ray& r, floa
     // a pointer phi, which pins slot and idx in scratch memory (a scratch round trip per step).
     Leaf lf;
     int32_t idx;
-    if (N2 && tr.accel != nullptr) {
+    if (N2 && (ACC == 1 || (ACC < 0 && tr.accel != nullptr))) {
         locate_accel(tr, px, py, pz, lf, idx);   // leaf.slot / leaf.levels are not reference-accurate here
     } else {
         locate<N2>(tr, px, py, pz, lf);

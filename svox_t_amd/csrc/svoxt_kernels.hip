@@ -77,17 +77,66 @@ __device__ __forceinline__ uint2 rec_get(const uint2* p) {
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 
+// Where record k of the ray handled by launch thread `tid` (tile tid >> 6, lane tid & 63) lives:
+// rec[tile][k / 8][lane][k % 8] -- the 8 records of a block are the lane's own 64-byte line.
+// (Round 1 kept rec[k][q]: every record a lone 8-byte store to a different line.  A wavefront's
+// vector-memory operations complete in order -- stores count in vmcnt -- so each of those stores
+// sat in front of the next tree word of the march: the record stores, not the loads, were what
+// made a crossing cost 2.5 us under load (r02: halving the records took the march kernel from
+// 0.227 to 0.178 ms, removing the sigma gather changed nothing), and they reached memory as
+// partial lines, 2.5x write amplification.  Now a lane stages 8 records in LDS and writes one
+// whole line per 8 records.)
+constexpr int kRecBlock = 8;
+__device__ __forceinline__ int64_t rec_index(int64_t tid, int k, int S) {
+    return ((((tid >> 6) * (int64_t)(S >> 3) + (k >> 3)) << 6) + (tid & 63)) * kRecBlock + (k & 7);
+}
+// the staging buffer of one wavefront: [8][64] records, lane-contiguous (conflict-free ds_write_b64)
+__device__ __forceinline__ void rec_stage_flush(const uint2* __restrict__ lds, int lane, uint2* __restrict__ rec,
+                                                int64_t tid, int S, int k0) {
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    v4u* dst = reinterpret_cast<v4u*>(rec + rec_index(tid, k0, S));      // 64-byte aligned
+#pragma unroll
+    for (int j = 0; j < kRecBlock / 2; ++j) {
+        const uint2 a = lds[(2 * j) * 64 + lane], b = lds[(2 * j + 1) * 64 + lane];
+        __builtin_nontemporal_store(v4u{a.x, a.y, b.x, b.y}, dst + j);
+    }
+}
+// record number k (the k-th of this ray) <- (feature row, delta_t); a full block goes out as one line
+__device__ __forceinline__ void rec_stage_put(uint2* __restrict__ lds, int lane, uint2* __restrict__ rec, int64_t tid,
+                                              int S, int k, uint32_t idx, float delta_t) {
+    lds[(k & 7) * 64 + lane] = make_uint2(idx, __float_as_uint(delta_t));
+    if ((k & 7) == 7) rec_stage_flush(lds, lane, rec, tid, S, k & ~7);
+}
+// at the end of a ray with nrec records: the partly filled last block (its unused slots carry stale values)
+__device__ __forceinline__ void rec_stage_finish(const uint2* __restrict__ lds, int lane, uint2* __restrict__ rec,
+                                                 int64_t tid, int S, int nrec) {
+    if (nrec & 7) rec_stage_flush(lds, lane, rec, tid, S, nrec & ~7);
+}
+
 // XF (SH only): per-leaf view rotations (tree.xform): the basis is re-evaluated
 // for every composited sample with the leaf's matrix (rt_kernel.cu:283-291).
-template <int FMT, int C, int BD, bool N2, bool REC, bool XF = false>
+// RESUME (tail launch of the two-kernel forward, see shade_tile_kernel): only rays whose sample
+// list overflowed (aux[q].x bit 31) do anything; they pick up the compositing state the shade
+// kernel left in `out` (colour sums, transmittance in the alpha slot) and march on from
+// aux[q].y, then finalise the pixel and the recorded final transmittance.
+template <int FMT, int C, int BD, bool N2, bool REC, bool XF = false, bool RESUME = false>
 __global__ void __launch_bounds__(kBlock)
 render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
                   uint2* __restrict__ rec, int S, uint4* __restrict__ aux) {
     static_assert(!XF || FMT == FMT_SH, "view rotations only matter for view-dependent formats");
+    static_assert(!(RESUME && REC), "the tail launch does not record");
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
-    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+    __shared__ uint2 rstage[REC ? kRecBlock * kBlock : 1];
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, tid);
     if (q >= rays.Q) return;
     float* o = out + q * (C + 1);
+    float t_start = 0.f;
+    if constexpr (RESUME) {
+        const uint4 a = aux[q];
+        if ((a.x & kRecOverflow) == 0u) return;
+        t_start = __uint_as_float(a.y);
+    }
 
     Ray r;
     if (!setup_ray(tr, rays, opt, q, r)) {
@@ -112,6 +161,12 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
 
     float light = 1.f;
     float t = r.tmin;
+    if constexpr (RESUME) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) acc[j] = o[j];
+        light = o[C];
+        t = t_start;
+    }
     bool stopped = false;
     // Software pipeline: where the ray goes next depends on the leaf geometry only,
     // not on the leaf's features, so the descent of step k+1 is issued right after
@@ -135,7 +190,7 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
             if (sigma > opt.sigma_thresh) {
                 if constexpr (REC) {
                     if (nrec < S) {
-                        rec_put(rec + ((int64_t)nrec * rays.Q + q), (uint32_t)idx, delta_t);
+                        rec_stage_put(rstage, (int)threadIdx.x, rec, tid, S, nrec, (uint32_t)idx, delta_t);
                         ++nrec;
                     } else if (!over) {
                         over = true;
@@ -176,9 +231,12 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
         for (int j = 0; j < C; ++j) o[j] = acc[j] + bg;
     }
     o[C] = 1.f - light;
-    if constexpr (REC)   // + the final transmittance, for the single-march backward
+    if constexpr (REC) {  // + the final transmittance, for the single-march backward
+        rec_stage_finish(rstage, (int)threadIdx.x, rec, tid, S, nrec);
         aux[q] = make_uint4((uint32_t)nrec | (over ? kRecOverflow : 0u), __float_as_uint(t_resume),
                             __float_as_uint(light), 0u);
+    }
+    if constexpr (RESUME) aux[q].z = __float_as_uint(light);
 }
 
 // Generic fallback: any K, any format, component sub-range; accumulators in
@@ -239,6 +297,206 @@ render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __re
     }
     for (int j = 0; j < C; ++j) o[j] += light * opt.background_brightness;
     o[C] = 1.f - light;
+}
+
+// ---------------------------------------------------------------------------
+// Forward as two kernels: march, then shade per tile (trace_ray, rt_kernel.cu:222-328)
+// ---------------------------------------------------------------------------
+//
+// render_fwd_kernel is as long as its longest wavefront: the 8x8 tile whose rays graze the
+// shell makes ~140 leaf crossings, and every crossing carries the whole shading of a sample
+// (row gather, basis products, four exponentials, three double-precision divisions: ~450
+// instructions, r02 ISA) in one dependent chain -- 1.8 us per crossing, 250 us for that
+// wavefront while the bulk of the grid is done after 70 us.  Where a ray goes next depends on
+// the leaf geometry alone, so the chain that must be sequential is the stepping: it gets a
+// kernel of its own, and the shading becomes throughput work.
+//
+//   march_rec_kernel   one ray per lane: locate leaf, step, nothing else.  The sigma of a
+//                      crossing (one 4-byte gather) is requested and looked at one crossing
+//                      later -- memory operations of a wavefront return in order, so it has
+//                      arrived with the next crossing's tree words and costs the chain nothing.
+//                      Samples that pass (sigma > sigma_thresh) are recorded as (feature row,
+//                      delta_t) in rec[k][q], the same lists the backward replays.
+//   shade_tile_kernel  one workgroup of eight wavefronts per 64 rays (lane l of each = ray l).
+//                      Per round, wavefronts 1..7 each take one list position of the 64 rays and
+//                      form what depends on the sample alone: att = exp(-delta_t ds sigma) and
+//                      e_c = exp(-x_c) (row gather, basis products, four exponentials); wavefront
+//                      0 then runs what is sequential along a ray -- weight = T (1 - att),
+//                      acc_c = float(double(acc_c) + double(weight) / (1.0 + double(e_c))),
+//                      T *= att -- through the round's positions in list order, one round behind
+//                      the others (double-buffered LDS, one barrier per round).  Operation for
+//                      operation render_fwd_kernel: outputs are bit-identical.
+//   render_fwd_kernel<..., RESUME>   rays whose list overflowed continue from where it ends.
+
+// STOP: apply the early-termination rule (T <= stop_thresh ends the ray, rt_kernel.cu:313-319)
+// while marching, with the transmittance formed exactly as the shade kernel forms it.  Off when
+// the lists are for a backward, which wants every sample with sigma > 0 (:382,456).
+template <bool N2, bool STOP, int ACC>
+__global__ void __launch_bounds__(kBlock)
+march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, uint2* __restrict__ rec, int S, uint4* __restrict__ aux) {
+    __shared__ uint2 rstage[kRecBlock * kBlock];
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, tid);
+    if (q >= rays.Q) return;
+    Ray r;
+    if (!setup_ray(tr, rays, opt, q, r)) {
+        aux[q] = make_uint4(0u, 0u, __float_as_uint(1.f), 0u);
+        return;
+    }
+    const int K = tr.K;
+    const float* __restrict__ sig_col = tr.features + (K - 1);
+    int nrec = 0;
+    bool over = false;
+    float t_resume = 0.f;
+    float light = 1.f;
+    float t = r.tmin;
+    // the crossing whose sigma is in flight
+    bool pend = false;
+    float p_sigma = 0.f, p_dt = 0.f, p_t = 0.f;
+    int32_t p_idx = 0;
+    bool done = false;
+    while (t < r.tmax) {
+        Sample s;
+        march_step<N2, ACC>(tr, r, opt.step_size, t, s);
+        if (pend && p_sigma > opt.sigma_thresh) {
+            if (nrec < S) {
+                rec_stage_put(rstage, (int)threadIdx.x, rec, tid, S, nrec, (uint32_t)p_idx, p_dt);
+                ++nrec;
+            } else {        // list full: whoever consumes it marches on from this crossing
+                over = true;
+                t_resume = p_t;
+                done = true;
+                break;
+            }
+            if constexpr (STOP) {
+                light *= pexpf(-p_dt * r.delta_scale * p_sigma);
+                if (light <= opt.stop_thresh) { done = true; break; }
+            }
+        }
+        pend = s.valid;
+        if (pend) {
+            p_sigma = sig_col[(int64_t)s.idx * K];
+            p_idx = s.idx;
+            p_dt = s.delta_t;
+            p_t = t;
+        }
+        t = march_advance(t, s.delta_t);
+    }
+    if (!done && pend && p_sigma > opt.sigma_thresh) {
+        if (nrec < S) {
+            rec_stage_put(rstage, (int)threadIdx.x, rec, tid, S, nrec, (uint32_t)p_idx, p_dt);
+            ++nrec;
+        } else {
+            over = true;
+            t_resume = p_t;
+        }
+    }
+    rec_stage_finish(rstage, (int)threadIdx.x, rec, tid, S, nrec);
+    aux[q] = make_uint4((uint32_t)nrec | (over ? kRecOverflow : 0u), __float_as_uint(t_resume),
+                        __float_as_uint(1.f), 0u);
+}
+
+template <int FMT, int BD, bool XF, bool STOP>
+__global__ void __launch_bounds__(512)
+shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, const uint2* __restrict__ rec, int S,
+                  uint4* __restrict__ aux, float* __restrict__ out) {
+    constexpr int C = 3, W = 8, P = W - 1;
+    constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
+    constexpr int NB = (FMT == FMT_SH) ? BD : 1;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __shared__ v4f terms[2][P][64];              // (att, e_0, e_1, e_2) of a list position, per ray
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * 64 + lane);
+    const bool inb = q < rays.Q;
+    uint4 a = make_uint4(0u, 0u, 0u, 0u);
+    if (inb) a = aux[q];
+    const int nrec = (int)(a.x & ~kRecOverflow);
+    int maxn = nrec;
+    for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
+    maxn = __builtin_amdgcn_readfirstlane(maxn);     // what decides the barrier count is scalar
+    const int nround = (maxn + P - 1) / P;           // the same in every wavefront of the workgroup
+
+    float delta_scale = 0.f;
+    float basis[NB];
+    float vd[3] = {0.f, 0.f, 0.f};
+    if (wave > 0 && nrec > 0) {
+        Ray r;
+        setup_ray(tr, rays, opt, q, r);               // a ray with samples hits the cube
+        delta_scale = r.delta_scale;
+        if constexpr (FMT == FMT_SH) {
+            load_vdir(rays, q, vd);
+            if constexpr (!XF) precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
+        }
+    }
+    float light = 1.f, acc[C] = {0.f, 0.f, 0.f};
+    bool stopped = false;
+
+    for (int rd = 0; rd <= nround; ++rd) {
+        if (wave > 0) {
+            const int k = rd * P + (wave - 1);
+            if (rd < nround && k < nrec) {
+                const uint2 e = rec_get(rec + rec_index((int64_t)blockIdx.x * 64 + lane, k, S));
+                const int32_t idx = (int32_t)e.x;
+                float row[K];
+                load_row<K>(tr.features + (int64_t)idx * K, row);
+                v4f tv;
+                tv.x = pexpf(-__uint_as_float(e.y) * delta_scale * row[K - 1]);
+                if constexpr (FMT == FMT_SH) {
+                    if constexpr (XF) rotated_sh_basis<BD>(tr, idx, vd, basis);
+                    float ex[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        float tmp = 0.f;
+#pragma unroll
+                        for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
+                        ex[c] = pexpf(-tmp);
+                    }
+                    tv.y = ex[0]; tv.z = ex[1]; tv.w = ex[2];
+                } else {
+                    tv.y = pexpf(-row[0]); tv.z = pexpf(-row[1]); tv.w = pexpf(-row[2]);
+                }
+                terms[rd & 1][wave - 1][lane] = tv;
+            }
+        } else if (rd > 0) {
+            const int kb = (rd - 1) * P;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                if (kb + j < nrec && !stopped) {
+                    const v4f tv = terms[(rd - 1) & 1][j][lane];
+                    const float weight = light * (1.f - tv.x);
+                    acc[0] = (float)((double)acc[0] + (double)weight / (1.0 + (double)tv.y));
+                    acc[1] = (float)((double)acc[1] + (double)weight / (1.0 + (double)tv.z));
+                    acc[2] = (float)((double)acc[2] + (double)weight / (1.0 + (double)tv.w));
+                    light *= tv.x;
+                    if constexpr (STOP) {
+                        if (light <= opt.stop_thresh) stopped = true;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0 && inb) {
+        float* o = out + q * (C + 1);
+        if (stopped) {
+            const float scale = (float)(1.0 / (1.0 - (double)light));
+#pragma unroll
+            for (int j = 0; j < C; ++j) o[j] = acc[j] * scale;
+            o[C] = 1.f - light;
+            a.x &= ~kRecOverflow;                    // nothing left for the tail launch
+        } else if (a.x & kRecOverflow) {             // state for render_fwd_kernel<..., RESUME>
+#pragma unroll
+            for (int j = 0; j < C; ++j) o[j] = acc[j];
+            o[C] = light;
+        } else {
+            const float bg = light * opt.background_brightness;
+#pragma unroll
+            for (int j = 0; j < C; ++j) o[j] = acc[j] + bg;
+            o[C] = 1.f - light;
+        }
+        a.z = __float_as_uint(light);                // the final transmittance, for the single-march backward
+        aux[q] = a;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -454,12 +712,14 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     constexpr int KS = K | 1;                         // odd LDS row stride: conflict-free column writes
     __shared__ float stage_all[(kBlock / 64) * 64 * KS];
     __shared__ int32_t sidx_all[kBlock];
+    __shared__ uint2 rstage[REPLAY ? 1 : kRecBlock * kBlock];     // pass 1 records into the workspace lists
 
     const int lane = threadIdx.x & 63;
     float* stage = stage_all + (threadIdx.x >> 6) * (64 * KS);
     int32_t* sidx = sidx_all + (threadIdx.x >> 6) * 64;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, tid);
     Ray r;
     bool alive = q < rays.Q;
     if constexpr (GATHER) {
@@ -520,11 +780,11 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 light_ray = __uint_as_float(a.z);
                 skip_pass1 = true;
                 if constexpr (XF) {
-                    if (nrec > 0) last_idx = (int32_t)rec_get(rec + ((int64_t)(nrec - 1) * rays.Q + q)).x;
+                    if (nrec > 0) last_idx = (int32_t)rec_get(rec + rec_index(tid, nrec - 1, S)).x;
                 }
             } else {
                 for (int k = 0; k < nrec; ++k) {
-                    const uint2 e = rec_get(rec + ((int64_t)k * rays.Q + q));
+                    const uint2 e = rec_get(rec + rec_index(tid, k, S));
                     float row[K];
                     load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
                     if constexpr (XF) { rotated_sh_basis<BD>(tr, (int32_t)e.x, vd, basis); last_idx = (int32_t)e.x; }
@@ -546,7 +806,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                     if constexpr (!REPLAY) {
                         if (S > 0) {
                             if (nrec < S) {
-                                rec_put(rec + ((int64_t)nrec * rays.Q + q), (uint32_t)s.idx, s.delta_t);
+                                rec_stage_put(rstage, (int)threadIdx.x, rec, tid, S, nrec, (uint32_t)s.idx, s.delta_t);
                                 ++nrec;
                             } else if (tmax2 < 0.f) {   // list full: pass 2 marches from this step on
                                 t_resume = t;
@@ -573,6 +833,9 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         if constexpr (XF) {
             if (last_idx >= 0) rotated_sh_basis<BD>(tr, last_idx, vd, basis_last);
         }
+        if constexpr (!REPLAY) {
+            if (S > 0) rec_stage_finish(rstage, (int)threadIdx.x, rec, tid, S, nrec);
+        }
     }
 
     // pass 2, wave-synchronous: replay the recorded samples, then (rays with
@@ -585,7 +848,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         // lane-independent: no wavefront-wide synchronisation while walking the list
         if (alive) {
             for (; k < nrec; ++k) {
-                uint2* slot = rec + ((int64_t)k * rays.Q + q);
+                uint2* slot = rec + rec_index(tid, k, S);
                 const uint2 e = rec_get(slot);
                 float row[K];
                 load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
@@ -621,7 +884,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         float delta_t = 0.f;
         float row[K];
         if (k < nrec) {
-            const uint2 e = rec_get(rec + ((int64_t)k * rays.Q + q));
+            const uint2 e = rec_get(rec + rec_index(tid, k, S));
             ++k;
             idx = (int32_t)e.x;
             delta_t = __uint_as_float(e.y);
@@ -752,7 +1015,7 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
             c_n[u] = v4f{0.f, 0.f, 0.f, 0.f};
             d_n[u] = v4f{0.f, 0.f, 0.f, 0.f};
             if (kb + u < nrec) {
-                e_n[u] = rec_get(rec + ((int64_t)(kb + u) * rays.Q + q));
+                e_n[u] = rec_get(rec + rec_index((int64_t)blockIdx.x * 64 + lane, kb + u, S));
                 c_n[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(kb + u) * rays.Q + q)));
                 if constexpr (XF)
                     d_n[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(S + kb + u) * rays.Q + q)));
@@ -923,7 +1186,7 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
 template <int FMT, int BD>
 __global__ void __launch_bounds__(512)
 grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
-                  const uint2* __restrict__ rec, const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
+                  const uint2* __restrict__ rec, int S, const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
                   float* __restrict__ grad, int gstride) {
     constexpr int C = 3, W = 8, NT = 64 * W, T = 1024, R = 1024, RPP = R / (64 * W);
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
@@ -993,7 +1256,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             const int k = kb + wave;
             const int slot = (rd * W + wave) * 64 + lane;
             if (k < nrec) {
-                const uint2 e = rec_get(rec + ((int64_t)k * rays.Q + q));
+                const uint2 e = rec_get(rec + rec_index((int64_t)blockIdx.x * 64 + lane, k, S));
                 float row[K];
                 load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
                 float att, tc, cf[C];
@@ -1378,7 +1641,9 @@ template <bool N2, bool REC = false>
 __global__ void __launch_bounds__(kBlock)
 opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
                    uint2* __restrict__ rec = nullptr, int S = 0, uint4* __restrict__ aux = nullptr) {
-    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+    __shared__ uint2 rstage[REC ? kRecBlock * kBlock : 1];
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, tid);
     if (q >= rays.Q) return;
     Ray r;
     if (!setup_ray(tr, rays, opt, q, r)) {
@@ -1399,7 +1664,7 @@ opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
             if (sigma > opt.sigma_thresh) {
                 if constexpr (REC) {
                     if (nrec < S) {
-                        rec_put(rec + ((int64_t)nrec * rays.Q + q), (uint32_t)s.idx, s.delta_t);
+                        rec_stage_put(rstage, (int)threadIdx.x, rec, tid, S, nrec, (uint32_t)s.idx, s.delta_t);
                         ++nrec;
                     } else if (!over) {
                         over = true;
@@ -1415,9 +1680,11 @@ opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
         t = march_advance(t, s.delta_t);
     }
     out[q] = 1.f - light;
-    if constexpr (REC)
+    if constexpr (REC) {
+        rec_stage_finish(rstage, (int)threadIdx.x, rec, tid, S, nrec);
         aux[q] = make_uint4((uint32_t)nrec | (over ? kRecOverflow : 0u), __float_as_uint(t_resume),
                             __float_as_uint(light), 0u);
+    }
 }
 
 // opacity_render_backward from recorded lists (C = 0 of trace_ray_backward,
@@ -1431,8 +1698,9 @@ opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
 template <bool N2>
 __global__ void __launch_bounds__(kBlock)
 opacity_walk_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
-                    float* __restrict__ grad, int gstride, uint2* __restrict__ rec, uint4* __restrict__ aux) {
-    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+                    float* __restrict__ grad, int gstride, uint2* __restrict__ rec, int S, uint4* __restrict__ aux) {
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, tid);
     if (q >= rays.Q) return;
     const uint4 a = aux[q];
     const int nrec = (int)(a.x & ~kRecOverflow);
@@ -1444,7 +1712,7 @@ opacity_walk_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict_
     const float g = grad_out[q];
     float light = 1.f;
     for (int k = 0; k < nrec; ++k) {
-        uint2* slot = rec + ((int64_t)k * rays.Q + q);
+        uint2* slot = rec + rec_index(tid, k, S);
         const uint2 e = rec_get(slot);
         const float delta_t = __uint_as_float(e.y);
         const float sigma = tr.features[(int64_t)(int32_t)e.x * K + (K - 1)];
@@ -1478,7 +1746,7 @@ opacity_walk_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict_
 // record is cheap, 28 were not), flushed after every pass of at most T records.
 template <int T, int W>
 __global__ void __launch_bounds__(64 * W)
-opacity_merge_kernel(RaysDev rays, const uint2* __restrict__ rec, const uint4* __restrict__ aux,
+opacity_merge_kernel(RaysDev rays, const uint2* __restrict__ rec, int S, const uint4* __restrict__ aux,
                      float* __restrict__ grad, int gstride, int col) {
     constexpr int NT = 64 * W;
     constexpr int kGroup = 2, kRound = kGroup * W, RPP = T / (64 * kRound);
@@ -1509,7 +1777,7 @@ opacity_merge_kernel(RaysDev rays, const uint2* __restrict__ rec, const uint4* _
 #pragma unroll
             for (int u = 0; u < kGroup; ++u) {
                 e[u] = make_uint2(0u, 0u);
-                if (kb + u < nrec) e[u] = rec_get(rec + ((int64_t)(kb + u) * rays.Q + q));
+                if (kb + u < nrec) e[u] = rec_get(rec + rec_index((int64_t)blockIdx.x * 64 + lane, kb + u, S));
             }
 #pragma unroll
             for (int u = 0; u < kGroup; ++u) {
@@ -1907,6 +2175,14 @@ namespace {
 
 inline unsigned nblocks(int64_t Q) { return (unsigned)((Q + kBlock - 1) / kBlock); }
 
+// sample lists: rec[tile][block of 8][lane][8], 8 bytes per record (rec_index)
+inline int64_t rec_rays(int64_t Q) { return (Q + 63) / 64 * 64; }
+inline int64_t rec_capacity(int64_t bytes, int64_t Q) {       // records per ray that fit: a multiple of 8, at most 4096
+    if (bytes <= 0 || Q <= 0) return 0;
+    int64_t S = bytes / (8 * rec_rays(Q)) / kRecBlock * kRecBlock;
+    return S > 4096 ? 4096 : S;
+}
+
 // Specialised payloads: (format, C, BD) with all components selected.
 struct Payload { int fmt, C, BD; };
 
@@ -1992,6 +2268,62 @@ bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
     return false;
 }
 
+// two-kernel forward (march_rec_kernel + shade_tile_kernel + tail launch of render_fwd_kernel):
+// 3-channel payloads, all components.  SVOXT_FWD_SPLIT=1 selects it; the default is the
+// one-kernel forward (r02, 800x800 depth-8 SH9: 0.247 ms against 0.156 + 0.123 ms).
+bool fwd_split_enabled() {      // read per call: tests and timing scripts compare the two forwards in one process
+    const char* e = getenv("SVOXT_FWD_SPLIT");
+    return e != nullptr && atoi(e) != 0;
+}
+
+bool fwd_split_payload(const svoxt_tree* t, const svoxt_options* o, int C) {
+    if (C != 3 || t->weight_accum != nullptr) return false;
+    if (o->format == SVOXT_FORMAT_RGBA) return t->K == 4;
+    if (o->format != SVOXT_FORMAT_SH || t->K != 3 * o->basis_dim + 1) return false;
+    return o->basis_dim == 1 || o->basis_dim == 4 || o->basis_dim == 9 || o->basis_dim == 16 || o->basis_dim == 25;
+}
+
+template <bool N2, bool STOP>
+bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out,
+                      uint2* rec, int S, uint4* aux, bool xf, hipStream_t st) {
+    const unsigned nb = nblocks(rays.Q);
+    if (xf && !N2) return false;
+    if (N2 && tr.accel != nullptr)
+        hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 1>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, rec, S, aux);
+    else
+        hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 0>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, rec, S, aux);
+#define SVOXT_SPLIT(F, BB, X)                                                                                 \
+    {                                                                                                         \
+        hipLaunchKernelGGL((shade_tile_kernel<F, BB, X, STOP>), dim3(nb), dim3(512), 0, st, tr, rays, opt,    \
+                           rec, S, aux, out);                                                                 \
+        hipLaunchKernelGGL((render_fwd_kernel<F, 3, BB, N2, false, X, true>), dim3(nb), dim3(kBlock), 0, st,  \
+                           tr, rays, opt, out, (uint2*)nullptr, S, aux);                                      \
+        return true;                                                                                          \
+    }
+    if (opt.format == FMT_RGBA) SVOXT_SPLIT(FMT_RGBA, 0, false)
+    if constexpr (N2) {
+        if (xf) {
+            switch (opt.basis_dim) {
+                case 1: SVOXT_SPLIT(FMT_SH, 1, true)
+                case 4: SVOXT_SPLIT(FMT_SH, 4, true)
+                case 9: SVOXT_SPLIT(FMT_SH, 9, true)
+                case 16: SVOXT_SPLIT(FMT_SH, 16, true)
+                case 25: SVOXT_SPLIT(FMT_SH, 25, true)
+            }
+            return false;
+        }
+    }
+    switch (opt.basis_dim) {
+        case 1: SVOXT_SPLIT(FMT_SH, 1, false)
+        case 4: SVOXT_SPLIT(FMT_SH, 4, false)
+        case 9: SVOXT_SPLIT(FMT_SH, 9, false)
+        case 16: SVOXT_SPLIT(FMT_SH, 16, false)
+        case 25: SVOXT_SPLIT(FMT_SH, 25, false)
+    }
+#undef SVOXT_SPLIT
+    return false;
+}
+
 // two-kernel backward: SH 1/4/9 (also with view rotations) and RGBA with 3 channels
 // (K <= 32) on N = 2 trees
 bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
@@ -2009,13 +2341,13 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
         hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
                            tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out, (float4*)nullptr);   \
         hipLaunchKernelGGL((grad_fused_kernel<F, BB>), dim3(nb), dim3(512), 0, st,                            \
-                           tr, rays, opt, grad_out, rec, aux, fwd_out, grad, gstride);                        \
+                           tr, rays, opt, grad_out, rec, S, aux, fwd_out, grad, gstride);                     \
         return true;                                                                                          \
     }                                                                                                         \
     hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
                        tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out, coef);                   \
     hipLaunchKernelGGL((grad_merge_kernel<F, BB, 1024, 1024, 4>), dim3(nb), dim3(256), 0, st, tr, rays,      \
-                       grad_out, rec, coef, aux, grad, gstride);                                              \
+                       grad_out, rec, coef, aux, grad, gstride, S);                                           \
     return true;
 #define SVOXT_GATHER_XF(BB)                                                                                       \
     hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, true, true, true>), dim3(nb), dim3(kBlock), 0, st, \
@@ -2103,8 +2435,7 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
     if (xf && lists != nullptr && !(full_comp(opt) && xform_special(tree, opt)))
         return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists with transformation_matrices need an SH payload on an N = 2 tree", fn);
     if (C > 0 && full_comp(opt) && xf && xform_special(tree, opt)) {
-        int64_t S = (workspace != nullptr && workspace_bytes > 0) ? workspace_bytes / (8 * rays->Q) : 0;
-        if (S > 4096) S = 4096;
+        const int64_t S = workspace != nullptr ? rec_capacity(workspace_bytes, rays->Q) : 0;
         if (lists != nullptr) {
             const int64_t need = (int64_t)lists->max_samples * rays->Q * 32;
             if (lists->coef != nullptr && tree->K <= 32 && lists->coef_bytes >= need)
@@ -2121,8 +2452,7 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
     } else if (C > 0 && full_comp(opt) && !xf)
     {
         // per-ray sample lists: S entries of 8 bytes per ray, laid out rec[k][q]
-        int64_t S = (workspace != nullptr && workspace_bytes > 0) ? workspace_bytes / (8 * rays->Q) : 0;
-        if (S > 4096) S = 4096;
+        const int64_t S = workspace != nullptr ? rec_capacity(workspace_bytes, rays->Q) : 0;
         uint2* rec = S > 0 ? reinterpret_cast<uint2*>(workspace) : nullptr;
         if (lists != nullptr) {
             uint2* lrec = reinterpret_cast<uint2*>(lists->rec);
@@ -2177,15 +2507,16 @@ int svoxt_out_data_dim(const svoxt_options* opt, int32_t K) {
 
 static int check_lists(const svoxt_sample_lists* l, const svoxt_options* opt, const char* fn) {
     if (l == nullptr) return fail(SVOXT_ERR_INVALID, "%s: lists is NULL", fn);
-    if (l->rec == nullptr || l->aux == nullptr || l->max_samples < 1 || l->max_samples > 4096)
-        return fail(SVOXT_ERR_INVALID, "%s: lists need rec, aux and 1 <= max_samples <= 4096", fn);
+    if (l->rec == nullptr || l->aux == nullptr || l->max_samples < 8 || l->max_samples > 4096 || l->max_samples % 8 != 0)
+        return fail(SVOXT_ERR_INVALID, "%s: lists need rec, aux and max_samples a multiple of 8 in [8, 4096]", fn);
     if (opt->sigma_thresh != 0.f || opt->stop_thresh != 0.f)
         return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists require sigma_thresh == stop_thresh == 0", fn);
     return SVOXT_OK;
 }
 
 static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt, float* out,
-                      const svoxt_sample_lists* lists, void* stream, const char* fn) {
+                      const svoxt_sample_lists* lists, void* stream, const char* fn,
+                      void* workspace = nullptr, int64_t workspace_bytes = 0) {
     int rc;
     if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) || (rc = check_opts(opt, tree, fn, true)))
         return rc;
@@ -2204,6 +2535,25 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
     const Opts od = to_dev(opt);
     const bool n2 = tree->N == 2;
     bool done = false;
+    // two kernels (march, shade per tile) where there is room for the lists: the caller's,
+    // or scratch (then the stop rule applies while marching -- those lists serve no backward)
+    if (fwd_split_enabled() && full_comp(opt) && fwd_split_payload(tree, opt, C) &&
+        (!uses_xform(tree, opt) || xform_special(tree, opt))) {
+        const bool xf = uses_xform(tree, opt);
+        if (lists != nullptr) {
+            uint2* rec = reinterpret_cast<uint2*>(lists->rec);
+            uint4* aux = reinterpret_cast<uint4*>(lists->aux);
+            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, rec, lists->max_samples, aux, xf, st)
+                      : launch_fwd_split<false, false>(tr, rd, od, out, rec, lists->max_samples, aux, xf, st);
+        } else if (workspace != nullptr && rec_capacity(workspace_bytes - rec_rays(rays->Q) * 16, rays->Q) >= kRecBlock) {
+            const int64_t S = rec_capacity(workspace_bytes - rec_rays(rays->Q) * 16, rays->Q);
+            uint4* aux = reinterpret_cast<uint4*>(workspace);                       // aux first: rec stays 64-byte aligned
+            uint2* rec = reinterpret_cast<uint2*>(reinterpret_cast<char*>(workspace) + rec_rays(rays->Q) * 16);
+            done = n2 ? launch_fwd_split<true, true>(tr, rd, od, out, rec, (int)S, aux, xf, st)
+                      : launch_fwd_split<false, true>(tr, rd, od, out, rec, (int)S, aux, xf, st);
+        }
+        if (done) return check_launch(fn);
+    }
     if (uses_xform(tree, opt)) {
         // per-leaf view rotations re-evaluate the basis per sample: specialised for SH
         // payloads on N = 2 trees, the generic kernel otherwise
@@ -2237,6 +2587,19 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
 int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
                             const svoxt_options* opt, float* out, void* stream) {
     return fwd_common(tree, rays, opt, out, nullptr, stream, "svoxt_volume_render_fwd");
+}
+
+int64_t svoxt_fwd_workspace_bytes(int64_t Q, int32_t max_samples) {
+    if (Q < 0 || max_samples < 1 || max_samples > 4096) return -1;
+    return rec_rays(Q) * (16 + (int64_t)((max_samples + 7) / 8 * 8) * 8);
+}
+
+int svoxt_volume_render_fwd_ws(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
+                               float* out, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (workspace_bytes < 0) return fail(SVOXT_ERR_INVALID, "%s: negative workspace size", "svoxt_volume_render_fwd_ws");
+    if (workspace != nullptr && ((uintptr_t)workspace & 63u) != 0)
+        return fail(SVOXT_ERR_INVALID, "%s: workspace must be 64-byte aligned", "svoxt_volume_render_fwd_ws");
+    return fwd_common(tree, rays, opt, out, nullptr, stream, "svoxt_volume_render_fwd_ws", workspace, workspace_bytes);
 }
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt) {
@@ -2344,9 +2707,9 @@ int svoxt_opacity_render_bwd_replay(const svoxt_tree* tree, const svoxt_rays* ra
     const RaysDev rd = to_dev(rays);
     uint2* rec = reinterpret_cast<uint2*>(lists->rec);
     uint4* aux = reinterpret_cast<uint4*>(lists->aux);
-    if (tree->N == 2) hipLaunchKernelGGL((opacity_walk_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), rd, to_dev(opt), grad_out, grad_features, gs, rec, aux);
-    else hipLaunchKernelGGL((opacity_walk_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), rd, to_dev(opt), grad_out, grad_features, gs, rec, aux);
-    hipLaunchKernelGGL((opacity_merge_kernel<1024, 4>), dim3(nb), dim3(256), 0, st, rd, rec, aux, grad_features, gs, (int)tree->K - 1);
+    if (tree->N == 2) hipLaunchKernelGGL((opacity_walk_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), rd, to_dev(opt), grad_out, grad_features, gs, rec, lists->max_samples, aux);
+    else hipLaunchKernelGGL((opacity_walk_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), rd, to_dev(opt), grad_out, grad_features, gs, rec, lists->max_samples, aux);
+    hipLaunchKernelGGL((opacity_merge_kernel<1024, 4>), dim3(nb), dim3(256), 0, st, rd, rec, lists->max_samples, aux, grad_features, gs, (int)tree->K - 1);
     return check_launch(fn);
 }
 
@@ -2422,7 +2785,7 @@ int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
 
 int64_t svoxt_bwd_workspace_bytes(int64_t Q, int32_t max_samples) {
     if (Q < 0 || max_samples < 0) return -1;
-    return Q * (int64_t)max_samples * 8;
+    return rec_rays(Q) * (int64_t)((max_samples + 7) / 8 * 8) * 8;
 }
 
 int64_t svoxt_query_leaves_workspace_bytes(int64_t n_slots) {

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_C.EXPORTS)          # the ctypes table and the header agree
-    assert lib.svoxt_abi_version() == _C.ABI_VERSION == 9
+    assert lib.svoxt_abi_version() == _C.ABI_VERSION == 10
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -73,7 +73,7 @@ def test_validation_codes_without_touching_the_gpu():
     # sample lists combine with per-leaf view rotations only for SH payloads on N = 2 trees
     o = _C._COptions(format=1, basis_dim=4, min_comp=0, max_comp=3)
     r = _C._CRays(Q=0)
-    l = _C._CLists(rec=p, aux=p, max_samples=4)
+    l = _C._CLists(rec=p, aux=p, max_samples=8)
     assert lib.svoxt_volume_render_fwd_record(ctypes.byref(t), ctypes.byref(r), ctypes.byref(o), None,
                                               ctypes.byref(l), None) == 2       # SVOXT_ERR_UNSUPPORTED
     assert lib.svoxt_can_record(ctypes.byref(t), ctypes.byref(o)) == 0

@@ -235,3 +235,44 @@ def test_two_kernel_backward_extreme_coherence(gpu, kind):
     out.backward(g.to(gpu))
     gw, ab = O.volume_render_backward(c.oracle_tree(), o.numpy(), d.numpy(), v.numpy(), c.oracle_opts(), g.numpy(), want_abs=True)
     assert_grads_close(tree.features.grad.cpu().numpy(), gw, ab)
+
+
+
+@pytest.mark.parametrize("name", ["d5_rgba4", "d5_sh9", "d5_sh4_world", "d4_sh16"])
+def test_two_kernel_forward_equals_one_kernel_forward(name, gpu, monkeypatch):
+    """SVOXT_FWD_SPLIT=1 (march_rec_kernel + shade_tile_kernel + tail launch, through
+    svoxt_volume_render_fwd_ws and svoxt_volume_render_fwd_record) against the one-kernel forward:
+    outputs bit-identical with thresholds 0 and 1e-2, with lists long enough and too short (the tail
+    launch finishes the rays), as an image and as a plain batch; lists recorded either way give the
+    backward the same gradient."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd.renderer import _rays_spec_from_rays
+    c = Case(**CASES[name])
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    spec = tree._spec(tree.features)
+    rays = c.rays_gpu(gpu)
+    W = CASES[name]["width"]
+    for rs in (_rays_spec_from_rays(rays), _rays_spec_from_rays(rays, (c.Q // W, W))):
+        for fast in (False, True):
+            opt = r._get_options(fast=fast)
+            monkeypatch.setenv("SVOXT_FWD_SPLIT", "0")
+            want = _C.volume_render(spec, rs, opt)
+            monkeypatch.setenv("SVOXT_FWD_SPLIT", "1")
+            for S in (96, 8):
+                monkeypatch.setattr(_C, "FWD_LIST_SAMPLES", S)
+                assert torch.equal(_C.volume_render(spec, rs, opt), want), (name, fast, S)
+        opt = r._get_options()
+        g = torch.randn_like(want)
+        grads = {}
+        for split in ("0", "1"):
+            monkeypatch.setenv("SVOXT_FWD_SPLIT", split)
+            for S in (96, 8):
+                monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", S)
+                out, lists = _C.volume_render(spec, rs, opt, record=True)
+                assert lists is not None and torch.equal(out, want)
+                grads[(split, S)] = _C.volume_render_backward(spec, rs, opt, g, lists=lists, fwd_output=out)
+        ref = grads[("0", 96)]
+        scale = ref.abs().max().item()
+        for k, v in grads.items():
+            assert (v - ref).abs().max().item() <= 1e-5 * scale, k
