@@ -201,10 +201,10 @@ typedef struct svoxt_sample_lists {
                               leaves each sample's contribution in factored form in rec / coef (rec is
                               overwritten), and a second kernel adds them up per 8x8 tile in LDS, so a
                               gradient row goes to memory once per tile instead of once per sample. */
-    int64_t coef_bytes;    /* size of coef (a buffer too small for the route is ignored); -1 with coef NULL:
-                              take the per-tile route if it can run as ONE kernel (no view rotations,
-                              fwd_out given: list walk and merge fused, nothing goes through coef), else
-                              the one-kernel backward */
+    int64_t coef_bytes;    /* size of coef (a buffer too small for the route is ignored; a buffer that is given
+                              selects the two-kernel form); -1 with coef NULL: take the per-tile route if it
+                              can run as ONE kernel (no view rotations, fwd_out given: list walk and merge
+                              fused, nothing goes through coef), else the one-kernel backward */
 } svoxt_sample_lists;
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt);

@@ -178,15 +178,38 @@ def volume_render(tree: Tree, origins, dirs, vdirs, opt: RenderOptions, count=Fa
     return (out, Counters(*cnt.tolist())) if count else out
 
 
+def volume_render_weights(tree: Tree, origins, dirs, vdirs, opt: RenderOptions):
+    """volume_render with tree._weight_accum set (rt_kernel.cu:266-267,309-311; svox.py:948-969):
+    returns (out, weight_accum [n_internal, N, N, N] float64) -- per leaf slot, the sum of the
+    compositing weights of the samples taken in that leaf."""
+    assert tree.dtype == np.float32
+    o, d, v = _rays(tree, origins, dirs, vdirs)
+    Q = o.shape[0]
+    out = np.zeros((Q, out_data_dim(opt, tree.K)), dtype=np.float32)
+    wacc = np.zeros(tree.child.shape, dtype=np.float64)
+    lib().svoxt_oracle_volume_render_weights_f32(*tree._args(), _p(o), _p(d), _p(v), ctypes.c_int64(Q),
+                                                  ctypes.byref(opt), _p(out), _p(wacc))
+    return out, wacc
+
+
 def volume_render_backward(tree: Tree, origins, dirs, vdirs, opt: RenderOptions,
                            grad_output, want_abs=False):
-    """Returns grad [M, K] float64 (and sum |contribution| if want_abs)."""
+    """Returns grad [M, K] float64 (and sum |contribution| if want_abs; want_abs="both": also the
+    tighter scale that prices `accum` by the reference's own sequential addends, see
+    trace_ray_backward in svoxt_oracle.cpp -- (grad, abs_sum, abs_sum_tight))."""
     o, d, v = _rays(tree, origins, dirs, vdirs)
     g = _c(grad_output, tree.dtype)
     Q = o.shape[0]
     assert g.shape[0] == Q
     grad = np.zeros((tree.M, tree.K), dtype=np.float64)
     absum = np.zeros((tree.M, tree.K), dtype=np.float64) if want_abs else None
+    if want_abs == "both":
+        assert tree.dtype == np.float32
+        tight = np.zeros((tree.M, tree.K), dtype=np.float64)
+        lib().svoxt_oracle_volume_render_backward_scales_f32(
+            *tree._args(), _p(o), _p(d), _p(v), ctypes.c_int64(Q), ctypes.byref(opt),
+            _p(g), ctypes.c_int(g.shape[1]), _p(grad), _p(absum), _p(tight))
+        return grad, absum, tight
     fn = lib().svoxt_oracle_volume_render_backward_f32 if tree.dtype == np.float32 \
         else lib().svoxt_oracle_volume_render_backward_f64
     fn(*tree._args(), _p(o), _p(d), _p(v), ctypes.c_int64(Q), ctypes.byref(opt),

@@ -351,9 +351,14 @@ inline Step<T> march_step(const Tree<T>& tree, const RaySetup<T>& r,
 }
 
 // rt_kernel.cu:222-328
+// weight_accum (nullable, [n_internal * N^3] doubles): per leaf slot, the sum of the compositing
+// weights of the samples taken there -- `tree.weight_accum[node_id] += weight` with node_id the
+// packed leaf id query_single_from_root returns (rt_kernel.cu:266-267, :309-311; common.cuh:90-93).
+// The reference adds without atomics (it races); the sum is what it means.  Kept in
+// double so that it does not depend on the order of the rays.
 template <typename T>
 void trace_ray(const Tree<T>& tree, const RaySetup<T>& r, const RenderOptions& opt,
-               T* out, int out_data_dim, Counters* cnt) {
+               T* out, int out_data_dim, Counters* cnt, double* weight_accum = nullptr) {
     if (!r.hit) {
         for (int j = 0; j < out_data_dim; ++j) out[j] = opt.background_brightness;
         out[out_data_dim] = 0;
@@ -387,6 +392,10 @@ void trace_ray(const Tree<T>& tree, const RaySetup<T>& r, const RenderOptions& o
                     out[j] += weight / (1.0 + exp_T<T>(-s.row[j]));
             }
             light_intensity *= att;
+            if (weight_accum != nullptr) {             // :309-311, after the transmittance update
+#pragma omp atomic
+                weight_accum[s.slot] += (double)weight;
+            }
             if (light_intensity <= opt.stop_thresh) {
                 T scale = 1.0 / (1.0 - light_intensity);
                 for (int j = 0; j != out_data_dim; ++j) out[j] *= scale;
@@ -412,14 +421,20 @@ void trace_ray(const Tree<T>& tree, const RaySetup<T>& r, const RenderOptions& o
 template <typename T>
 void trace_ray_backward(const Tree<T>& tree, const RaySetup<T>& r, const RenderOptions& opt,
                         const T* grad_output, int out_data_dim,
-                        double* grad, double* abs_sum, bool atomic) {
+                        double* grad, double* abs_sum, bool atomic, double* abs_sum_tight = nullptr) {
     if (!r.hit) return;
     T basis_fn[25];
     precalc_basis<T>(opt.format, opt.basis_dim, tree, r.vdir, basis_fn);
     const int K = tree.K;
 
     // mag: magnitude of the terms that enter v before any cancellation
-    auto add = [&](int64_t e, T v, double mag) {
+    // abs_sum_tight: the same with the size of `accum` taken as the sum of |w_j * total_color_j| and
+    // |T * bg * sum_c g_c| -- the quantities the reference's own sequential pass 1 adds
+    // (rt_kernel.cu:428-436) -- i.e. what bounds a backward that forms accum the way the reference
+    // does (two walks: SVOXT_BWD_EXACT).  abs_sum takes the sum of |w_j * s_jc * g_c| and
+    // |T * bg * g_c| instead: what bounds ANY order of adding those products, e.g. accum formed as
+    // sum_c g_c * out_c from the forward's output (the single-march backward).
+    auto add = [&](int64_t e, T v, double mag, double mag_tight) {
         if (atomic) {
 #pragma omp atomic
             grad[e] += (double)v;
@@ -427,9 +442,14 @@ void trace_ray_backward(const Tree<T>& tree, const RaySetup<T>& r, const RenderO
 #pragma omp atomic
                 abs_sum[e] += mag;
             }
+            if (abs_sum_tight) {
+#pragma omp atomic
+                abs_sum_tight[e] += mag_tight;
+            }
         } else {
             grad[e] += (double)v;
             if (abs_sum) abs_sum[e] += mag;
+            if (abs_sum_tight) abs_sum_tight[e] += mag_tight;
         }
     };
 
@@ -438,6 +458,7 @@ void trace_ray_backward(const Tree<T>& tree, const RaySetup<T>& r, const RenderO
     // (w_j * s_jc * g_c and T * bg * g_c): the size its rounding error scales with,
     // whichever order the products are added in
     double accum_scale = 0.0;
+    double accum_scale_tight = 0.0;
     T light_intensity_ray = 0.0;
     {   // PASS 1 (:365-437)
         T light_intensity = 1.f, t = r.tmin;
@@ -462,7 +483,7 @@ void trace_ray_backward(const Tree<T>& tree, const RaySetup<T>& r, const RenderO
                         const T grad_sigmoid = sigmoid * (1.0 - sigmoid);
                         for (int i = opt.min_comp; i <= opt.max_comp; ++i) {
                             const T toadd = weight * basis_fn[i] * grad_sigmoid * grad_output[c];
-                            add(base + off + i, toadd, std::fabs((double)toadd));
+                            add(base + off + i, toadd, std::fabs((double)toadd), std::fabs((double)toadd));
                         }
                         total_color += sigmoid * grad_output[c];
                         color_mag += std::fabs((double)sigmoid * (double)grad_output[c]);
@@ -471,7 +492,7 @@ void trace_ray_backward(const Tree<T>& tree, const RaySetup<T>& r, const RenderO
                     for (int j = 0; j < out_data_dim; ++j) {
                         const T sigmoid = 1.0 / (1.0 + exp_T<T>(-s.row[j]));
                         const T toadd = weight * sigmoid * (1.f - sigmoid) * grad_output[j];
-                        add(base + j, toadd, std::fabs((double)toadd));
+                        add(base + j, toadd, std::fabs((double)toadd), std::fabs((double)toadd));
                         total_color += sigmoid * grad_output[j];
                         color_mag += std::fabs((double)sigmoid * (double)grad_output[j]);
                     }
@@ -479,6 +500,7 @@ void trace_ray_backward(const Tree<T>& tree, const RaySetup<T>& r, const RenderO
                 light_intensity *= att;
                 accum += weight * total_color;
                 accum_scale += std::fabs((double)weight) * color_mag;
+                accum_scale_tight += std::fabs((double)weight * (double)total_color);
             }
             t += s.delta_t;
         }
@@ -488,6 +510,7 @@ void trace_ray_backward(const Tree<T>& tree, const RaySetup<T>& r, const RenderO
         double grad_mag = 0.0;
         for (int j = 0; j < out_data_dim; ++j) grad_mag += std::fabs((double)grad_output[j]);
         accum_scale += std::fabs((double)light_intensity * opt.background_brightness) * grad_mag;
+        accum_scale_tight += std::fabs((double)light_intensity * opt.background_brightness * (double)total_grad);
         light_intensity_ray = light_intensity;
     }
     {   // PASS 2 (:439-494)
@@ -520,9 +543,9 @@ void trace_ray_backward(const Tree<T>& tree, const RaySetup<T>& r, const RenderO
                 // taken down again, so its rounding error scales with the sum of
                 // its addends (accum_scale), not with its current value
                 const double dd = std::fabs((double)s.delta_t * (double)r.delta_scale);
-                add(base + K - 1, toadd,
-                    dd * (std::fabs((double)total_color * (double)light_intensity) + accum_scale
-                          + std::fabs((double)grad_output[out_data_dim] * (double)light_intensity_ray)));
+                const double rest = std::fabs((double)total_color * (double)light_intensity)
+                                  + std::fabs((double)grad_output[out_data_dim] * (double)light_intensity_ray);
+                add(base + K - 1, toadd, dd * (rest + accum_scale), dd * (rest + accum_scale_tight));
             }
             t += s.delta_t;
         }
@@ -758,7 +781,7 @@ template <typename T>
 void render_impl(const T* features, int64_t M, int K, const int32_t* data, const int32_t* child,
                  int N, const T* offset, const T* scaling, const T* extra, int er, int ec,
                  const T* origins, const T* dirs, const T* vdirs, int64_t Q,
-                 const RenderOptions* opt, T* out, int64_t* counters5) {
+                 const RenderOptions* opt, T* out, int64_t* counters5, double* weight_accum = nullptr) {
     const Tree<T> tree = make_tree<T>(features, M, K, data, child, N, offset, scaling, extra, er, ec);
     const int od = get_out_data_dim(opt->format, opt->basis_dim, K);   // = C + 1
     int64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
@@ -766,7 +789,7 @@ void render_impl(const T* features, int64_t M, int K, const int32_t* data, const
     for (int64_t q = 0; q < Q; ++q) {
         Counters cnt = {0, 0, 0, 0, 0};
         const RaySetup<T> r = setup_ray<T>(tree, origins + 3 * q, dirs + 3 * q, vdirs + 3 * q);
-        trace_ray<T>(tree, r, *opt, out + q * od, od - 1, counters5 ? &cnt : nullptr);
+        trace_ray<T>(tree, r, *opt, out + q * od, od - 1, counters5 ? &cnt : nullptr, weight_accum);
         c0 += cnt.rays_hit; c1 += cnt.steps; c2 += cnt.levels; c3 += cnt.valid; c4 += cnt.active;
     }
     if (counters5) { counters5[0] = c0; counters5[1] = c1; counters5[2] = c2; counters5[3] = c3; counters5[4] = c4; }
@@ -777,10 +800,11 @@ void render_backward_impl(const T* features, int64_t M, int K, const int32_t* da
                           int N, const T* offset, const T* scaling, const T* extra, int er, int ec,
                           const T* origins, const T* dirs, const T* vdirs, int64_t Q,
                           const RenderOptions* opt, const T* grad_output, int grad_cols,
-                          double* grad, double* abs_sum) {
+                          double* grad, double* abs_sum, double* abs_sum_tight = nullptr) {
     const Tree<T> tree = make_tree<T>(features, M, K, data, child, N, offset, scaling, extra, er, ec);
     std::memset(grad, 0, sizeof(double) * (size_t)M * K);
     if (abs_sum) std::memset(abs_sum, 0, sizeof(double) * (size_t)M * K);
+    if (abs_sum_tight) std::memset(abs_sum_tight, 0, sizeof(double) * (size_t)M * K);
     int nthreads = 1;
 #ifdef _OPENMP
     nthreads = omp_get_max_threads();
@@ -790,7 +814,7 @@ void render_backward_impl(const T* features, int64_t M, int K, const int32_t* da
     for (int64_t q = 0; q < Q; ++q) {
         const RaySetup<T> r = setup_ray<T>(tree, origins + 3 * q, dirs + 3 * q, vdirs + 3 * q);
         trace_ray_backward<T>(tree, r, *opt, grad_output + q * grad_cols, grad_cols - 1,
-                              grad, abs_sum, atomic);
+                              grad, abs_sum, atomic, abs_sum_tight);
     }
 }
 
@@ -957,6 +981,16 @@ void svoxt_oracle_volume_render_f32(
                        origins, dirs, vdirs, Q, opt, out, counters5);
 }
 
+// ... with tree._weight_accum set (svox.py:948-969): weight_accum [n_internal * N^3], zeroed by the caller
+void svoxt_oracle_volume_render_weights_f32(
+    const float* features, int64_t M, int K, const int32_t* data, const int32_t* child, int N,
+    const float* offset, const float* scaling, const float* extra, int er, int ec,
+    const float* origins, const float* dirs, const float* vdirs, int64_t Q,
+    const RenderOptions* opt, float* out, double* weight_accum) {
+    render_impl<float>(features, M, K, data, child, N, offset, scaling, extra, er, ec,
+                       origins, dirs, vdirs, Q, opt, out, nullptr, weight_accum);
+}
+
 void svoxt_oracle_volume_render_f64(
     const double* features, int64_t M, int K, const int32_t* data, const int32_t* child, int N,
     const double* offset, const double* scaling, const double* extra, int er, int ec,
@@ -986,6 +1020,17 @@ void svoxt_oracle_volume_render_backward_f64(
     double* grad, double* abs_sum) {
     render_backward_impl<double>(features, M, K, data, child, N, offset, scaling, extra, er, ec,
                                  origins, dirs, vdirs, Q, opt, grad_output, grad_cols, grad, abs_sum);
+}
+
+// ... with both error scales (see trace_ray_backward): abs_sum and abs_sum_tight, [M, K] each
+void svoxt_oracle_volume_render_backward_scales_f32(
+    const float* features, int64_t M, int K, const int32_t* data, const int32_t* child, int N,
+    const float* offset, const float* scaling, const float* extra, int er, int ec,
+    const float* origins, const float* dirs, const float* vdirs, int64_t Q,
+    const RenderOptions* opt, const float* grad_output, int grad_cols,
+    double* grad, double* abs_sum, double* abs_sum_tight) {
+    render_backward_impl<float>(features, M, K, data, child, N, offset, scaling, extra, er, ec,
+                                origins, dirs, vdirs, Q, opt, grad_output, grad_cols, grad, abs_sum, abs_sum_tight);
 }
 
 // opacity_render (rt_kernel.cu:1574-1591).  out is [Q, 1].

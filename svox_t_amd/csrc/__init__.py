@@ -513,7 +513,7 @@ BWD_EXACT = os.environ.get("SVOXT_BWD_EXACT", "0") not in ("", "0")
 # merge in LDS -> one atomic row per tile and feature row, include/svoxt.h
 # svoxt_sample_lists.coef) for batches declared as images; 2: whenever the payload allows
 GATHER_ALIGNED = os.environ.get("SVOXT_GATHER_ALIGNED", "1") not in ("", "0")   # 64-byte-aligned rows for the merge kernel too
-BWD_FUSED = os.environ.get("SVOXT_BWD_FUSED", "1") not in ("", "0")   # 0: list walk and merge as two kernels (read by the library too)
+BWD_FUSED = os.environ.get("SVOXT_BWD_FUSED", "1") not in ("", "0")   # 0: list walk and merge as two kernels (a coef buffer is handed over)
 BWD_GATHER = int(os.environ.get("SVOXT_BWD_GATHER", "1") or 0)     # 0 never, 1 for image batches, 2 whenever possible
 
 

@@ -113,6 +113,18 @@ __device__ __forceinline__ void rec_stage_finish(const uint2* __restrict__ lds, 
     if (nrec & 7) rec_stage_flush(lds, lane, rec, tid, S, nrec & ~7);
 }
 
+// The packed leaf id (node * N^3 + u * N^2 + v * N + w, common.cuh:90-93) of the crossing at t, for
+// tree.weight_accum (rt_kernel.cu:266-267, 309-311).  The acceleration grid does not carry it
+// for leaves it resolves by itself (slot = ~0): those take the root descent -- only for samples
+// that are composited, i.e. for the few coarse leaves that hold data.
+template <bool N2>
+__device__ __forceinline__ uint32_t leaf_slot(const TreeDev& tr, const Ray& r, float t, uint32_t slot) {
+    if (slot != 0xffffffffu) return slot;
+    Leaf lf;
+    locate<N2>(tr, r.ox + t * r.dx, r.oy + t * r.dy, r.oz + t * r.dz, lf);
+    return lf.slot;
+}
+
 // XF (SH only): per-leaf view rotations (tree.xform): the basis is re-evaluated
 // for every composited sample with the leaf's matrix (rt_kernel.cu:283-291).
 // RESUME (tail launch of the two-kernel forward, see shade_tile_kernel): only rays whose sample
@@ -214,7 +226,7 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
                         acc[j] = (float)((double)acc[j] + (double)weight / (1.0 + (double)pexpf(-row[j])));
                 }
                 light *= att;
-                if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + slot, weight);
+                if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + leaf_slot<N2>(tr, r, t_cur, slot), weight);
                 if constexpr (!REC) {
                     if (light <= opt.stop_thresh) { stopped = true; break; }
                 }
@@ -284,7 +296,7 @@ render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __re
                         o[j] = (float)((double)o[j] + (double)weight / (1.0 + (double)pexpf(-row[j])));
                 }
                 light *= att;
-                if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + s.leaf.slot, weight);
+                if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + leaf_slot<N2>(tr, r, t, s.leaf.slot), weight);
                 if (light <= opt.stop_thresh) {
                     const float scale = (float)(1.0 / (1.0 - (double)light));
                     for (int j = 0; j < C; ++j) o[j] *= scale;
@@ -2143,8 +2155,7 @@ TreeDev to_dev(const svoxt_tree* t) {
     d.weight_accum = t->weight_accum;
     d.xform = t->xform;   // consulted by the generic render kernels only
     d.xform_dim = t->xform_dim == 4 ? 4 : 3;
-    // the grid caches data words but not slot ids: per-slot weight accumulation takes the plain descent
-    const bool use_accel = t->accel != nullptr && t->N == 2 && t->weight_accum == nullptr;
+    const bool use_accel = t->accel != nullptr && t->N == 2;
     d.accel = use_accel ? reinterpret_cast<const uint2*>(t->accel) : nullptr;
     d.accel_g = use_accel ? t->accel_log2 : 0;
     return d;
@@ -2331,8 +2342,10 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
                        const float* fwd_out, float4* coef, bool xf, hipStream_t st) {
     if (C != 3) return false;
     const unsigned nb = nblocks(rays.Q);
-    static const bool fused_on = [] { const char* e = getenv("SVOXT_BWD_FUSED"); return e == nullptr || atoi(e) != 0; }();
-    const bool fused = fused_on && !xf && fwd_out != nullptr;
+    // a caller that hands over a coef buffer asks for the two-kernel form; without one (coef_bytes < 0)
+    // the per-tile route runs if it can run as ONE kernel.  (The choice is the caller's alone: the
+    // Python layer reads SVOXT_BWD_FUSED, the library reads no environment for this.)
+    const bool fused = coef == nullptr && !xf && fwd_out != nullptr;
     if (!fused && coef == nullptr) return false;            // the two-kernel form needs its buffer
     // four wavefronts per tile and tables of 1024 (measured: one wavefront per tile 0.41 ms,
     // two 0.33, four 0.30 before step 15; tables of 512 / 256 cost more passes than they buy)

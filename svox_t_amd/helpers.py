@@ -103,7 +103,9 @@ class N3TreeView:
 
     @property
     def lengths_local(self):
-        return 2.0 ** (-self.depths.float() - 1.0)
+        # leaf side N^-(depth + 1).  The reference writes 2.0 ** (...) (helpers.py:164,176), which is
+        # this for the N = 2 trees it is used with and wrong for any other branching factor.
+        return float(self.tree.N) ** (-self.depths.float() - 1.0)
 
     @property
     def lengths(self):

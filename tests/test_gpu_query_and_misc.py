@@ -128,6 +128,37 @@ def test_component_subrange_and_sg_format(gpu):
     assert_grads_close(f.grad.cpu().numpy(), want, absum)
 
 
+def test_asg_format(gpu):
+    """Anisotropic spherical gaussians (maybe_precalc_basis FORMAT_ASG, rt_kernel.cu:118-130, marked
+    untested there): basis_i = S * exp(-lambda dot_x^2 - mu dot_y^2) / basis_dim from extra_data rows
+    [lambda, mu, x(3), y(3), z(3)] -- forward bit-exact vs the oracle, gradient within tolerance,
+    and the basis values themselves against a float64 evaluation of the formula."""
+    g = torch.Generator().manual_seed(5)
+    B = 5
+    frames = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0]                 # orthonormal lobe frames
+    lobes = torch.cat([torch.rand(B, 2, generator=g) * 3 + 0.3, frames.reshape(B, 9)], -1).contiguous()
+    cs = Case(depth=4, K=3 * B + 1, data_format=f"ASG{B}", width=40, height=40)
+    assert (cs.format, cs.basis_dim) == (O.FORMAT_ASG, B)
+    t = svox.N3Tree.from_arrays(cs.st.child, cs.st.data, cs.st.parent_depth, cs.features,
+                                data_format=f"ASG{B}", extra_data=lobes, device=gpu)
+    rs = svox.VolumeRenderer(t)
+    f = t.features
+    out = rs(f, cs.rays_gpu(gpu))
+    ot = O.Tree(cs.features.numpy(), cs.st.data, cs.st.child, extra=lobes.numpy())
+    opt = O.make_options(format=O.FORMAT_ASG, basis_dim=B)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O.volume_render(ot, *cs.rays_np(), opt))
+    gout = synth.grad_output(cs.Q, 4)
+    out.backward(gout.to(gpu))
+    want, absum = O.volume_render_backward(ot, *cs.rays_np(), opt, gout.numpy(), want_abs=True)
+    assert_grads_close(f.grad.cpu().numpy(), want, absum)
+    assert np.abs(want[:, :-1]).max() > 0
+    # the oracle's basis against the formula in float64
+    d = cs.vdirs.numpy().astype(np.float64)[:200]
+    L = lobes.numpy().astype(np.float64)
+    ref = (d @ L[:, 8:11].T) * np.exp(-L[:, 0] * (d @ L[:, 2:5].T) ** 2 - L[:, 1] * (d @ L[:, 5:8].T) ** 2) / B
+    np.testing.assert_allclose(O.basis(O.FORMAT_ASG, B, cs.vdirs.numpy()[:200], extra=lobes.numpy()), ref, rtol=2e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("Q", [0, 1, 63, 257])
 def test_ragged_and_empty_ray_batches(gpu, Q):
     c = Case(depth=4, K=4, data_format="RGBA", width=32, height=32)
@@ -180,6 +211,55 @@ def test_weight_accumulation(gpu):
     assert (w[empty] == 0).all()
 
 
+@pytest.mark.parametrize("name", ["d5_rgba4", "d6_sh9", "random2", "random3"])
+@pytest.mark.parametrize("accel", ["grid", "plain"])
+def test_weight_accumulation_matches_oracle(gpu, name, accel, monkeypatch):
+    """tree._weight_accum (rt_kernel.cu:266-267, 309-311; svox.py:948-969) per leaf slot against the
+    oracle's double-precision sums: every weight is bit-identical, so the only difference is the
+    order of the float atomics -- bounded by 1e-6 of the slot's sum (the weights are positive).
+    With the acceleration grid (which resolves coarse leaves without their slot id: the kernel
+    recovers it by the root descent) and without; on the shell trees, and on random trees whose
+    coarse leaves hold data; with and without early termination; N = 2 and 3."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd.renderer import _rays_spec_from_rays
+    monkeypatch.setenv("SVOXT_ACCEL_LOG2", "0" if accel == "plain" else "5")
+    if name.startswith("random"):
+        from tests.test_gpu_random_stress import random_rays, random_tree
+        N = int(name[-1])
+        t, feats = random_tree(7, N=N, max_depth=6 if N == 2 else 3, data_format="SH4", K=13)
+        n = t.n_internal
+        o, d, v = random_rays(107, 6000, t)
+        fmt, bd = svox.DataFormat("SH4").format, 4
+        ot = O.Tree(feats.numpy(), t.data[:n].numpy().copy(), t.child[:n].numpy().copy(),
+                    offset=t.offset.numpy().copy(), scaling=t.invradius.numpy().copy())
+        tree = t.to(gpu)           # nn.Module.to moves the buffers in place: host copies were taken above
+        features = feats.to(gpu)
+        rays = svox.Rays(o.to(gpu), d.to(gpu), v.to(gpu))
+        rays_np = (o.numpy(), d.numpy(), v.numpy())
+    else:
+        cfg = dict(d5_rgba4=dict(depth=5, K=4, data_format="RGBA", width=64, height=64),
+                   d6_sh9=dict(depth=6, K=28, data_format="SH9", width=96, height=96))[name]
+        c = Case(**cfg)
+        tree, ot = c.tree(gpu), c.oracle_tree()
+        features = tree.features
+        fmt, bd = c.format, c.basis_dim
+        rays, rays_np = c.rays_gpu(gpu), c.rays_np()
+    r = svox.VolumeRenderer(tree)
+    for fast in (False, True):
+        th = 1e-2 if fast else 0.0
+        with torch.no_grad(), tree.accumulate_weights() as acc:
+            out = r(features, rays, fast=fast)
+            got = acc.value.double().cpu().numpy()
+        want_out, want = O.volume_render_weights(ot, *rays_np, O.make_options(format=fmt, basis_dim=bd,
+                                                                               sigma_thresh=th, stop_thresh=th))
+        np.testing.assert_array_equal(out.cpu().numpy(), want_out)
+        want = want[:got.shape[0]]
+        assert got.shape == want.shape
+        assert (got[want == 0] == 0).all()                      # exactly the slots the oracle touches
+        assert want.sum() > 0
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
+
+
 # ------------------------------------------------------------ full-size configs
 @pytest.fixture(scope="module")
 def cfg3():
@@ -222,6 +302,52 @@ def test_config3_backward_full_size(cfg3, gpu):
     out2 = r(tree.features, c.rays_gpu(gpu))
     out2.backward(2 * gout.to(gpu))
     assert_grads_close(tree.features.grad.cpu().numpy(), 2 * want, 2 * absum)
+
+
+def test_config3_backward_relative_error_both_routes(cfg3, gpu, monkeypatch, capsys):
+    """What "1e-5 relative" holds for at full size, route by route.
+
+    (a) SVOXT_BWD_EXACT (two list walks, accum added up sequentially like the reference's pass 1,
+        rt_kernel.cu:365-437): every entry within 1e-5 of the TIGHT scale -- accum priced by
+        |w_j * total_color_j| and |T * bg * sum g|, the scale that was in force before the
+        single-march backward existed.
+    (b) the default single-march route (accum = sum_c g_c * out_c from the forward's output):
+        within 1e-5 of the sum-of-elementary-magnitudes scale (any order of adding them).
+    For both, the plain elementwise criterion |got - want| <= 1e-5 |want| is REPORTED and
+    bounded: it cannot hold for every entry of any float-atomic backward, the reference's
+    included -- an entry that is the small difference of large contributions has |want| far
+    below the rounding error of its own sum.  Thresholds: at most 2 % of the sigma entries and
+    0.5 % of the colour entries off (measured r02: see DESIGN.md 4), and the two routes within
+    a factor 1.5 of each other -- i.e. the single march is no worse than float-atomic
+    reordering already is."""
+    c = cfg3
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    gout = synth.grad_output(c.Q, 4)
+    want, absum, tight = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), gout.numpy(),
+                                                   want_abs="both")
+    assert (tight <= absum * (1 + 1e-5) + 1e-300).all()      # |sum| <= sum|.|, up to the float rounding of total_color
+    stats = {}
+    for route, exact in (("exact", True), ("single-march", False)):
+        monkeypatch.setattr(_C, "BWD_EXACT", exact)
+        tree.features.grad = None
+        out = r(tree.features, c.rays_gpu(gpu), image_shape=(800, 800))
+        out.backward(gout.to(gpu))
+        got = tree.features.grad.double().cpu().numpy()
+        assert_grads_close(got, want, tight if exact else absum, what=route)
+        err = np.abs(got - want)
+        touched = absum > 0
+        sig = np.zeros_like(touched); sig[:, -1] = True
+        off = err > 1e-5 * np.abs(want)
+        stats[route] = (float(off[touched & sig].mean()), float(off[touched & ~sig].mean()),
+                        float((err / (tight + 1e-300))[touched].max()))
+    with capsys.disabled():
+        for k, (fs, fc, worst) in stats.items():
+            print(f"\n[cfg3 backward, {k}] entries with |err| > 1e-5 |want|: sigma column {fs:.4%}, "
+                  f"colour columns {fc:.4%}; worst |err| / tight scale {worst:.2e}")
+    for k, (fs, fc, _) in stats.items():
+        assert fs <= 0.02 and fc <= 0.005, (k, fs, fc)
+    assert stats["single-march"][0] <= 1.5 * stats["exact"][0] + 1e-4
 
 
 def test_config4_depth9_features32_and_depth(gpu):

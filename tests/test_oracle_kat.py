@@ -210,3 +210,31 @@ def test_counters_and_algorithmic_bytes():
     assert cnt.levels <= cnt.steps * 5                   # depth-5 tree: at most 5 child reads per step
     bf = O.algorithmic_bytes_forward(cnt, c.Q, 4, 3)
     assert bf == c.Q * 52 + 4 * (cnt.levels + cnt.steps + cnt.valid) + 12 * cnt.active
+
+
+def test_weight_accum_and_error_scales_of_the_oracle():
+    """oracle.volume_render_weights (rt_kernel.cu:266-267, 309-311): every compositing weight lands
+    in exactly one leaf slot, so the slot sums add up to the rays' alpha (thresholds 0), internal
+    and empty slots stay 0, and the rendered rows are volume_render's.  volume_render_backward's
+    two error scales: the tight one (accum priced by the reference's sequential addends) never
+    exceeds the sum-of-elementary-magnitudes one, and both cover |grad|."""
+    from tests.util import Case
+    from svox_t_amd import synth
+    c = Case(depth=5, K=13, data_format="SH4", width=48, height=48)
+    ot, rays, opt = c.oracle_tree(), c.rays_np(), c.oracle_opts()
+    out, w = O.volume_render_weights(ot, *rays, opt)
+    np.testing.assert_array_equal(out, O.volume_render(ot, *rays, opt))
+    assert w.shape == ot.child.shape and w.min() >= 0
+    assert abs(w.sum() - out[:, 3].astype(np.float64).sum()) <= 1e-5 * w.sum()
+    assert (w[ot.child != 0] == 0).all()
+    assert (w[(ot.data.reshape(ot.child.shape) >= ot.M) | (ot.data.reshape(ot.child.shape) < 0)] == 0).all()
+    # early termination drops the weights behind the stopping sample
+    _, wf = O.volume_render_weights(ot, *rays, c.oracle_opts(fast=True))
+    assert wf.sum() < w.sum() and (wf <= w + 1e-12).all()
+    g = synth.grad_output(c.Q, 4).numpy()
+    grad, loose, tight = O.volume_render_backward(ot, *rays, opt, g, want_abs="both")
+    grad2, loose2 = O.volume_render_backward(ot, *rays, opt, g, want_abs=True)
+    np.testing.assert_array_equal(grad, grad2)
+    np.testing.assert_allclose(loose, loose2, rtol=1e-12)
+    assert (tight <= loose * (1 + 1e-5)).all() and (np.abs(grad) <= tight * (1 + 1e-5) + 1e-30).all()
+    assert (tight[:, :-1] == loose[:, :-1]).all() and (tight[:, -1] < loose[:, -1]).any()
