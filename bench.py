@@ -2,23 +2,27 @@
 """Headline benchmark: Mrays/s of volume_render forward + backward on synthetic
 800x800 renders of the depth-8 SH9 shell tree (BASELINE.json configs[2]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ...] [--forward-only] [--route plain]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one ray batch: VolumeRenderer.forward
-on Q = 800*800 rays followed by backward() of a fixed upstream gradient, i.e.
-volume_render + volume_render_backward through the autograd.Function surface.
-Inputs (tree topology, feature table, rays, upstream gradient) are resident in
-HBM before the timed region.  With N > 1 every rank holds a replica of the tree
-and renders its own camera (weak scaling: per-GPU work fixed); each step ends
-with the exchange a data-parallel caller needs: RCCL all-reduce(sum) of the
-feature gradient and all-gather of the rendered pixels.
+A "step" is one pass of the hot path over one ray batch: VolumeRenderer.forward on Q = W*H rays
+followed by backward() of a fixed upstream gradient, i.e. volume_render + volume_render_backward
+through the autograd.Function surface.  Inputs (tree topology, feature table, rays, upstream
+gradient) are resident in HBM before the timed region.  With N > 1 every rank holds a replica of
+the tree and renders its own camera (weak scaling: per-GPU work fixed); the gradient all-reduce of
+a step runs on a side stream, in row chunks, under the next step's forward, and the pixels are
+gathered while the backward runs (svox_t_amd/parallel.py).
 
-Prints ONE JSON line on rank 0 (contract in the task statement), including
-`roofline` (algorithmic bytes of the dominant kernel / its mean duration,
-against the 8 TB/s HBM peak) and `cpu_baseline` (the CPU oracle on the same
-workload, host cores).
+Prints ONE JSON line on rank 0 (contract in the task statement).  `roofline` prices the bytes
+THIS implementation cannot avoid moving to and from memory for the dominant kernel group (what
+the algorithm as run reads and writes once: rays, pixels, sample records, the distinct feature
+rows and tree words touched, the memset, the atomic requests, the row compaction -- counted on
+the device before the timed region) against the 8 TB/s HBM peak; `reference_equivalent_gbps`
+keeps SURVEY.md 8(d)'s figure for the reference's algorithm (three marches, 8 B per gradient
+float) next to it.  The working set of configs 1-3 lives in the 256 MiB Infinity Cache, so
+`limits` names what actually bounds each kernel.  `cpu_baseline`: the CPU oracle on the same
+workload, host cores.
 """
 from __future__ import annotations
 
@@ -35,31 +39,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-
-# Memory-side traffic of the two hot kernels, from separate rocprofv3 --pmc passes
-# of this same command (scripts/pmc_passes.sh -> scripts/pmc_summary.py), committed
-# under profiles/.  FETCH_SIZE / WRITE_SIZE are KiB per dispatch.
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_s_pmc.json")
-
-
-def pmc_traffic(which):
-    """(bytes per launch, note) for kernel "fwd" / "bwd", or (None, reason)."""
-    try:
-        with open(PMC_FILE) as f:
-            counters = json.load(f)["counters"]
-        c = counters[which]
-        raw = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-        if which == "bwd":                              # the backward is several kernels
-            for extra in ("merge", "fused", "compact"):
-                if extra in counters:
-                    raw += (counters[extra]["FETCH_SIZE"] + counters[extra]["WRITE_SIZE"]) * 1024.0
-        return int(raw), ("(FETCH_SIZE + WRITE_SIZE) * 1024 from " + os.path.relpath(PMC_FILE, ROOT) +
-                          "; TCC_EA0 requests, Infinity-Cache hits included; gfx950 FETCH_SIZE reads 1/2 of a wide "
-                          "coalesced stream and is uncalibrated for these 4-16 B gathers (true read part: 1-2x); "
-                          "WRITE_SIZE counts a 64 B request per partial line (scattered 8 B records, 112 B atomic rows)")
-    except Exception as exc:   # no profile committed for this build
-        return None, f"no PMC summary ({exc.__class__.__name__})"
-
+# exp/atomic_bench.hip: the memory side takes 64-byte float-atomic requests at
+# ~22 G/s whatever their size or scope (3.0 M wave-atomics of two segments each: 0.614 ms)
+ATOMIC_REQUESTS_PER_S = 22e9
+# us per leaf crossing of a wavefront alone on its SIMD: r02 timeline of march_rec_kernel
+# (exp/trace_march.py, profiles/r02_march_timeline.txt) for the stepping alone; r01 timeline of
+# render_fwd_kernel ("Timelines") for stepping + shading in one chain
+US_PER_CROSSING_UNLOADED = {"march": 0.72, "march+shade": 1.14}
 
 WORKLOADS = {
     # name: (depth, K, data_format, width, height)
@@ -69,8 +55,30 @@ WORKLOADS = {
 }
 
 
-def algorithmic_bytes(cnt, Q, M, K, C):
-    """SURVEY.md 8(d).  cnt = (rays_hit, steps S, levels sum L, valid, active)."""
+def pmc_traffic(workload, forward_only, group):
+    """(bytes per launch group, note) from this round's committed rocprofv3 --pmc passes of the same
+    command (scripts/pmc_passes.sh -> scripts/pmc_summary.py), or (None, reason)."""
+    name = f"r02_{workload}{'_fwd' if forward_only else ''}_pmc.json"
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        with open(path) as f:
+            counters = json.load(f)["counters"]
+        ks = {"forward": ("fwd", "march", "shade"), "backward": ("bwd", "fused", "merge", "wide", "compact")}[group]
+        fetch = sum(counters[k]["FETCH_SIZE"] for k in ks if k in counters) * 1024.0
+        write = sum(counters[k]["WRITE_SIZE"] for k in ks if k in counters) * 1024.0
+        if fetch + write == 0:
+            return None, f"no kernel of the {group} group in profiles/{name}"
+        return int(2 * fetch + write), (
+            f"(2 x FETCH_SIZE + WRITE_SIZE) x 1024 from profiles/{name} (separate --pmc passes of this command): "
+            "MI355X_MICROARCH.md 'HBM': gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes -- doubled; "
+            "WRITE_SIZE exact for streaming stores and float atomics.  Memory-side requests of the L2s: "
+            "Infinity-Cache hits are included, so this bounds HBM bytes from above")
+    except Exception as exc:   # no profile committed for this build / workload
+        return None, f"no PMC summary profiles/{name} ({exc.__class__.__name__})"
+
+
+def reference_equivalent_bytes(cnt, Q, M, K, C):
+    """the bytes of the REFERENCE's algorithm.  cnt = (rays_hit, steps S, levels sum L, valid, active)."""
     _, S, L, V, A = cnt
     march = 4 * L + 4 * S + 4 * V + 4 * (K - 1) * A
     fwd = Q * (36 + 4 * (C + 1)) + march
@@ -84,7 +92,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="d8_sh9_800", choices=list(WORKLOADS))
+    ap.add_argument("--route", default="hinted", choices=["hinted", "plain"],
+                    help="hinted: VolumeRenderer.forward(..., image_shape=(H, W)); plain: exactly the two calls the "
+                         "reference's own autograd function makes on the operator module (no hint, no extra argument)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plain", action="store_true", help="skip the extra plain-route measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for dry runs")
     ap.add_argument("--share-device", action="store_true",
                     help="dry run: put every rank on cuda:0 (to rehearse the N>1 code path on a 1-GPU box)")
@@ -114,7 +126,7 @@ def main():
 
     import svox_t_amd as svox
     import svox_t_amd.csrc as _C
-    from svox_t_amd import synth
+    from svox_t_amd import parallel, synth
     from svox_t_amd.renderer import _rays_spec_from_rays
 
     depth, K, fmt, W, H = WORKLOADS[args.workload]
@@ -133,44 +145,80 @@ def main():
     C = _C.get_out_data_dim(opt, K) - 1
     gout = synth.grad_output(Q, C + 1).to(dev)
 
-    cnt = _C.count_forward(tree._spec(features), _rays_spec_from_rays(rays), opt).cpu().tolist()
-    bytes_fwd, bytes_bwd = algorithmic_bytes(cnt, Q, M, K, C)
+    class _ReferenceShaped(torch.autograd.Function):
+        """svox_t/renderer.py:60-77: the two calls the reference's own function makes."""
 
-    gathered = None
-    if dist is not None:
-        gathered = torch.empty((world * Q, C + 1), dtype=torch.float32, device=dev)
+        @staticmethod
+        def forward(ctx, data, tspec, rspec, ropt):
+            out = _C.volume_render(tspec, rspec, ropt)
+            ctx.tree, ctx.rays, ctx.opt = tspec, rspec, ropt
+            return out
 
+        @staticmethod
+        def backward(ctx, grad_out):
+            return _C.volume_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out.contiguous()), None, None, None
+
+    def render(route):
+        if route == "plain":
+            rs = _C.RaysSpec()
+            rs.origins, rs.dirs, rs.vdirs = rays.origins, rays.dirs, rays.viewdirs
+            return _ReferenceShaped.apply(features, tree._spec(features), rs, opt)
+        return renderer(features, rays, image_shape=(H, W))
+
+    # ---- one-off device-side counts (before the timed region) -------------------------------
+    rs_hint = _rays_spec_from_rays(rays, (H, W))
+    rs_hint.need_grad = False
+    spec = tree._spec(features)
+    cnt = _C.count_forward(spec, rs_hint, opt).cpu().tolist()
+    touched = _C.count_touched(spec, rs_hint, opt)
+    atomic_requests = merged_rows = rays_with_samples = None
+    if not args.forward_only:
+        with _C.bwd_counters(dev) as ctr:
+            features.grad = None
+            render(args.route).backward(gout)
+            torch.cuda.synchronize()
+        atomic_requests, merged_rows = ctr.read()
+        features.grad = None
+    reducer = parallel.OverlappedGradReducer(dist, backend=args.backend) if dist is not None else None
+    gathered = torch.empty((world * Q, C + 1), dtype=torch.float32, device=dev) if dist is not None else None
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
 
-    def step(i=None):
-        features.grad = None
+    def step(i=None, route=args.route):
         e = ev[i] if i is not None else None
+        features.grad = None              # (a gradient still travelling is held by the reducer)
         if e: e[0].record()
         if args.forward_only:
             with torch.no_grad():                              # inference: nothing is recorded for a backward
-                out = renderer(features, rays, image_shape=(H, W))
+                out = render(route)
         else:
-            out = renderer(features, rays, image_shape=(H, W))   # the batch is an H x W render
+            out = render(route)
         if e: e[1].record()
         gather = None
         if dist is not None:
             # the pixels are final after the forward: gather them while the backward runs
-            if args.backend == "nccl":
-                gather = dist.all_gather_into_tensor(gathered, out.detach(), async_op=True)
-            else:   # gloo dry run
-                dist.all_gather(list(gathered.chunk(world)), out.detach())
+            gather = parallel.gather_pixels_async(dist, gathered, out.detach(), backend=args.backend)
         if not args.forward_only:
             out.backward(gout)
         if e: e[2].record()
         if dist is not None:
             if not args.forward_only:
-                dist.all_reduce(features.grad)
+                # gradient accumulation over batches: the previous batch's reduced gradient is complete
+                # here; this batch's travels (side stream, row chunks) under the next batch's work
+                reducer.start(features.grad)
             if gather is not None:
                 gather.wait()
         return out
 
+    # Setup, not measurement: the first process on a fresh box has been seen to run its first
+    # dozens of steps far below steady state (allocator growth, code-object loads, clocks).
+    # Bring the device there before the W warm-up steps the contract asks for.
+    for _ in range(30):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
+    if reducer is not None:
+        reducer.wait()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -178,6 +226,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    if reducer is not None:
+        reducer.wait()                    # the last gradient is reduced inside the timed region
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -188,19 +238,72 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    route_fwd, route_bwd = _C.LAST_ROUTE["forward"], (None if args.forward_only else _C.LAST_ROUTE["backward"])
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     bwd_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+
+    # the other route, for the record (same process, after the timed region)
+    other = None
+    if world == 1 and not args.no_plain:
+        oroute = "plain" if args.route == "hinted" else "hinted"
+        for _ in range(3):
+            step(route=oroute)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(route=oroute)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / args.steps
+        other = {"route": oroute, "value": round(Q / dt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(dt * 1e3, 4),
+                 "what": ("the two calls the reference's own autograd function makes (svox_t/renderer.py:60-77) on "
+                          "svox_t_amd.csrc: no image hint; the operator layer orders the rays, records and replays "
+                          "the sample lists by itself" if oroute == "plain" else
+                          "VolumeRenderer.forward(..., image_shape=(H, W))")}
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * Q / (elapsed / args.steps) / 1e6
+        ref_fwd, ref_bwd = reference_equivalent_bytes(cnt, Q, M, K, C)
+        A = cnt[4]
+        stride = K if (K <= 8 or K % 16 == 0) else (K + 15) // 16 * 16
+        tree_bytes = 8 * (touched.get("grid_cells", 0) + touched.get("node_pairs", 0)) + \
+            4 * (touched.get("child_words", 0) + touched.get("data_words", 0))
+        recording = not args.forward_only
+        fwd_parts = {
+            "rays": 36 * Q, "pixels_written": 4 * (C + 1) * Q,
+            "feature_rows_read": 4 * K * touched["rows_valid"], "tree_words_read": tree_bytes,
+            "records_written": 8 * A if recording else 0, "aux_written": 16 * Q if recording else 0,
+        }
+        bwd_parts = None
+        if not args.forward_only:
+            bwd_parts = {
+                "grad_memset": 4 * M * stride, "upstream_gradient_read": 4 * (C + 1) * Q, "aux_read": 16 * Q,
+                "rays": 36 * cnt[0], "records_read": 8 * A, "feature_rows_read": 4 * K * touched["rows_composited"],
+                "atomic_requests_64B": 64 * atomic_requests if atomic_requests else 4 * K * A,
+                "row_compaction": (4 * M * stride + 4 * M * K) if stride != K else 0,
+            }
+        fwd_bytes = sum(fwd_parts.values())
+        bwd_bytes = sum(bwd_parts.values()) if bwd_parts else 0
         if args.forward_only or fwd_ms >= bwd_ms:
-            dom, dom_ms, dom_bytes = "render_fwd_kernel", fwd_ms, bytes_fwd
+            dom, dom_kernel, dom_ms, dom_bytes, dom_ref = "forward", route_fwd, fwd_ms, fwd_bytes, ref_fwd
         else:
-            dom, dom_ms, dom_bytes = "grad_fused_kernel (+ tail-only render_bwd_kernel, grad memset, row compaction)", bwd_ms, bytes_bwd
+            dom, dom_kernel, dom_ms, dom_bytes, dom_ref = "backward", route_bwd, bwd_ms, bwd_bytes, ref_bwd
+            dom_kernel += " + grad memset + row compaction"
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic, traffic_note = pmc_traffic("fwd" if dom.startswith("render_fwd") else "bwd") \
-            if args.workload == "d8_sh9_800" and world == 1 else (None, "PMC profile exists for the default workload at N=1 only")
+        traffic, traffic_note = pmc_traffic(args.workload, args.forward_only, dom) if world == 1 else \
+            (None, "PMC profiles exist for N=1 only")
+        chain = "march" if "march_rec" in (route_fwd or "") else "march+shade"
+        limits = {"forward": {
+            "bound": "dependent chain of the longest ray (tree words -> step -> next tree words), not bytes",
+            "longest_ray_crossings": touched["longest_ray_crossings"],
+            "us_per_crossing_unloaded": US_PER_CROSSING_UNLOADED[chain],
+            "floor_ms": round(touched["longest_ray_crossings"] * US_PER_CROSSING_UNLOADED[chain] * 1e-3, 4),
+            "measured_ms": round(fwd_ms, 4)}}
+        if atomic_requests:
+            limits["backward"] = {
+                "bound": "rate at which the memory side takes 64-byte float-atomic requests (exp/atomic_bench.hip: 22 G/s)",
+                "atomic_requests": atomic_requests, "merged_rows": merged_rows,
+                "floor_ms": round(atomic_requests / ATOMIC_REQUESTS_PER_S * 1e3, 4), "measured_ms": round(bwd_ms, 4)}
         res = {
             "metric": "Mrays/s fwd+bwd, 800×800 render, depth-8 SH9 N3Tree, 1→8 MI355X"
                       if args.workload == "d8_sh9_800" and not args.forward_only
@@ -222,27 +325,41 @@ def main():
                             f"{'forward' if args.forward_only else 'forward+backward'}, "
                             f"step_size 1e-3, thresholds 0",
                 "rays_per_gpu": Q,
+                "route": args.route,
+                "backward_arithmetic": None if args.forward_only else
+                ("exact (every contribution the reference's formula)" if _C.BWD_EXACT else "single march (SVOXT_BWD_EXACT=0)"),
                 "partitioning": "replicated tree, one camera (ray batch) per GPU"
-                                + ("; all-gather of pixels + all-reduce of grad per step" if world > 1 else ""),
+                                + ("; all-gather of pixels under the backward, all-reduce of grad in row chunks on a "
+                                   "side stream under the next step's forward" if world > 1 else ""),
             },
             "kernel_ms": {"forward": round(fwd_ms, 4), "backward": round(bwd_ms, 4)},
+            "kernels": {"forward": route_fwd, "backward": route_bwd},
             "counters": dict(zip(("rays_hit", "steps", "levels", "valid", "active"), cnt)),
-            "algorithmic_bytes": {"forward": bytes_fwd, "backward": bytes_bwd},
+            "touched": touched,
+            "compulsory_bytes": {"forward": fwd_parts, "backward": bwd_parts,
+                                 "step_total": fwd_bytes + bwd_bytes,
+                                 "step_gbps": round((fwd_bytes + bwd_bytes) / (ms_per_step * 1e-3) / 1e9, 2)},
             "roofline": {
                 "bound": "hbm",
-                "kernel": dom,
+                "kernel": dom_kernel,
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "traffic_note": traffic_note,
-                "achieved_note": "algorithmic bytes are SURVEY.md 8(d)'s figure for the reference's algorithm (for the "
-                                 "backward: two re-marches and 8 B per gradient float); this implementation replays "
-                                 "recorded sample lists and merges gradient rows per tile before they leave the CU, so "
-                                 "it moves far fewer bytes (see traffic) and the fraction can approach or pass 1",
+                "achieved_note": f"compulsory bytes of the {dom} as run (compulsory_bytes.{dom}: each item counted once, "
+                                 "distinct rows / tree words / atomic requests counted on the device) / its mean duration "
+                                 "from HIP events on the launch stream; the working set of this config sits in the 256 MiB "
+                                 "Infinity Cache, so the fraction of the HBM roofline is low by construction: see limits",
+                "reference_equivalent_gbps": round(dom_ref / (dom_ms * 1e-3) / 1e9, 2),
+                "reference_equivalent_note": "SURVEY.md 8(d): the bytes the REFERENCE's algorithm moves for the same result "
+                                             "(a tree march per pass, 8 B per gradient float) / this kernel group's time",
             },
+            "limits": limits,
         }
+        if other is not None:
+            res["other_route"] = other
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(st, feats, o, d, v, fmt, K, gout.cpu(), args.forward_only)
         print(json.dumps(res), flush=True)

@@ -288,6 +288,22 @@ int svoxt_query_bwd(const svoxt_tree* tree, const float* points, int64_t Q,
 int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
                     const svoxt_options* opt, int64_t* counters, void* stream);
 
+/* Instrumentation for the roofline (no counterpart in the reference): what ONE forward march of
+ * this ray batch touches.  row_mask: device [2 * M] bytes, pre-zeroed -- [idx] = 1 for every valid
+ * leaf's feature row (read by the forward), [M + idx] = 1 where a sample is composited (read again
+ * by the backward).  tree_mask: device bytes, pre-zeroed -- with tree->accel: [cell] for the grid
+ * cells and [n_cells + slot] for the (child, data) pairs read; without: [slot] for child words and
+ * [n_slots + slot] for data words (N = 2; other N: data words only).  longest: device int64,
+ * pre-zeroed <- the most leaf crossings of any ray.  The march is the production one. */
+int svoxt_count_touched(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
+                        uint8_t* row_mask, uint8_t* tree_mask, int64_t* longest, void* stream);
+
+/* Instrumentation: counters [2] (device int64, caller-zeroed) or NULL.  While set, the one-kernel
+ * per-tile backward (grad_fused_kernel) adds to counters[0] the number of 64-byte atomic requests it
+ * sends to the gradient table and to counters[1] the number of (tile, pass, feature row) groups they
+ * belong to.  Process-wide; meant for bench.py. */
+int svoxt_set_bwd_counters(int64_t* counters);
+
 /* Acceleration grid (no counterpart in the reference).  A 2^g x 2^g x 2^g table
  * that caches, per cell, where the root->leaf descent of common.cuh:63-100
  * stands after g levels (the leaf and its data word if it ended earlier), so a

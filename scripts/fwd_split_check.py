@@ -56,6 +56,7 @@ def both(name, rs, opt, record):
     for split in ("0", "1"):
         os.environ["SVOXT_FWD_SPLIT"] = split
         _C.FWD_LIST_SAMPLES = 96 if split == "1" else 0
+        rs.need_grad = False          # record=False means a forward nobody differentiates
         x = _C.volume_render(spec, rs, opt, record=record)
         torch.cuda.synchronize()
         res[split] = x

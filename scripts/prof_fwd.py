@@ -22,6 +22,7 @@ o, d, v = synth.pinhole_rays(W, H)
 rays = svox.Rays(o.to(dev), d.to(dev), v.to(dev))
 spec = tree._spec(tree.features)
 rsh = _rays_spec_from_rays(rays, (H, W))
+rsh.need_grad = False             # record=0: a forward nobody differentiates
 opt = r._get_options()
 for _ in range(n):
     _C.volume_render(spec, rsh, opt, record=record)

@@ -119,6 +119,8 @@ EXPORTS = {
     "svoxt_query_fwd": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "svoxt_query_bwd": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp, _vp, _vp]),
     "svoxt_count_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
+    "svoxt_count_touched": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp, _vp]),
+    "svoxt_set_bwd_counters": (ctypes.c_int, [_vp]),
     "svoxt_ray_order_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "svoxt_ray_order": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, ctypes.c_int64, _vp]),
     "svoxt_accel_bytes": (ctypes.c_int64, [_i32, ctypes.c_int64]),
@@ -157,9 +159,9 @@ class RaysSpec:
         # size; the kernels then walk it in 8x8 tiles.  0 = unknown.
         self.image_width = 0
         self.image_height = 0
-        # optional (not in the reference): ask the renderer to sort the batch (svoxt_ray_order) /
-        # the batch is in such an order
-        self.sort = False
+        # optional (not in the reference): render the batch in svoxt_ray_order's order (True / False;
+        # None = decide by size, SORT_RAYS below) / the batch already is in such an order
+        self.sort = None
         self.coherent = False
 
 
@@ -473,6 +475,109 @@ def ray_order(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tenso
     return perm.long()
 
 
+# ---------------------------------------------------------------------------
+# What a plain caller gets.  The reference's autograd functions call
+#     out  = _C.volume_render(tree, rays, opt)                         (renderer.py:63)
+#     grad = _C.volume_render_backward(tree, rays, opt, grad_out)      (renderer.py:72)
+# with the SAME spec objects (they sit on the ctx, renderer.py:64-66) and nothing else.  Everything
+# this implementation adds lives below these two calls: the forward of a differentiable feature
+# table records the sample lists, a batch that is not an image is rendered in svoxt_ray_order's
+# order, and both are left on the rays spec object for the backward that arrives with it -- which
+# then replays the lists (per-tile, one kernel) instead of marching.  A backward whose forward left
+# nothing (another spec object, features changed in place since, SVOXT_AUTO_PLAN=0) marches, as
+# the reference does.  The explicit forms (record=True / lists= / fwd_output=) remain.
+# ---------------------------------------------------------------------------
+AUTO_PLAN = os.environ.get("SVOXT_AUTO_PLAN", "1") not in ("", "0")
+# Batches that are not declared images are rendered in a coherent order (svoxt_ray_order,
+# include/svoxt.h: sort by the rays' entry points into the cube, three gathers, a scatter --
+# ~0.3 ms per 640 000 rays) from SORT_RAYS_MIN rays on, and their backward then takes the
+# per-tile route: 640 000 rays forward+backward, shuffled within one camera 1.47 -> 0.93 ms,
+# drawn from 8 cameras 1.48 -> 1.29 ms, row-major but not declared an image 1.29 -> 0.92 ms
+# (profiles/r01_s_ray_order_timing.txt).  SVOXT_SORT_RAYS=0 never, =1 always; RaysSpec.sort per call.
+SORT_RAYS = os.environ.get("SVOXT_SORT_RAYS", "auto")
+SORT_RAYS_MIN = 16384
+
+
+class _Plan:
+    """What a forward leaves on its rays / camera spec for the backward of the same call."""
+    __slots__ = ("features", "fver", "optkey", "lists", "out", "over", "perm", "rays")
+
+
+def _opt_key(opt):
+    return (float(opt.step_size), float(opt.background_brightness), int(opt.format), int(opt.basis_dim),
+            int(opt.ndc_width), int(opt.ndc_height), float(opt.ndc_focal), int(opt.min_comp), int(opt.max_comp),
+            float(opt.sigma_thresh), float(opt.stop_thresh))
+
+
+def _wants_sort(rays) -> bool:
+    if isinstance(rays, CameraSpec) or not isinstance(rays.origins, torch.Tensor) or rays.origins.dim() != 2:
+        return False                        # (a malformed spec: _pack_rays will say what is wrong)
+    Q = rays.origins.shape[0]
+    w, h = int(getattr(rays, "image_width", 0) or 0), int(getattr(rays, "image_height", 0) or 0)
+    if Q == 0 or (w * h == Q and w % 8 == 0 and h % 8 == 0) or getattr(rays, "coherent", False):
+        return False                        # an image is walked in 8x8 tiles: coherent as it stands
+    s = getattr(rays, "sort", None)
+    if s is None:
+        s = SORT_RAYS == "1" or (SORT_RAYS == "auto" and Q >= SORT_RAYS_MIN)
+    return bool(s)
+
+
+def _in_coherent_order(tree, rays, opt):
+    """(rays spec to render, perm): the batch gathered into svoxt_ray_order's order when that pays
+    (perm: sorted position -> position in the caller's batch), else as it is."""
+    if not _wants_sort(rays):
+        return rays, None
+    perm = ray_order(tree, rays, opt)
+    s = RaysSpec()
+    s.origins = rays.origins.index_select(0, perm)
+    s.dirs = rays.dirs.index_select(0, perm)
+    s.vdirs = rays.vdirs.index_select(0, perm)
+    s.sort = False
+    s.coherent = True           # neighbouring rays revisit the same leaves: the per-tile backward pays
+    return s, perm
+
+
+def _to_caller_order(out_sorted, perm):
+    if perm is None:
+        return out_sorted
+    out = torch.empty_like(out_sorted)
+    out[perm] = out_sorted
+    return out
+
+
+def _need_grad(tree, rays):
+    """Will a backward follow?  The caller's autograd function may say so (rays.need_grad, set by
+    this package's own functions from ctx.needs_input_grad); the reference's do not, and inside an
+    autograd.Function's forward grad mode is off either way: then the feature table decides."""
+    ng = getattr(rays, "need_grad", None)
+    return bool(tree.features.requires_grad) if ng is None else bool(ng)
+
+
+def _planned_forward(render, tree, rays, opt):
+    """render(tree, rays_spec, opt, record) -> (out, lists): the forward of a plain call."""
+    rr, perm = _in_coherent_order(tree, rays, opt)
+    if _need_grad(tree, rays):
+        out, lists = render(tree, rr, opt, True)
+        p = _Plan()
+        p.features, p.fver, p.optkey = tree.features, tree.features._version, _opt_key(opt)
+        p.lists, p.out, p.over, p.perm, p.rays = lists, out, out._version, perm, rr
+        rays._svoxt_plan = p
+    else:
+        out = render(tree, rr, opt, False)
+        rays._svoxt_plan = None
+    return _to_caller_order(out, perm)
+
+
+def _take_plan(tree, rays, opt):
+    p = getattr(rays, "_svoxt_plan", None)
+    if p is None:
+        return None
+    rays._svoxt_plan = None              # the lists serve one backward; a second one marches
+    if p.features is not tree.features or p.fver != tree.features._version or p.optkey != _opt_key(opt):
+        return None
+    return p
+
+
 def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bool = False):
     """rt_kernel.cu:1362-1379.
 
@@ -480,9 +585,22 @@ def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bo
     volume_render_backward can replay; the call then returns (out, lists), with
     lists = None when recording does not apply (non-zero thresholds, a payload
     without a specialised kernel, SVOXT_BWD_LIST=0)."""
+    if not record and AUTO_PLAN:
+        return _planned_forward(lambda t, r, o, rec: _volume_render(t, r, o, rec), tree, rays, opt)
+    return _volume_render(tree, rays, opt, record)
+
+
+# which kernels the last volume_render / volume_render_backward took (for bench.py's labels)
+LAST_ROUTE = {"forward": None, "backward": None}
+
+
+def _volume_render(tree, rays, opt, record):
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
     lists = None
+    split = os.environ.get("SVOXT_FWD_SPLIT", "0") not in ("", "0")
+    LAST_ROUTE["forward"] = ("march_rec_kernel + shade_tile_kernel (two-kernel forward)" if split
+                             else "render_fwd_kernel") + (", recording sample lists" if record else "")
     with torch.cuda.device(dev):
         out = torch.empty((cr.Q, get_out_data_dim(opt, ct.K)), dtype=torch.float32, device=dev)
         if record and BWD_LIST_SAMPLES > 0 and cr.Q > 0 and \
@@ -504,10 +622,14 @@ def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bo
     return (out, lists) if record else out
 
 
-# SVOXT_BWD_EXACT=1: never use the forward output in the backward (two list walks,
-# every contribution bit-identical to the reference formulas; ~0.2 ms slower on
-# the headline workload).
-BWD_EXACT = os.environ.get("SVOXT_BWD_EXACT", "0") not in ("", "0")
+# The backward's arithmetic.  Default (exact): `accum` and the ray's final transmittance are added
+# up sequentially over the ray's samples as the reference's first pass does (rt_kernel.cu:365-437),
+# every gradient contribution bit-identical to the reference's formulas.  SVOXT_BWD_EXACT=0 opts
+# into the single march: accum = sum_c g_c * out_c from the forward's output -- one sweep over the
+# lists instead of two (0.34 vs 0.43 ms on the headline workload, r02), equal up to the rounding of
+# that sum, which is enough to move 36 % of the sigma-column entries by more than 1e-5 of their own
+# value (tests/test_gpu_query_and_misc.py::test_config3_backward_relative_error_both_routes).
+BWD_EXACT = os.environ.get("SVOXT_BWD_EXACT", "1") not in ("", "0")
 # SVOXT_BWD_GATHER=0: always the one-kernel backward (every sample's row goes to memory as
 # shaped atomics); 1 (default): the two-kernel one (list walk -> factored records -> per-tile
 # merge in LDS -> one atomic row per tile and feature row, include/svoxt.h
@@ -523,7 +645,21 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
     """rt_kernel.cu:1402-1426.  `lists` (optional, not in the reference): what
     volume_render(..., record=True) returned for the same tree / rays / options;
     `fwd_output` (optional): the output of that forward, which saves the
-    backward its first pass (include/svoxt.h, svoxt_volume_render_bwd_replay)."""
+    backward its first pass (include/svoxt.h, svoxt_volume_render_bwd_replay).
+    Neither given: what the forward of the same spec objects left behind (see _Plan)."""
+    if lists is None and fwd_output is None and AUTO_PLAN:
+        p = _take_plan(tree, rays, opt)
+        if p is not None:
+            _check_input(grad_output, "grad_output")
+            g = grad_output if p.perm is None else grad_output.index_select(0, p.perm)
+            fo = p.out if (p.lists is not None and p.out._version == p.over) else None
+            if fo is not None and fo.dim() == 3:
+                fo = fo.view(-1, fo.shape[2])
+            return _volume_render_backward(tree, p.rays, opt, g, p.lists, fo)
+    return _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output)
+
+
+def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     _check_input(grad_output, "grad_output")
     if grad_output.dtype != torch.float32 or grad_output.dim() != 2 or grad_output.shape[0] != cr.Q:
@@ -555,19 +691,25 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
                 if fwd_output.shape != grad_output.shape or fwd_output.dtype != torch.float32:
                     raise RuntimeError("fwd_output must match grad_output")
                 fo = fwd_output
-            fused = gather and BWD_FUSED and ct.xform is None and fo is not None
+            fused = gather and BWD_FUSED and ct.xform is None      # (fo None: the fused kernel's exact form)
             if gather and not fused:
                 # with view rotations a second plane holds each sample's rotated direction
                 planes = 2 if ct.xform is not None else 1
                 lists.coef = torch.empty((planes * lists.S, cr.Q, 4), dtype=torch.float32, device=dev)
                 lists.consumed = True         # the two-kernel form rewrites rec
             cl = lists.c_struct()
+            LAST_ROUTE["backward"] = (
+                ("grad_fused_kernel<EXACT> (two sweeps over the lists + per-tile merge)" if fo is None else
+                 "grad_fused_kernel (one sweep over the lists + per-tile merge; accum from the forward's output)") if fused else
+                "render_bwd_kernel<GATHER> + grad_merge_kernel (list walk, then per-tile merge)" if gather else
+                "render_bwd_kernel<REPLAY> (list walk, one atomic row per sample)")
             if fused:
                 cl.coef_bytes = -1            # list walk and merge as one kernel: no buffer, rec stays as recorded
             _call("svoxt_volume_render_bwd_replay", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(grad_output), grad_output.shape[1], _ptr(buf), stride, ctypes.byref(cl), _ptr(fo),
                   _stream(dev))
         else:
+            LAST_ROUTE["backward"] = "render_bwd_kernel (marches, one atomic row per sample)"
             ws_bytes = _lib.svoxt_bwd_workspace_bytes(cr.Q, BWD_LIST_SAMPLES)
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes > 0 else None
             _call("svoxt_volume_render_bwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
@@ -585,7 +727,7 @@ def volume_render_image(tree: TreeSpec, cam: CameraSpec, opt: RenderOptions, rec
     rays (cam2world_ray, and maybe_world2ndc when opt.ndc_width >= 0) are generated
     inside the kernels.  (The reference's version cannot run: it allocates and
     dispatches on the int32 index tensor, :1390-1393.)"""
-    res = volume_render(tree, cam, opt, record=record)
+    res = volume_render(tree, cam, opt, record=record)      # (a plain call leaves its plan on `cam`)
     out = res[0] if record else res
     out = out.view(int(cam.height), int(cam.width), -1)
     return (out, res[1]) if record else out
@@ -617,6 +759,12 @@ def render_depth(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Te
 def opacity_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bool = False):
     """rt_kernel.cu:1574-1591.  `record=True` (not in the reference): also return the
     sample lists opacity_render_backward can walk (None when thresholds are non-zero)."""
+    if not record and AUTO_PLAN:
+        return _planned_forward(lambda t, r, o, rec: _opacity_render(t, r, o, rec), tree, rays, opt)
+    return _opacity_render(tree, rays, opt, record)
+
+
+def _opacity_render(tree, rays, opt, record):
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
     lists = None
@@ -636,7 +784,18 @@ def opacity_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: b
 def opacity_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
                             grad_output: torch.Tensor, lists: SampleLists = None) -> torch.Tensor:
     """rt_kernel.cu:1593-1616.  `lists` (optional, not in the reference): what
-    opacity_render(..., record=True) returned for the same tree / rays / options."""
+    opacity_render(..., record=True) returned for the same tree / rays / options; not given:
+    what the forward of the same spec objects left behind (see _Plan)."""
+    if lists is None and AUTO_PLAN:
+        p = _take_plan(tree, rays, opt)
+        if p is not None:
+            _check_input(grad_output, "grad_output")
+            g = grad_output if p.perm is None else grad_output.index_select(0, p.perm)
+            return _opacity_render_backward(tree, p.rays, opt, g, p.lists)
+    return _opacity_render_backward(tree, rays, opt, grad_output, lists)
+
+
+def _opacity_render_backward(tree, rays, opt, grad_output, lists):
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     _check_input(grad_output, "grad_output")
     if grad_output.dtype != torch.float32 or grad_output.numel() != cr.Q:
@@ -727,6 +886,47 @@ def count_forward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.T
         _call("svoxt_count_fwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
               _ptr(counters), _stream(dev))
     return counters
+
+
+def count_touched(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions):
+    """Roofline instrumentation (include/svoxt.h, svoxt_count_touched): what one forward march of
+    the batch touches.  Returns a dict of counts: feature rows read by the forward (valid leaves)
+    and again by the backward (composited samples), grid cells and (child, data) pairs (or child /
+    data words without the grid), and the most leaf crossings of any ray."""
+    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
+    dev = tree.features.device
+    n_slots = ct.n_internal * ct.N ** 3
+    with torch.cuda.device(dev):
+        rows = torch.zeros((2 * ct.M,), dtype=torch.uint8, device=dev)
+        n_cells = (1 << (3 * ct.accel_log2)) if ct.accel else 0
+        tmask = torch.zeros(((n_cells + n_slots) if ct.accel else 2 * n_slots,), dtype=torch.uint8, device=dev)
+        longest = torch.zeros((1,), dtype=torch.int64, device=dev)
+        _call("svoxt_count_touched", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co), _ptr(rows), _ptr(tmask),
+              _ptr(longest), _stream(dev))
+        first = n_cells if ct.accel else n_slots
+        res = {"rows_valid": int(rows[:ct.M].sum(dtype=torch.int64)), "rows_composited": int(rows[ct.M:].sum(dtype=torch.int64)),
+               "longest_ray_crossings": int(longest.item()), "accel": bool(ct.accel)}
+        a, b = int(tmask[:first].sum(dtype=torch.int64)), int(tmask[first:].sum(dtype=torch.int64))
+        res.update({"grid_cells": a, "node_pairs": b} if ct.accel else {"child_words": a, "data_words": b})
+    return res
+
+
+class bwd_counters:
+    """`with bwd_counters() as c: ...backward...; c.read()` -> (64-byte atomic requests, (tile, pass, row)
+    groups) of the one-kernel per-tile backwards run inside (svoxt_set_bwd_counters)."""
+
+    def __init__(self, device):
+        self.buf = torch.zeros((2,), dtype=torch.int64, device=device)
+
+    def __enter__(self):
+        _call("svoxt_set_bwd_counters", _ptr(self.buf))
+        return self
+
+    def __exit__(self, *exc):
+        _call("svoxt_set_bwd_counters", None)
+
+    def read(self):
+        return tuple(int(v) for v in self.buf.cpu().tolist())
 
 
 def motion_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions):

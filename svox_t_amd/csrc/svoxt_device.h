@@ -236,8 +236,10 @@ __device__ __forceinline__ void descend_generic(const TreeDev& tr, int32_t node,
 constexpr int kFixBits = 22;   // integer descent handles up to 22 levels
 
 // query_single_from_root (common.cuh:63-100) for a tree-space point.
-template <bool N2>
-__device__ __forceinline__ void locate(const TreeDev& tr, float px, float py, float pz, Leaf& lf) {
+// MARK (instrumentation, svoxt_count_touched): mark[slot] = 1 for every child word read
+template <bool N2, bool MARK = false>
+__device__ __forceinline__ void locate(const TreeDev& tr, float px, float py, float pz, Leaf& lf,
+                                       uint8_t* mark = nullptr) {
     px = fmaxf(0.f, fminf(kClampHi, px));
     py = fmaxf(0.f, fminf(kClampHi, py));
     pz = fmaxf(0.f, fminf(kClampHi, pz));
@@ -258,6 +260,7 @@ __device__ __forceinline__ void locate(const TreeDev& tr, float px, float py, fl
             const uint32_t cell = (((ux >> sh) & 1u) << 2) | (((uy >> sh) & 1u) << 1) | ((uz >> sh) & 1u);
             slot = ((uint32_t)node << 3) + cell;
             skip = tr.child[slot];
+            if constexpr (MARK) mark[slot] = 1;
             if (skip == 0 || k == kFixBits) break;
             node += skip;
         }
@@ -285,8 +288,10 @@ __device__ __forceinline__ void locate(const TreeDev& tr, float px, float py, fl
 // per level below the grid (none for the data word).
 constexpr uint32_t kAccelLeaf = 0x80000000u;
 
+// MARK: mark[cell] = 1 for the grid cell read, mark[n_cells + slot] = 1 for every (child, data) pair read
+template <bool MARK = false>
 __device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float py, float pz,
-                                             Leaf& lf, int32_t& idx) {
+                                             Leaf& lf, int32_t& idx, uint8_t* mark = nullptr) {
     px = fmaxf(0.f, fminf(kClampHi, px));
     py = fmaxf(0.f, fminf(kClampHi, py));
     pz = fmaxf(0.f, fminf(kClampHi, pz));
@@ -298,6 +303,7 @@ __device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float 
     const int gs = kFixBits - G;
     const uint32_t ci = ((((ux >> gs) << G) + (uy >> gs)) << G) + (uz >> gs);
     const uint2 cell = tr.accel[ci];
+    if constexpr (MARK) mark[ci] = 1;
     int k;
     uint32_t slot = 0xffffffffu;
     if (cell.y & kAccelLeaf) {
@@ -324,6 +330,7 @@ __device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float 
             const unsigned long long w64 = __hip_atomic_load(
                 reinterpret_cast<const unsigned long long*>(nodes + slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             cd = make_uint2((uint32_t)w64, (uint32_t)(w64 >> 32));
+            if constexpr (MARK) mark[((size_t)1 << (3 * G)) + slot] = 1;
             skip = (int32_t)cd.x;
             if (skip == 0 || k == kFixBits) break;
             node += skip;
@@ -357,9 +364,10 @@ struct Sample {
 // ACC: -1 = look at tr.accel at run time; 1 / 0 = the caller knows the acceleration grid is
 // there / is not (a kernel instance without the other descent: fewer registers, and no false
 // register hazards between the two paths' loads for the wait-count placement to trip over).
-template <bool N2, int ACC = -1>
+// MARK: see locate / locate_accel; without the grid the leaf's data word is mark[n_slots + slot].
+template <bool N2, int ACC = -1, bool MARK = false>
 __device__ __forceinline__ void march_step(const TreeDev& tr, const Ray& r, float step_size,
-                                           float t, Sample& s) {
+                                           float t, Sample& s, uint8_t* mark = nullptr, uint32_t n_slots = 0) {
     const float px = r.ox + t * r.dx;
     const float py = r.oy + t * r.dy;
     const float pz = r.oz + t * r.dz;
@@ -369,10 +377,11 @@ __device__ __forceinline__ void march_step(const TreeDev& tr, const Ray& r, floa
     Leaf lf;
     int32_t idx;
     if (N2 && (ACC == 1 || (ACC < 0 && tr.accel != nullptr))) {
-        locate_accel(tr, px, py, pz, lf, idx);   // leaf.slot / leaf.levels are not reference-accurate here
+        locate_accel<MARK>(tr, px, py, pz, lf, idx, mark);   // leaf.slot / leaf.levels are not reference-accurate here
     } else {
-        locate<N2>(tr, px, py, pz, lf);
+        locate<N2, MARK>(tr, px, py, pz, lf, mark);
         idx = tr.data[lf.slot];
+        if constexpr (MARK) mark[n_slots + lf.slot] = 1;
     }
     s.leaf = lf;
     s.idx = idx;

@@ -113,6 +113,12 @@ __device__ __forceinline__ void rec_stage_finish(const uint2* __restrict__ lds, 
     if (nrec & 7) rec_stage_flush(lds, lane, rec, tid, S, nrec & ~7);
 }
 
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
 // The packed leaf id (node * N^3 + u * N^2 + v * N + w, common.cuh:90-93) of the crossing at t, for
 // tree.weight_accum (rt_kernel.cu:266-267, 309-311).  The acceleration grid does not carry it
 // for leaves it resolves by itself (slot = ~0): those take the root descent -- only for samples
@@ -850,6 +856,15 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         }
     }
 
+    if constexpr (GATHER) {
+        // tail-only launch in front of grad_fused_kernel<..., EXACT>: an overflowed ray's pass 1
+        // (list + tail) is complete only here; its results travel in aux[q].z / .w
+        if (coef_out == nullptr && fwd_out == nullptr && alive && tmax2 >= 0.f) {
+            uint4* aw = const_cast<uint4*>(aux) + q;
+            aw->z = __float_as_uint(light_ray);
+            aw->w = __float_as_uint(accum);
+        }
+    }
     // pass 2, wave-synchronous: replay the recorded samples, then (rays with
     // unrecorded samples only) march the rest.
     float light = 1.f;
@@ -1195,11 +1210,21 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
 // (row, delta_t), coef is not used) and there is no separate list-walk kernel with its tail.
 // Operation for operation coef_sample(); rays whose list overflowed have their tail handled
 // by a tail-only launch of render_bwd_kernel<..., GATHER> in front.
-template <int FMT, int BD>
+// EXACT (fwd_out == NULL): nothing is taken from the forward's output.  A first sweep over the
+// lists -- the same division of labour: eight wavefronts form (att, total_color) of eight list
+// positions, wavefront 0 runs along the rays -- builds `accum` and the final transmittance exactly
+// as the reference's first pass does (rt_kernel.cu:365-437: total_color summed in float there, in
+// double in the second pass, :472-476 -- both are reproduced), so every gradient contribution is
+// bit-identical to the reference's formulas.  Without it (fwd_out given) accum = sum_c g_c out_c:
+// one sweep, but a third of the sigma entries then differ from the reference's by more than 1e-5
+// of their own value (r02, tests/test_gpu_query_and_misc.py) -- opt-in.
+// COUNT (instrumentation, svoxt_set_bwd_counters): counters[0] += 64-byte atomic requests sent,
+// counters[1] += (tile, pass, feature row) groups; the work itself is unchanged.
+template <int FMT, int BD, bool EXACT, bool COUNT = false>
 __global__ void __launch_bounds__(512)
 grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                   const uint2* __restrict__ rec, int S, const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
-                  float* __restrict__ grad, int gstride) {
+                  float* __restrict__ grad, int gstride, unsigned long long* __restrict__ counters = nullptr) {
     constexpr int C = 3, W = 8, NT = 64 * W, T = 1024, R = 1024, RPP = R / (64 * W);
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     constexpr int NB = (FMT == FMT_SH) ? BD : 0;
@@ -1232,7 +1257,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     Ray r;
     float basis[NB > 0 ? NB : 1], g[C + 1];
     float accum = 0.f, light = 1.f;
-    const float light_ray = __uint_as_float(a.z);
+    float light_ray = __uint_as_float(a.z);
     r.delta_scale = 0.f;
 #pragma unroll
     for (int j = 0; j <= C; ++j) g[j] = 0.f;
@@ -1246,9 +1271,11 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j <= C; ++j) g[j] = grad_out[q * (C + 1) + j];
         if (wave == 0) {
-            const float* o = fwd_out + q * (C + 1);          // see render_bwd_kernel: single march
+            if constexpr (!EXACT) {
+                const float* o = fwd_out + q * (C + 1);      // see render_bwd_kernel: single march
 #pragma unroll
-            for (int c = 0; c < C; ++c) accum += g[c] * o[c];
+                for (int c = 0; c < C; ++c) accum += g[c] * o[c];
+            }
 #pragma unroll
             for (int i = 0; i < NB; ++i) bases[lane * BDS + i] = basis[i];
 #pragma unroll
@@ -1257,6 +1284,62 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     }
     for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
     for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
+    if constexpr (EXACT) {
+        // ---- sweep 1: pass 1 of the reference without its atomics (accum_sample), W positions per
+        // round; r_w / r_sg carry (att, total_color) from the wavefront that formed them to wavefront 0,
+        // double-buffered by the parity of the round (one barrier per round)
+        float light1 = 1.f;
+        const int nr1 = (maxn + W - 1) / W;                  // the same in every wavefront
+        for (int rd = 0; rd <= nr1; ++rd) {
+            const int k = rd * W + wave;
+            if (rd < nr1 && k < nrec) {
+                const uint2 e = rec_get(rec + rec_index((int64_t)blockIdx.x * 64 + lane, k, S));
+                float row[K];
+                load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
+                const float att = pexpf<true>(-__uint_as_float(e.y) * row[K - 1] * r.delta_scale);
+                float total_color = 0.f;
+                if constexpr (FMT == FMT_SH) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        float tmp = 0.f;
+#pragma unroll
+                        for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
+                        total_color += (float)sigmoid_d<true>(tmp) * g[c];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < C; ++j) total_color += (float)sigmoid_d<true>(row[j]) * g[j];
+                }
+                const int sl = ((rd & 1) * W + wave) * 64 + lane;
+                r_w[sl] = att; r_sg[sl] = total_color;
+            }
+            if (wave == 0 && rd > 0) {
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    if ((rd - 1) * W + j < nrec) {
+                        const int sl = (((rd - 1) & 1) * W + j) * 64 + lane;
+                        const float att = r_w[sl];
+                        const float weight = light1 * (1.f - att);
+                        light1 *= att;
+                        accum += weight * r_sg[sl];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            if (a.x & kRecOverflow) {                        // list + tail: from the tail-only launch in front
+                light_ray = __uint_as_float(a.z);
+                accum = __uint_as_float(a.w);
+            } else {
+                float total_grad = 0.f;
+#pragma unroll
+                for (int j = 0; j < C; ++j) total_grad += g[j];
+                accum += light1 * opt.background_brightness * total_grad;
+                light_ray = light1;
+            }
+        }
+    }
     __syncthreads();
 
     for (int k0 = 0; k0 < maxn; k0 += RPP * W) {
@@ -1320,6 +1403,12 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         }
         __syncthreads();
         const int nb = __builtin_amdgcn_readfirstlane(s_nb);
+        if constexpr (COUNT) {          // distinct feature rows of this pass = occupied table slots
+            unsigned long long rows = 0;
+            for (int i = threadIdx.x; i < T; i += NT) rows += keys[i] >= 0 ? 1u : 0u;
+            rows = wave_sum(rows);
+            if (lane == 0 && rows) atomicAdd(counters + 1, rows);
+        }
         for (int rr = threadIdx.x; rr < R; rr += NT) {
             const uint32_t v = r_sl[rr];
             if (v != 0xffffffffu) order[atomicAdd(cnt + (v >> 6), 1)] = (uint16_t)rr;
@@ -1375,6 +1464,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                     const bool has = sub < ncol;
                     int cur = -1;
                     float acc = 0.f;
+                    unsigned long long nreq = 0;
                     int keyv[16];
                     float xv[16];
 #pragma unroll
@@ -1388,12 +1478,18 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                         const int key = keyv[t];
                         if (key != cur) {
                             if (cur >= 0 && has) atomicAdd(grad + (int64_t)cur * gstride + c_lo + sub, acc);
+                            if constexpr (COUNT) nreq += (cur >= 0 && sub == 0) ? 1u : 0u;
                             acc = 0.f;
                             cur = key;
                         }
                         acc += xv[t];
                     }
                     if (cur >= 0 && has) atomicAdd(grad + (int64_t)cur * gstride + c_lo + sub, acc);
+                    if constexpr (COUNT) {
+                        nreq += (cur >= 0 && sub == 0) ? 1u : 0u;
+                        nreq = wave_sum(nreq);
+                        if (lane == 0 && nreq) atomicAdd(counters, nreq);
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -1845,11 +1941,6 @@ depth_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ depth) {
 // Roofline counters
 // ---------------------------------------------------------------------------
 
-__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
 
 template <bool N2>
 __global__ void __launch_bounds__(kBlock)
@@ -1887,6 +1978,41 @@ count_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, unsigned long long* __restr
         atomicAdd(counters + 3, valid);
         atomicAdd(counters + 4, active);
     }
+}
+
+// What one forward march touches (svoxt_count_touched; for the roofline's compulsory bytes):
+// row_mask[idx] = 1 for every valid leaf's feature row (the forward reads it), row_mask[M + idx] = 1
+// if a sample there is composited (the backward reads the row again); tree_mask: grid cells and (child, data)
+// pairs with the acceleration grid, child and data words without (march_step<..., MARK>);
+// longest[0] = the most leaf crossings any ray makes.  The march is the real one.
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+count_touched_kernel(TreeDev tr, RaysDev rays, Opts opt, uint8_t* __restrict__ row_mask,
+                     uint8_t* __restrict__ tree_mask, uint32_t n_slots, unsigned long long* __restrict__ longest) {
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+    unsigned long long steps = 0;
+    Ray r;
+    if (q < rays.Q && setup_ray(tr, rays, opt, q, r)) {
+        const int K = tr.K;
+        float light = 1.f, t = r.tmin;
+        while (t < r.tmax) {
+            Sample s;
+            march_step<N2, -1, true>(tr, r, opt.step_size, t, s, tree_mask, n_slots);
+            ++steps;
+            if (s.valid) {
+                const float sigma = tr.features[(int64_t)s.idx * K + (K - 1)];
+                row_mask[s.idx] = 1;                      // (every writer stores the same value: no race to lose)
+                if (sigma > opt.sigma_thresh) {
+                    row_mask[tr.M + s.idx] = 1;
+                    light *= pexpf(-s.delta_t * r.delta_scale * sigma);
+                    if (light <= opt.stop_thresh) break;
+                }
+            }
+            t = march_advance(t, s.delta_t);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) steps = max(steps, (unsigned long long)__shfl_down(steps, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(longest, steps);
 }
 
 // ---------------------------------------------------------------------------
@@ -2076,6 +2202,7 @@ using namespace svoxt;
 
 namespace {
 thread_local char g_err[512] = "";
+int64_t* g_bwd_counters = nullptr;      // svoxt_set_bwd_counters (instrumentation)
 }
 
 namespace svoxt {
@@ -2345,7 +2472,7 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
     // a caller that hands over a coef buffer asks for the two-kernel form; without one (coef_bytes < 0)
     // the per-tile route runs if it can run as ONE kernel.  (The choice is the caller's alone: the
     // Python layer reads SVOXT_BWD_FUSED, the library reads no environment for this.)
-    const bool fused = coef == nullptr && !xf && fwd_out != nullptr;
+    const bool fused = coef == nullptr && !xf;
     if (!fused && coef == nullptr) return false;            // the two-kernel form needs its buffer
     // four wavefronts per tile and tables of 1024 (measured: one wavefront per tile 0.41 ms,
     // two 0.33, four 0.30 before step 15; tables of 512 / 256 cost more passes than they buy)
@@ -2353,8 +2480,19 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
     if (fused) {   /* tails of overflowed rays (a tail-only launch), then list walk and merge in one kernel */ \
         hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
                            tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out, (float4*)nullptr);   \
-        hipLaunchKernelGGL((grad_fused_kernel<F, BB>), dim3(nb), dim3(512), 0, st,                            \
-                           tr, rays, opt, grad_out, rec, S, aux, fwd_out, grad, gstride);                     \
+        unsigned long long* ctr = reinterpret_cast<unsigned long long*>(g_bwd_counters);                      \
+        if (fwd_out != nullptr && ctr == nullptr)                                                             \
+            hipLaunchKernelGGL((grad_fused_kernel<F, BB, false>), dim3(nb), dim3(512), 0, st,                 \
+                               tr, rays, opt, grad_out, rec, S, aux, fwd_out, grad, gstride);                 \
+        else if (ctr == nullptr)                                                                              \
+            hipLaunchKernelGGL((grad_fused_kernel<F, BB, true>), dim3(nb), dim3(512), 0, st,                  \
+                               tr, rays, opt, grad_out, rec, S, aux, fwd_out, grad, gstride);                 \
+        else if (fwd_out != nullptr)                                                                          \
+            hipLaunchKernelGGL((grad_fused_kernel<F, BB, false, true>), dim3(nb), dim3(512), 0, st,           \
+                               tr, rays, opt, grad_out, rec, S, aux, fwd_out, grad, gstride, ctr);            \
+        else                                                                                                  \
+            hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, true>), dim3(nb), dim3(512), 0, st,            \
+                               tr, rays, opt, grad_out, rec, S, aux, fwd_out, grad, gstride, ctr);            \
         return true;                                                                                          \
     }                                                                                                         \
     hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
@@ -2793,6 +2931,29 @@ int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
     tr.accel = nullptr;   // the counters are the reference's: levels of the plain root descent
     if (tree->N == 2) hipLaunchKernelGGL((count_fwd_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, to_dev(rays), to_dev(opt), c);
     else hipLaunchKernelGGL((count_fwd_kernel<false>), dim3(nb), dim3(kBlock), 0, st, tr, to_dev(rays), to_dev(opt), c);
+    return check_launch(fn);
+}
+
+int svoxt_set_bwd_counters(int64_t* counters) {
+    g_bwd_counters = counters;
+    return SVOXT_OK;
+}
+
+int svoxt_count_touched(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
+                        uint8_t* row_mask, uint8_t* tree_mask, int64_t* longest, void* stream) {
+    const char* fn = "svoxt_count_touched";
+    int rc;
+    if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) || (rc = check_opts(opt, tree, fn, false)))
+        return rc;
+    if (row_mask == nullptr || tree_mask == nullptr || longest == nullptr)
+        return fail(SVOXT_ERR_INVALID, "%s: row_mask / tree_mask / longest is NULL", fn);
+    if (rays->Q == 0) return SVOXT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = nblocks(rays->Q);
+    const uint32_t n_slots = (uint32_t)(tree->n_internal * tree->N * tree->N * tree->N);
+    unsigned long long* lg = reinterpret_cast<unsigned long long*>(longest);
+    if (tree->N == 2) hipLaunchKernelGGL((count_touched_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), row_mask, tree_mask, n_slots, lg);
+    else hipLaunchKernelGGL((count_touched_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), row_mask, tree_mask, n_slots, lg);
     return check_launch(fn);
 }
 

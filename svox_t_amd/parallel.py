@@ -12,8 +12,11 @@ the feature gradient.
                    -- render_sharded -- or whole cameras i = r, r + W, ...
                    in image mode -- render_cameras
     forward        local render, then ONE all-gather of [Q/W, C+1] fp32 tiles
+                   (gather_pixels_async: under the backward; to one rank if only one needs it)
     backward       local backward of the rank's own rows of grad_out, then ONE
-                   all-reduce(sum) of grad_features [M, K]
+                   all-reduce(sum) of grad_features [M, K] -- or, across the batches of a
+                   gradient-accumulation step, OverlappedGradReducer: row chunks on a side
+                   stream under the next batch's forward and backward
 
 `torch.distributed` with backend "nccl" is RCCL on ROCm (xGMI inside a node);
 the same code runs on "gloo" for the CPU tests.  The render function is
@@ -194,6 +197,92 @@ def render_cameras(renderer_or_fn, features: torch.Tensor, c2ws: torch.Tensor,
     else:
         fn = renderer_or_fn
     return _CameraSet.apply(features, fn, c2ws, group)
+
+
+class OverlappedGradReducer:
+    """All-reduce(sum) of the feature gradient off the critical path.
+
+    `start(grad)` hands over a gradient [M, K] as it comes out of a backward: it is reduced in
+    place, in row-range chunks (each chunk one collective: on xGMI a chunk of a few tens of MB
+    keeps all links busy without one 75 MB -- or 578 MB at depth 9 -- transfer holding the
+    queue), on a side stream that waits for the backward's last kernel and nothing else (RCCL's
+    own stream for the "nccl" backend).  The compute stream goes on -- the next batch's forward
+    and backward run while the chunks travel.  `wait()` makes the compute stream (gloo: the host)
+    wait for the reduced gradient; call it before the gradient is read.  One gradient is in
+    flight at a time (`start` waits for the previous one).
+
+    When that overlap is legitimate: gradient accumulation -- the sum of the gradients of several
+    ray batches / cameras before one update of the features, the usual arrangement when every
+    rank renders whole cameras -- and inference-time sensitivity passes.  A trainer that updates
+    the features after EVERY batch must wait() before the update; what still overlaps then is the
+    pixel gather (under the backward, gather_pixels_async) and the next batch's ray upload.
+    bench.py --gpus N times the accumulation arrangement and says so.
+    """
+
+    def __init__(self, dist_module=dist, group=None, backend: str = "nccl", chunk_bytes: int = 32 << 20):
+        self.dist, self.group, self.backend = dist_module, group, backend
+        self.chunk_bytes = int(chunk_bytes)
+        self._works, self._grad = [], None
+        self._side = torch.cuda.Stream() if backend == "nccl" and torch.cuda.is_available() else None
+
+    def chunks(self, grad: torch.Tensor):
+        """Row ranges [lo, hi) of `grad` of at most chunk_bytes each (at least one row)."""
+        M = grad.shape[0]
+        row_bytes = max(1, grad[0].numel() * grad.element_size()) if M else 1
+        rows = max(1, self.chunk_bytes // row_bytes)
+        return [(lo, min(M, lo + rows)) for lo in range(0, M, rows)]
+
+    def start(self, grad: torch.Tensor) -> None:
+        self.wait()
+        if grad is None or grad.numel() == 0 or self.dist.get_world_size(self.group) == 1:
+            return
+        assert grad.is_contiguous()
+        self._grad = grad                                   # stays alive while it travels
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream(grad.device))
+            grad.record_stream(self._side)
+            with torch.cuda.stream(self._side):
+                self._works = [self.dist.all_reduce(grad[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+                               for lo, hi in self.chunks(grad)]
+        else:
+            self._works = [self.dist.all_reduce(grad[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+                           for lo, hi in self.chunks(grad)]
+
+    def wait(self) -> Optional[torch.Tensor]:
+        """The reduced gradient handed to the last start() (None if there was none)."""
+        for w in self._works:
+            w.wait()                                        # nccl: the current stream waits; gloo: the host does
+        self._works = []
+        g, self._grad = self._grad, None
+        return g
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def gather_pixels_async(dist_module, gathered: torch.Tensor, local: torch.Tensor, backend: str = "nccl",
+                        group=None, dst: Optional[int] = None):
+    """Start collecting every rank's [q, C+1] pixels into `gathered` [world * q, C+1] and return a
+    handle with .wait(): with "nccl" the transfer runs beside whatever the compute stream does next
+    (the backward).  dst = r: only rank r needs the image (a viewer, a logger): a gather to that
+    rank moves 1/world of what the all-gather moves over every other rank's links."""
+    world = dist_module.get_world_size(group)
+    if world == 1:
+        gathered.copy_(local)
+        return _Done()
+    if dst is not None:
+        me = dist_module.get_rank(group)
+        outs = list(gathered.chunk(world)) if me == dst else None
+        if backend == "nccl":
+            return dist_module.gather(local, outs, dst=dst, group=group, async_op=True)
+        dist_module.gather(local, outs, dst=dst, group=group)
+        return _Done()
+    if backend == "nccl":
+        return dist_module.all_gather_into_tensor(gathered, local, group=group, async_op=True)
+    dist_module.all_gather(list(gathered.chunk(world)), local, group=group)
+    return _Done()
 
 
 def broadcast_tree(tree, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> None:

@@ -28,49 +28,18 @@ Rays = namedtuple("Rays", ["origins", "dirs", "viewdirs"])
 _C = _get_c_extension()
 
 
-# Batches that are not declared images are rendered in a coherent order (svoxt_ray_order,
-# include/svoxt.h: sort by the rays' entry points into the cube, three gathers, a scatter --
-# ~0.3 ms per 640 000 rays) from SORT_RAYS_MIN rays on, and their backward then takes the
-# per-tile route: 640 000 rays forward+backward, shuffled within one camera 1.47 -> 0.93 ms,
-# drawn from 8 cameras 1.48 -> 1.29 ms, row-major but not declared an image 1.29 -> 0.92 ms
-# (profiles/r01_s_ray_order_timing.txt).  SVOXT_SORT_RAYS=0 never, =1 always; sort_rays= per call.
-SORT_RAYS = os.environ.get("SVOXT_SORT_RAYS", "auto")
-SORT_RAYS_MIN = 16384
-
-
 def _rays_spec_from_rays(rays, image_shape=None, sort_rays=None):
+    """svox_t/renderer.py:44-49, plus two optional hints for the operator layer (svox_t_amd.csrc):
+    the batch is a row-major H x W image (walked in 8x8 tiles), and whether to render a batch that
+    is not an image in svoxt_ray_order's order (None: decided by its size)."""
     spec = _C.RaysSpec()
     spec.origins = rays.origins
     spec.dirs = rays.dirs
     spec.vdirs = rays.viewdirs
     if image_shape is not None:
         spec.image_height, spec.image_width = int(image_shape[0]), int(image_shape[1])
-    if sort_rays is None:
-        sort_rays = SORT_RAYS == "1" or (SORT_RAYS == "auto" and rays.origins.shape[0] >= SORT_RAYS_MIN)
-    spec.sort = bool(sort_rays) and image_shape is None
+    spec.sort = None if sort_rays is None else bool(sort_rays)
     return spec
-
-
-def _in_coherent_order(tree, rays, opt):
-    """(rays spec to render, perm): the batch gathered into svoxt_ray_order's order when its
-    spec asks for that (perm: sorted position -> position in the caller's batch), else as is."""
-    if not getattr(rays, "sort", False) or rays.origins.shape[0] == 0:
-        return rays, None
-    perm = _C.ray_order(tree, rays, opt)
-    s = _C.RaysSpec()
-    s.origins = rays.origins.index_select(0, perm)
-    s.dirs = rays.dirs.index_select(0, perm)
-    s.vdirs = rays.vdirs.index_select(0, perm)
-    s.coherent = True           # neighbouring rays revisit the same leaves: the two-kernel backward pays
-    return s, perm
-
-
-def _to_caller_order(out_sorted, perm):
-    if perm is None:
-        return out_sorted
-    out = torch.empty_like(out_sorted)
-    out[perm] = out_sorted
-    return out
 
 
 def _make_camera_spec(c2w, width, height, fx, fy):
@@ -124,60 +93,46 @@ def pinhole_rays(c2w, width, height, fx, fy, ndc: NDCConfig = None, near=1.0):
 
 
 class _VolumeRenderFunction(autograd.Function):
-    """Argument order (data, tree_spec, rays_spec, opt) and "gradient for
-    argument 0 only" as in svox_t/renderer.py:60-77.  The specs are kept on the
-    ctx (not save_for_backward), as the reference does."""
+    """svox_t/renderer.py:60-77, as it stands there: argument order (data, tree_spec, rays_spec,
+    opt), the specs kept on the ctx (not save_for_backward), a gradient for argument 0 only.
+    What makes the pair fast -- sample lists recorded by the forward and replayed by the backward,
+    coherent ray order -- happens below these two calls (svox_t_amd.csrc, _Plan), so the
+    reference's own function gets it too.  The one addition: the forward says whether a backward
+    will follow (inside an autograd.Function the operator layer cannot see that)."""
 
     @staticmethod
     def forward(ctx, data, tree, rays, opt):
-        # A batch that is not an image is rendered in a coherent order (results are per ray)
-        rays, ctx.perm = _in_coherent_order(tree, rays, opt)
-        # When a backward will follow, the forward also records which samples
-        # each ray composited so that the backward need not traverse the tree.
-        if ctx.needs_input_grad[0]:
-            out, ctx.lists = _C.volume_render(tree, rays, opt, record=True)
-        else:
-            out, ctx.lists = _C.volume_render(tree, rays, opt), None
+        rays.need_grad = ctx.needs_input_grad[0]
+        out = _C.volume_render(tree, rays, opt)
         ctx.tree = tree
         ctx.rays = rays
         ctx.opt = opt
-        if ctx.lists is not None:
-            ctx.save_for_backward(out)      # with the lists it spares the backward its first pass
-        return _to_caller_order(out, ctx.perm)
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        if ctx.needs_input_grad[0]:
-            fwd_out = ctx.saved_tensors[0] if ctx.lists is not None else None
-            grad_out = grad_out.contiguous() if ctx.perm is None else grad_out.index_select(0, ctx.perm)
-            return _C.volume_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out,
-                                             lists=ctx.lists, fwd_output=fwd_out), None, None, None
-        return None, None, None, None
-
-
-class _VolumeRenderImageFunction(autograd.Function):
-    """svox_t/renderer.py:79-94; as _VolumeRenderFunction, the forward records the
-    sample lists when a backward will follow."""
-
-    @staticmethod
-    def forward(ctx, data, tree, cam, opt):
-        if ctx.needs_input_grad[0]:
-            out, ctx.lists = _C.volume_render_image(tree, cam, opt, record=True)
-        else:
-            out, ctx.lists = _C.volume_render_image(tree, cam, opt), None
-        ctx.tree = tree
-        ctx.cam = cam
-        ctx.opt = opt
-        if ctx.lists is not None:
-            ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         if ctx.needs_input_grad[0]:
-            fwd_out = ctx.saved_tensors[0] if ctx.lists is not None else None
-            return _C.volume_render_image_backward(ctx.tree, ctx.cam, ctx.opt, grad_out.contiguous(),
-                                                   lists=ctx.lists, fwd_output=fwd_out), None, None, None
+            return _C.volume_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out.contiguous()), None, None, None
+        return None, None, None, None
+
+
+class _VolumeRenderImageFunction(autograd.Function):
+    """svox_t/renderer.py:79-94."""
+
+    @staticmethod
+    def forward(ctx, data, tree, cam, opt):
+        cam.need_grad = ctx.needs_input_grad[0]
+        out = _C.volume_render_image(tree, cam, opt)
+        ctx.tree = tree
+        ctx.cam = cam
+        ctx.opt = opt
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if ctx.needs_input_grad[0]:
+            return _C.volume_render_image_backward(ctx.tree, ctx.cam, ctx.opt, grad_out.contiguous()), \
+                None, None, None
         return None, None, None, None
 
 
@@ -205,22 +160,17 @@ class _OpacityRenderFunction(autograd.Function):
 
     @staticmethod
     def forward(ctx, data, tree, rays, opt):
-        rays, ctx.perm = _in_coherent_order(tree, rays, opt)
-        if ctx.needs_input_grad[0]:
-            out, ctx.lists = _C.opacity_render(tree, rays, opt, record=True)
-        else:
-            out, ctx.lists = _C.opacity_render(tree, rays, opt), None
+        rays.need_grad = ctx.needs_input_grad[0]
+        out = _C.opacity_render(tree, rays, opt)
         ctx.tree = tree
         ctx.rays = rays
         ctx.opt = opt
-        return _to_caller_order(out, ctx.perm)
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
         if ctx.needs_input_grad[0]:
-            grad_out = grad_out.contiguous() if ctx.perm is None else grad_out.index_select(0, ctx.perm)
-            return _C.opacity_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out,
-                                              lists=ctx.lists), None, None, None
+            return _C.opacity_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out.contiguous()), None, None, None
         return None, None, None, None
 
 
@@ -271,8 +221,8 @@ class VolumeRenderer(nn.Module):
         :param sort_rays: (not in the reference) render a batch that is not an image in the
                order of its rays' entry points into the tree's cube, so that the 64 rays of
                a wavefront cross the same leaves; every ray's result is unchanged and comes
-               back at the ray's own position.  None: from 16 384 rays on (SORT_RAYS above;
-               SVOXT_SORT_RAYS=0/1 overrides)
+               back at the ray's own position.  None: from 16 384 rays on (svox_t_amd.csrc
+               SORT_RAYS; SVOXT_SORT_RAYS=0/1 overrides)
         :return: [Q, C+1]: C colour/feature channels then accumulated alpha
         """
         self._require_gpu(cuda, "forward")

@@ -307,19 +307,19 @@ def test_config3_backward_full_size(cfg3, gpu):
 def test_config3_backward_relative_error_both_routes(cfg3, gpu, monkeypatch, capsys):
     """What "1e-5 relative" holds for at full size, route by route.
 
-    (a) SVOXT_BWD_EXACT (two list walks, accum added up sequentially like the reference's pass 1,
-        rt_kernel.cu:365-437): every entry within 1e-5 of the TIGHT scale -- accum priced by
-        |w_j * total_color_j| and |T * bg * sum g|, the scale that was in force before the
-        single-march backward existed.
-    (b) the default single-march route (accum = sum_c g_c * out_c from the forward's output):
-        within 1e-5 of the sum-of-elementary-magnitudes scale (any order of adding them).
-    For both, the plain elementwise criterion |got - want| <= 1e-5 |want| is REPORTED and
-    bounded: it cannot hold for every entry of any float-atomic backward, the reference's
-    included -- an entry that is the small difference of large contributions has |want| far
-    below the rounding error of its own sum.  Thresholds: at most 2 % of the sigma entries and
-    0.5 % of the colour entries off (measured r02: see DESIGN.md 4), and the two routes within
-    a factor 1.5 of each other -- i.e. the single march is no worse than float-atomic
-    reordering already is."""
+    (a) the default, exact route (grad_fused_kernel<..., EXACT>: accum added up sequentially like the
+        reference's pass 1, rt_kernel.cu:365-437; every contribution bit-identical to the
+        reference's formulas): every entry within 1e-5 of the TIGHT scale -- accum priced by
+        |w_j * total_color_j| and |T * bg * sum g|, the scale in force before the single-march
+        backward existed -- and the plain elementwise criterion |got - want| <= 1e-5 |want| fails
+        for at most 0.5 % of the entries, sigma column and colour columns alike (measured r02:
+        0.157 % / 0.157 %).  That remainder is float-atomic reordering: an entry that is the small
+        sum of many contributions of both signs has |want| below the rounding error of its own
+        sum -- true of the reference's atomics too.
+    (b) the opt-in single-march route (SVOXT_BWD_EXACT=0: accum = sum_c g_c * out_c from the
+        forward's output, one sweep, 0.10 ms faster): within 1e-5 of the sum-of-elementary-
+        magnitudes scale, colour columns as (a) -- but 36 % of the sigma entries miss the
+        elementwise criterion (r02), which is why it is not the default.  Reported here."""
     c = cfg3
     tree = c.tree(gpu)
     r = svox.VolumeRenderer(tree)
@@ -345,9 +345,9 @@ def test_config3_backward_relative_error_both_routes(cfg3, gpu, monkeypatch, cap
         for k, (fs, fc, worst) in stats.items():
             print(f"\n[cfg3 backward, {k}] entries with |err| > 1e-5 |want|: sigma column {fs:.4%}, "
                   f"colour columns {fc:.4%}; worst |err| / tight scale {worst:.2e}")
-    for k, (fs, fc, _) in stats.items():
-        assert fs <= 0.02 and fc <= 0.005, (k, fs, fc)
-    assert stats["single-march"][0] <= 1.5 * stats["exact"][0] + 1e-4
+    fs, fc, worst = stats["exact"]
+    assert fs <= 0.005 and fc <= 0.005 and worst <= 1e-5
+    assert stats["single-march"][1] <= 0.005
 
 
 def test_config4_depth9_features32_and_depth(gpu):

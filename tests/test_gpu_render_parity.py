@@ -257,12 +257,16 @@ def test_two_kernel_forward_equals_one_kernel_forward(name, gpu, monkeypatch):
         for fast in (False, True):
             opt = r._get_options(fast=fast)
             monkeypatch.setenv("SVOXT_FWD_SPLIT", "0")
+            rs.need_grad = False                 # forwards nobody differentiates
             want = _C.volume_render(spec, rs, opt)
             monkeypatch.setenv("SVOXT_FWD_SPLIT", "1")
             for S in (96, 8):
                 monkeypatch.setattr(_C, "FWD_LIST_SAMPLES", S)
                 assert torch.equal(_C.volume_render(spec, rs, opt), want), (name, fast, S)
         opt = r._get_options()
+        monkeypatch.setenv("SVOXT_FWD_SPLIT", "0")
+        rs.need_grad = False
+        want = _C.volume_render(spec, rs, opt)
         g = torch.randn_like(want)
         grads = {}
         for split in ("0", "1"):
@@ -276,3 +280,72 @@ def test_two_kernel_forward_equals_one_kernel_forward(name, gpu, monkeypatch):
         scale = ref.abs().max().item()
         for k, v in grads.items():
             assert (v - ref).abs().max().item() <= 1e-5 * scale, k
+
+
+class _ReferenceShapedFunction(torch.autograd.Function):
+    """What the reference's own svox_t/renderer.py:60-77 does with whatever module it found as
+    `svox_t.csrc` -- two calls, the same spec objects, nothing else (route B of INTEGRATION.md)."""
+
+    @staticmethod
+    def forward(ctx, data, C, tree, rays, opt):
+        out = C.volume_render(tree, rays, opt)
+        ctx.C, ctx.tree, ctx.rays, ctx.opt = C, tree, rays, opt
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ctx.C.volume_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out.contiguous()), None, None, None, None
+
+
+@pytest.mark.parametrize("name", ["d5_rgba4", "d5_sh9"])
+def test_plain_calls_hand_the_forwards_lists_to_the_backward(name, gpu, monkeypatch):
+    """The two plain calls of the reference's autograd function (no record=, no lists=): the forward
+    leaves its sample lists -- and, for a batch that is not an image, the coherent ray order -- on
+    the rays spec; the backward of the same spec objects picks them up.  Same output (bit for bit)
+    and same gradient as the explicit route and as the oracle; a backward that finds nothing
+    (second backward, another rays spec, features edited in between) marches and agrees too."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd.renderer import _rays_spec_from_rays
+    c = Case(**CASES[name])
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    rays = c.rays_gpu(gpu)
+    opt = r._get_options()
+    from svox_t_amd import synth
+    g = synth.grad_output(c.Q, 4).to(gpu)
+    want_out = O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts())
+    want, absum = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.cpu().numpy(), want_abs=True)
+    monkeypatch.setattr(_C, "SORT_RAYS_MIN", 1024)          # these small batches take the sorted route too
+    for sort in (None, False):
+        f = tree.features.detach().clone().requires_grad_(True)
+        rs = _C.RaysSpec()                                   # as the reference fills it: three tensors
+        rs.origins, rs.dirs, rs.vdirs = rays.origins, rays.dirs, rays.viewdirs
+        rs.sort = sort
+        spec = tree._spec(f)
+        out = _ReferenceShapedFunction.apply(f, _C, spec, rs, opt)
+        np.testing.assert_array_equal(out.detach().cpu().numpy(), want_out)
+        plan = rs._svoxt_plan
+        assert plan is not None and plan.lists is not None and (plan.perm is not None) == (sort is None)
+        out.backward(g, retain_graph=True)
+        assert rs._svoxt_plan is None                        # taken
+        assert_grads_close(f.grad.cpu().numpy(), want, absum)
+        first = f.grad.clone()
+        f.grad = None
+        out.backward(g)                                      # nothing left behind: the backward marches
+        assert_grads_close(f.grad.cpu().numpy(), want, absum)
+        assert (f.grad - first).abs().max().item() <= 1e-5 * first.abs().max().item()
+    # features edited in place between forward and backward: the plan is refused (the march reads the new values)
+    f = tree.features.detach().clone().requires_grad_(True)
+    rs = _rays_spec_from_rays(rays)
+    spec = tree._spec(f)
+    out = _ReferenceShapedFunction.apply(f, _C, spec, rs, opt)
+    with torch.no_grad():
+        f.mul_(1.0)
+    assert _C._take_plan(spec, rs, opt) is None
+    # a forward nobody differentiates leaves nothing
+    rs2 = _rays_spec_from_rays(rays)
+    with torch.no_grad():
+        out2 = r(tree.features, rays)
+    np.testing.assert_array_equal(out2.cpu().numpy(), want_out)
+    _C.volume_render(tree._spec(tree.features.detach()), rs2, opt)
+    assert rs2._svoxt_plan is None

@@ -123,3 +123,49 @@ def test_render_cameras_two_ranks(tmp_path, n_cam):
         assert n == n_cam and amax > 0.1
         assert dout == 0.0
         assert gmax > 0 and dgrad <= 1e-12 * max(gmax, 1.0)
+
+
+def _reducer_worker(rank, world, port, result_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        red = parallel.OverlappedGradReducer(dist, backend="gloo", chunk_bytes=4096)
+        outs = []
+        for step in range(3):                                   # three batches of an accumulation step
+            grad = torch.randn(1000 + step, 28, generator=g)
+            assert len(red.chunks(grad)) > 1 and red.chunks(grad)[0] == (0, 4096 // (28 * 4))
+            mine = grad.clone()
+            red.start(grad)                                     # waits for the previous one, sends this one off
+            work_between = mine.sum()                           # (the next batch's forward would run here)
+            outs.append((mine, grad, work_between))
+        last = red.wait()
+        assert last is outs[-1][1] and red.wait() is None
+        torch.save([(m, r) for m, r, _ in outs], os.path.join(result_dir, f"red{rank}.pt"))
+        # pixel gather: all ranks, and to rank 0 only
+        local = torch.full((5, 4), float(rank))
+        full = torch.empty((world * 5, 4))
+        parallel.gather_pixels_async(dist, full, local, backend="gloo").wait()
+        assert all((full[r * 5:(r + 1) * 5] == r).all() for r in range(world))
+        only0 = torch.full((world * 5, 4), -1.0)
+        parallel.gather_pixels_async(dist, only0, local, backend="gloo", dst=0).wait()
+        if rank == 0:
+            assert torch.equal(only0, full)
+        else:
+            assert (only0 == -1).all()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_chunked_grad_reduce_equals_plain_sum(tmp_path):
+    """OverlappedGradReducer (row chunks, one gradient in flight, wait() before the read) on two
+    gloo ranks: every reduced gradient equals the sum of the two ranks' gradients, as ONE plain
+    all-reduce would give; gather_pixels_async to all ranks and to one."""
+    world = 2
+    port = 29500 + (os.getpid() % 400) + 401
+    mp.spawn(_reducer_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = (torch.load(os.path.join(str(tmp_path), f"red{r}.pt")) for r in range(world))
+    for (mine_a, red_a), (mine_b, red_b) in zip(a, b):
+        assert torch.equal(red_a, red_b)
+        torch.testing.assert_close(red_a, mine_a + mine_b, rtol=0, atol=0)
