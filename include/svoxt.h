@@ -140,17 +140,23 @@ int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
                             const svoxt_options* opt, float* out, void* stream);
 
 /* The same result (bit for bit) with device scratch: with svoxt_fwd_workspace_bytes(Q, S)
- * bytes (S >= 1, 96 is a good value) the 3-channel payloads run as two kernels -- one that
- * only steps the rays through the tree and lists each ray's samples (up to S; longer rays
- * finish in a tail launch), one that shades the lists per 64-ray tile with eight wavefronts
- * sharing the work -- instead of one kernel as long as its longest ray (800x800, depth-8 SH9:
- * see DESIGN.md 5).  Other payloads, tree->weight_accum, a NULL or too small workspace:
- * exactly svoxt_volume_render_fwd.  Contents of the workspace on return are unspecified.
+ * bytes (S >= 8, 96 is a good value) the forward can run as two kernels -- one that only
+ * steps the rays through the tree and lists each ray's samples (up to S; longer rays finish in a
+ * tail launch), one that shades the lists: per 64-ray tile with eight wavefronts sharing the
+ * work (3-channel payloads; chosen with SVOXT_FWD_SPLIT=1), or with the channels of a row on
+ * the lanes of a wavefront (RGBA-style rows of 8 / 16 / 32 floats: the default for them) --
+ * instead of one kernel as long as its longest ray.  Other payloads,
+ * tree->weight_accum, a NULL or too small workspace: exactly svoxt_volume_render_fwd.  Contents of the workspace on return are unspecified.
  * (Reference: volume_render, rt_kernel.cu:1362-1379; trace_ray :222-328.) */
+/* flags: 0, or SVOXT_FWD_FAST_SIGMOID -- an opt-in tolerance mode for RGBA-style rows of 8 / 16 / 32
+ * floats: the per-channel quotient w / (1 + exp(-x)), double precision in the reference
+ * (rt_kernel.cu:300-305), is taken in float with the hardware reciprocal.  Each term then lies
+ * within 2e-7 of the reference's, outputs within 1e-5 relative (tests); no longer bit for bit. */
+#define SVOXT_FWD_FAST_SIGMOID 1
 int64_t svoxt_fwd_workspace_bytes(int64_t Q, int32_t max_samples);
 int svoxt_volume_render_fwd_ws(const svoxt_tree* tree, const svoxt_rays* rays,
                                const svoxt_options* opt, float* out,
-                               void* workspace, int64_t workspace_bytes, void* stream);
+                               void* workspace, int64_t workspace_bytes, int32_t flags, void* stream);
 
 /* grad_out: device [Q, grad_cols] with grad_cols = C+1.
  * grad_features: device [M, grad_stride] floats of which columns 0..K-1 are the

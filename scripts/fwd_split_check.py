@@ -18,7 +18,7 @@ from svox_t_amd.renderer import _rays_spec_from_rays
 
 dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "d8"
-depth, K, fmt, W, H = (8, 28, "SH9", 800, 800) if which == "d8" else (9, 4, "RGBA", 1024, 1024)
+depth, K, fmt, W, H = (8, 28, "SH9", 800, 800) if which == "d8" else (9, 32, "RGBA", 1024, 1024)
 st = synth.shell_tree(depth)
 feats = synth.shell_features(st.n_features, K)
 tree = svox.N3Tree.from_arrays(st.child, st.data, st.parent_depth, feats, data_format=fmt, device=dev)

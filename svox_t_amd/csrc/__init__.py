@@ -101,7 +101,7 @@ EXPORTS = {
     "svoxt_out_data_dim": (ctypes.c_int, [_P(_COptions), _i32]),
     "svoxt_volume_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
     "svoxt_fwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
-    "svoxt_volume_render_fwd_ws": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _i64, _vp]),
+    "svoxt_volume_render_fwd_ws": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _i64, _i32, _vp]),
     "svoxt_volume_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _vp, _i64, _vp]),
     "svoxt_bwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
     "svoxt_can_record": (ctypes.c_int, [_P(_CTree), _P(_COptions)]),
@@ -429,6 +429,9 @@ BWD_LIST_SAMPLES = int(os.environ.get("SVOXT_BWD_LIST", "96"))
 # The same for a forward nobody differentiates: scratch lists for the two-kernel forward
 # (0 = always the one-kernel forward, svoxt_volume_render_fwd).
 FWD_LIST_SAMPLES = int(os.environ.get("SVOXT_FWD_LIST", "96"))
+# SVOXT_FAST_SIGMOID=1: opt into the tolerance mode of forwards nobody differentiates (include/svoxt.h,
+# SVOXT_FWD_FAST_SIGMOID: float quotient for RGBA-style rows of 8 / 16 / 32 floats, outputs within 1e-5)
+FAST_SIGMOID = os.environ.get("SVOXT_FAST_SIGMOID", "0") not in ("", "0")
 
 
 class SampleLists:
@@ -598,8 +601,12 @@ def _volume_render(tree, rays, opt, record):
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
     lists = None
-    split = os.environ.get("SVOXT_FWD_SPLIT", "0") not in ("", "0")
-    LAST_ROUTE["forward"] = ("march_rec_kernel + shade_tile_kernel (two-kernel forward)" if split
+    env = os.environ.get("SVOXT_FWD_SPLIT", "")
+    wide = co.format == FORMAT_RGBA and ct.K in (8, 16, 32)
+    split = (env not in ("", "0")) if env != "" else wide
+    LAST_ROUTE["forward"] = (("march_rec_kernel + shade_chan_kernel (two-kernel forward, channels on lanes"
+                              + (", float quotient)" if FAST_SIGMOID and not record else ")") if wide else
+                              "march_rec_kernel + shade_tile_kernel (two-kernel forward)") if split
                              else "render_fwd_kernel") + (", recording sample lists" if record else "")
     with torch.cuda.device(dev):
         out = torch.empty((cr.Q, get_out_data_dim(opt, ct.K)), dtype=torch.float32, device=dev)
@@ -615,7 +622,7 @@ def _volume_render(tree, rays, opt, record):
             nbytes = _lib.svoxt_fwd_workspace_bytes(cr.Q, FWD_LIST_SAMPLES)
             ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
             _call("svoxt_volume_render_fwd_ws", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
-                  _ptr(out), _ptr(ws), nbytes, _stream(dev))
+                  _ptr(out), _ptr(ws), nbytes, 1 if FAST_SIGMOID else 0, _stream(dev))
         else:
             _call("svoxt_volume_render_fwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(out), _stream(dev))

@@ -52,6 +52,7 @@ struct RaysDev {
     const float* __restrict__ vdirs;
     int64_t Q;
     int tiles_per_row;   // > 0: rays are a row-major W x H image (W = 8 * tiles_per_row), walk it in 8x8 tiles
+    uint32_t tile0;      // launches that cover a range of the batch's 64-ray tiles start at this one (else 0)
     // camera mode (c2w != null): ray q is pixel (q % width, q / width) of a pinhole
     // camera, generated in the kernel; origins / dirs / vdirs are not read
     const float* __restrict__ c2w;   // camera-to-world, rows of 4 floats, 3 rows used

@@ -145,7 +145,7 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
     static_assert(!(RESUME && REC), "the tail launch does not record");
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     __shared__ uint2 rstage[REC ? kRecBlock * kBlock : 1];
-    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t tid = ((int64_t)blockIdx.x + rays.tile0) * kBlock + threadIdx.x;
     const int64_t q = ray_of_thread(rays, tid);
     if (q >= rays.Q) return;
     float* o = out + q * (C + 1);
@@ -353,7 +353,7 @@ template <bool N2, bool STOP, int ACC>
 __global__ void __launch_bounds__(kBlock)
 march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, uint2* __restrict__ rec, int S, uint4* __restrict__ aux) {
     __shared__ uint2 rstage[kRecBlock * kBlock];
-    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t tid = ((int64_t)blockIdx.x + rays.tile0) * kBlock + threadIdx.x;
     const int64_t q = ray_of_thread(rays, tid);
     if (q >= rays.Q) return;
     Ray r;
@@ -424,7 +424,8 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, const uint2* __restrict__ 
     typedef float v4f __attribute__((ext_vector_type(4)));
     __shared__ v4f terms[2][P][64];              // (att, e_0, e_1, e_2) of a list position, per ray
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * 64 + lane);
+    const int64_t tile = (int64_t)blockIdx.x + rays.tile0;
+    const int64_t q = ray_of_thread(rays, tile * 64 + lane);
     const bool inb = q < rays.Q;
     uint4 a = make_uint4(0u, 0u, 0u, 0u);
     if (inb) a = aux[q];
@@ -453,7 +454,7 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, const uint2* __restrict__ 
         if (wave > 0) {
             const int k = rd * P + (wave - 1);
             if (rd < nround && k < nrec) {
-                const uint2 e = rec_get(rec + rec_index((int64_t)blockIdx.x * 64 + lane, k, S));
+                const uint2 e = rec_get(rec + rec_index(tile * 64 + lane, k, S));
                 const int32_t idx = (int32_t)e.x;
                 float row[K];
                 load_row<K>(tr.features + (int64_t)idx * K, row);
@@ -515,6 +516,108 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, const uint2* __restrict__ 
         a.z = __float_as_uint(light);                // the final transmittance, for the single-march backward
         aux[q] = a;
     }
+}
+
+// The shade kernel for RGBA-style rows of K = 8, 16 or 32 floats (C = K - 1 feature channels and
+// sigma: BASELINE configs[3] is K = 32): CHANNELS on lanes.  A wavefront takes 64 / K rays; lane
+// (g, c) is channel c of ray g.  Per list position a lane reads ITS float of the sample's row --
+// the K lanes of a ray read one contiguous row -- and forms one exponential; the sigma lane
+// (c = K - 1) forms the attenuation instead and hands it to its group (one cross-lane read), then
+// every channel lane runs its own chain  acc = float(double(acc) + double(T (1 - att)) / (1.0 +
+// double(e)))  along the ray: the same operations in the same order as render_fwd_kernel, bit for
+// bit, with every lane busy, ~30 registers, no LDS, no barrier.  (render_fwd_kernel<RGBA, 31>
+// keeps 31 accumulators and the 32-float row per lane: 1.1 wavefronts per SIMD on average and the
+// VALU half idle at 1024 x 1024, depth 9 -- r02 PMC -- because a wavefront shades all 31
+// channels of whichever of its 64 rays have a sample.)
+// FAST (opt-in tolerance mode): the quotient in float with the hardware reciprocal,
+// acc += w * rcp(1 + e): each term within 2e-7 of the reference's double-precision quotient.
+template <int K, bool STOP, bool FAST>
+__global__ void __launch_bounds__(256)
+shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, const uint2* __restrict__ rec, int S,
+                  uint4* __restrict__ aux, float* __restrict__ out) {
+    static_assert(K == 8 || K == 16 || K == 32, "row widths with a channel-lane instance");
+    constexpr int RPW = 64 / K;                                  // rays per wavefront
+    const int lane = threadIdx.x & 63;
+    const int c = lane & (K - 1);
+    const int sig_lane = lane | (K - 1);                         // the sigma lane of this lane's ray
+    // t: the launch thread of march_rec_kernel that holds this ray (tile t >> 6, lane t & 63)
+    const int64_t t = (int64_t)rays.tile0 * 64 + ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + (lane / K);
+    const int64_t q = ray_of_thread(rays, t);
+    const bool inb = q < rays.Q;
+    uint4 a = make_uint4(0u, 0u, 0u, 0u);
+    if (inb) a = aux[q];
+    const int nrec = (int)(a.x & ~kRecOverflow);
+    int maxn = nrec;
+    for (int off = 32; off >= K; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
+    maxn = __builtin_amdgcn_readfirstlane(maxn);
+    float ds = 0.f;
+    if (nrec > 0) {
+        Ray r;
+        setup_ray(tr, rays, opt, q, r);                          // a ray with samples hits the cube
+        ds = r.delta_scale;
+    }
+    const uint2* __restrict__ my = rec + rec_index(t, 0, S);     // this ray's block 0, slot 0
+    const int64_t blk = (int64_t)64 * kRecBlock;                 // records from block b to block b + 1
+    float light = 1.f, acc = 0.f;
+    bool stopped = false;
+    // A block of 8 records is the ray's own 64-byte line: fetch it whole, request the 8 rows it
+    // names back to back (the K lanes of a ray: one contiguous row each), form the 8 exponentials --
+    // all independent -- and only then run the chain along the ray.  (One record, one row, one step
+    // at a time the kernel was a chain of two dependent loads per sample: 1.12 ms at 1024 x 1024,
+    // depth 9, K = 32, and no faster with the float quotient.)
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    for (int kb = 0; kb < maxn; kb += kRecBlock) {
+        uint32_t idx[kRecBlock];
+        float dt[kRecBlock], ex[kRecBlock];
+        const int n_here = min(nrec - kb, kRecBlock);            // records of this ray in the block (<= 0: none)
+        if (n_here > 0) {
+            const v4u* line = reinterpret_cast<const v4u*>(my + (kb >> 3) * blk);
+#pragma unroll
+            for (int j = 0; j < kRecBlock / 2; ++j) {
+                const v4u w = __builtin_nontemporal_load(line + j);
+                idx[2 * j] = w.x; dt[2 * j] = __uint_as_float(w.y);
+                idx[2 * j + 1] = w.z; dt[2 * j + 1] = __uint_as_float(w.w);
+            }
+        }
+        float x[kRecBlock];
+#pragma unroll
+        for (int j = 0; j < kRecBlock; ++j) {
+            x[j] = 0.f;
+            if (j < n_here) x[j] = tr.features[(int64_t)(int32_t)idx[j] * K + c];
+        }
+#pragma unroll
+        for (int j = 0; j < kRecBlock; ++j) {
+            ex[j] = 1.f;
+            if (j < n_here) ex[j] = pexpf(c == K - 1 ? -dt[j] * ds * x[j] : -x[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < kRecBlock; ++j) {
+            const float att = __shfl(ex[j], sig_lane, 64);       // every lane takes part
+            if (j < n_here && !stopped) {
+                const float weight = light * (1.f - att);
+                if constexpr (FAST) acc += weight * __builtin_amdgcn_rcpf(1.f + ex[j]);
+                else acc = (float)((double)acc + (double)weight / (1.0 + (double)ex[j]));
+                light *= att;
+                if constexpr (STOP) {
+                    if (light <= opt.stop_thresh) stopped = true;
+                }
+            }
+        }
+    }
+    if (!inb) return;
+    const bool over = (a.x & kRecOverflow) != 0u && !stopped;    // state for render_fwd_kernel<..., RESUME>
+    float v;
+    if (c < K - 1) {
+        if (stopped) v = acc * (float)(1.0 / (1.0 - (double)light));
+        else if (over) v = acc;
+        else v = acc + light * opt.background_brightness;
+    } else {
+        v = over ? light : 1.f - light;
+        if (stopped) a.x &= ~kRecOverflow;
+        a.z = __float_as_uint(light);
+        aux[q] = a;
+    }
+    out[q * K + c] = v;
 }
 
 // ---------------------------------------------------------------------------
@@ -2295,6 +2398,7 @@ RaysDev to_dev(const svoxt_rays* r) {
     const bool tiled = r->image_width > 0 && r->image_height > 0 && r->image_width % 8 == 0 &&
                        r->image_height % 8 == 0 && (int64_t)r->image_width * r->image_height == r->Q;
     d.tiles_per_row = tiled ? r->image_width / 8 : 0;
+    d.tile0 = 0;
     d.c2w = r->c2w; d.fx = r->fx; d.fy = r->fy;
     d.width = r->image_width; d.height = r->image_height;
     return d;
@@ -2392,6 +2496,8 @@ bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
     return true;
     if (opt.format == FMT_RGBA) {
         if (C == 3) { SVOXT_FWD(FMT_RGBA, 3, 0) }
+        if (C == 7) { SVOXT_FWD(FMT_RGBA, 7, 0) }
+        if (C == 15) { SVOXT_FWD(FMT_RGBA, 15, 0) }
         if (C == 31) { SVOXT_FWD(FMT_RGBA, 31, 0) }
     } else if (opt.format == FMT_SH && C == 3) {
         switch (opt.basis_dim) {
@@ -2406,30 +2512,30 @@ bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
     return false;
 }
 
-// two-kernel forward (march_rec_kernel + shade_tile_kernel + tail launch of render_fwd_kernel):
-// 3-channel payloads, all components.  SVOXT_FWD_SPLIT=1 selects it; the default is the
-// one-kernel forward (r02, 800x800 depth-8 SH9: 0.247 ms against 0.156 + 0.123 ms).
-bool fwd_split_enabled() {      // read per call: tests and timing scripts compare the two forwards in one process
+// two-kernel forward (march_rec_kernel + a shade kernel + tail launch of render_fwd_kernel), all
+// components.  Default: on for RGBA-style rows of 8 / 16 / 32 floats (shade_chan_kernel: r02,
+// 1024 x 1024 depth-9 K = 32), off for the 3-channel payloads (shade_tile_kernel:
+// 800x800 depth-8 SH9 0.156 + 0.123 ms against 0.247 ms for the one-kernel forward).
+// SVOXT_FWD_SPLIT=0 / 1 forces it off / on where a shade kernel exists.
+bool fwd_split_enabled(const svoxt_tree* t, const svoxt_options* o) {   // read per call: tests compare both in one process
     const char* e = getenv("SVOXT_FWD_SPLIT");
-    return e != nullptr && atoi(e) != 0;
+    if (e != nullptr && *e != 0) return atoi(e) != 0;
+    return o->format == SVOXT_FORMAT_RGBA && (t->K == 8 || t->K == 16 || t->K == 32);
 }
 
 bool fwd_split_payload(const svoxt_tree* t, const svoxt_options* o, int C) {
-    if (C != 3 || t->weight_accum != nullptr) return false;
+    if (t->weight_accum != nullptr) return false;
+    if (o->format == SVOXT_FORMAT_RGBA && (t->K == 8 || t->K == 16 || t->K == 32)) return true;   // channel lanes
+    if (C != 3) return false;
     if (o->format == SVOXT_FORMAT_RGBA) return t->K == 4;
     if (o->format != SVOXT_FORMAT_SH || t->K != 3 * o->basis_dim + 1) return false;
     return o->basis_dim == 1 || o->basis_dim == 4 || o->basis_dim == 9 || o->basis_dim == 16 || o->basis_dim == 25;
 }
 
+// The shade (+ tail) launches of one range of tiles.
 template <bool N2, bool STOP>
-bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out,
-                      uint2* rec, int S, uint4* aux, bool xf, hipStream_t st) {
-    const unsigned nb = nblocks(rays.Q);
-    if (xf && !N2) return false;
-    if (N2 && tr.accel != nullptr)
-        hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 1>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, rec, S, aux);
-    else
-        hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 0>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, rec, S, aux);
+bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out, uint2* rec, int S, uint4* aux,
+                  bool xf, bool fast, unsigned nb, hipStream_t st) {
 #define SVOXT_SPLIT(F, BB, X)                                                                                 \
     {                                                                                                         \
         hipLaunchKernelGGL((shade_tile_kernel<F, BB, X, STOP>), dim3(nb), dim3(512), 0, st, tr, rays, opt,    \
@@ -2437,6 +2543,27 @@ bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
         hipLaunchKernelGGL((render_fwd_kernel<F, 3, BB, N2, false, X, true>), dim3(nb), dim3(kBlock), 0, st,  \
                            tr, rays, opt, out, (uint2*)nullptr, S, aux);                                      \
         return true;                                                                                          \
+    }
+    if (opt.format == FMT_RGBA && tr.K != 4) {
+        // rows of 8 / 16 / 32 floats: channels on lanes, 64 / K rays per wavefront, 4 wavefronts per workgroup
+#define SVOXT_CHAN(KK)                                                                                        \
+        {                                                                                                     \
+            const unsigned nbc = (unsigned)(((int64_t)nb * 64 / (64 / KK) + 3) / 4);                          \
+            if (fast) hipLaunchKernelGGL((shade_chan_kernel<KK, STOP, true>), dim3(nbc), dim3(256), 0, st,    \
+                                         tr, rays, opt, rec, S, aux, out);                                    \
+            else hipLaunchKernelGGL((shade_chan_kernel<KK, STOP, false>), dim3(nbc), dim3(256), 0, st,        \
+                                    tr, rays, opt, rec, S, aux, out);                                         \
+            hipLaunchKernelGGL((render_fwd_kernel<FMT_RGBA, KK - 1, 0, N2, false, false, true>), dim3(nb),    \
+                               dim3(kBlock), 0, st, tr, rays, opt, out, (uint2*)nullptr, S, aux);             \
+            return true;                                                                                      \
+        }
+        switch (tr.K) {
+            case 8: SVOXT_CHAN(8)
+            case 16: SVOXT_CHAN(16)
+            case 32: SVOXT_CHAN(32)
+        }
+#undef SVOXT_CHAN
+        return false;
     }
     if (opt.format == FMT_RGBA) SVOXT_SPLIT(FMT_RGBA, 0, false)
     if constexpr (N2) {
@@ -2460,6 +2587,71 @@ bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
     }
 #undef SVOXT_SPLIT
     return false;
+}
+
+// A side stream and a few events per device, made on first use: the march of one range of tiles
+// runs on the caller's stream while the side stream shades the range before it.  (The idea: the
+// march is bound by its dependent loads and leaves the vector ALUs half idle, the shade kernels
+// are bound by those ALUs.  See fwd_split_chunks for what it measured.)
+struct SideStream {
+    hipStream_t st = nullptr;
+    hipEvent_t ev[8] = {};
+    bool ok = false;
+};
+SideStream* side_stream() {
+    static thread_local SideStream tab[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStream& s = tab[dev];
+    if (!s.ok) {
+        if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (auto& e : s.ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        s.ok = true;
+    }
+    return &s;
+}
+
+// Measured r02 and NOT the default: with 4 ranges the forward got slower, not faster (800x800
+// depth-8 SH9 0.29 -> 0.59 ms, 1024x1024 depth-9 K = 32 1.47 -> 2.0 ms): each cross-stream event
+// dependency costs more than the overlap returns.  SVOXT_FWD_CHUNKS=n (2..7) keeps the experiment
+// reachable; the default is one range on the caller's stream.
+int fwd_split_chunks(int64_t ntiles) {
+    const char* e = getenv("SVOXT_FWD_CHUNKS");
+    int n = (e != nullptr && *e != 0) ? atoi(e) : 1;
+    if (n < 1) n = 1;
+    if (n > 7) n = 7;
+    return (int64_t)n > ntiles ? (int)ntiles : n;
+}
+
+template <bool N2, bool STOP>
+bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out,
+                      uint2* rec, int S, uint4* aux, bool xf, bool fast, hipStream_t st) {
+    const unsigned nb = nblocks(rays.Q);
+    if (xf && !N2) return false;
+    const bool acc = N2 && tr.accel != nullptr;
+    int nchunk = fwd_split_chunks(nb);
+    SideStream* ss = nchunk > 1 ? side_stream() : nullptr;
+    if (ss == nullptr) nchunk = 1;
+    bool ok = true;
+    for (int c = 0; c < nchunk && ok; ++c) {
+        const unsigned lo = (unsigned)((uint64_t)nb * c / nchunk), hi = (unsigned)((uint64_t)nb * (c + 1) / nchunk);
+        RaysDev rc = rays;
+        rc.tile0 = lo;
+        if (acc) hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 1>), dim3(hi - lo), dim3(kBlock), 0, st, tr, rc, opt, rec, S, aux);
+        else hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 0>), dim3(hi - lo), dim3(kBlock), 0, st, tr, rc, opt, rec, S, aux);
+        if (nchunk == 1) {
+            ok = launch_shade<N2, STOP>(tr, rc, opt, out, rec, S, aux, xf, fast, hi - lo, st);
+        } else {
+            // the side stream takes over this range once its march is done
+            if (hipEventRecord(ss->ev[c], st) != hipSuccess || hipStreamWaitEvent(ss->st, ss->ev[c], 0) != hipSuccess) return false;
+            ok = launch_shade<N2, STOP>(tr, rc, opt, out, rec, S, aux, xf, fast, hi - lo, ss->st);
+        }
+    }
+    if (nchunk > 1) {   // join: what follows on the caller's stream sees every pixel
+        if (hipEventRecord(ss->ev[7], ss->st) != hipSuccess || hipStreamWaitEvent(st, ss->ev[7], 0) != hipSuccess) return false;
+    }
+    return ok;
 }
 
 // two-kernel backward: SH 1/4/9 (also with view rotations) and RGBA with 3 channels
@@ -2539,6 +2731,8 @@ bool launch_bwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
     return true;
     if (opt.format == FMT_RGBA) {
         if (C == 3) { SVOXT_BWD(FMT_RGBA, 3, 0) }
+        if (C == 7) { SVOXT_BWD(FMT_RGBA, 7, 0) }
+        if (C == 15) { SVOXT_BWD(FMT_RGBA, 15, 0) }
         if (C == 31) { SVOXT_BWD(FMT_RGBA, 31, 0) }
     } else if (opt.format == FMT_SH && C == 3) {
         switch (opt.basis_dim) {
@@ -2667,7 +2861,7 @@ static int check_lists(const svoxt_sample_lists* l, const svoxt_options* opt, co
 
 static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt, float* out,
                       const svoxt_sample_lists* lists, void* stream, const char* fn,
-                      void* workspace = nullptr, int64_t workspace_bytes = 0) {
+                      void* workspace = nullptr, int64_t workspace_bytes = 0, int32_t flags = 0) {
     int rc;
     if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) || (rc = check_opts(opt, tree, fn, true)))
         return rc;
@@ -2688,20 +2882,21 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
     bool done = false;
     // two kernels (march, shade per tile) where there is room for the lists: the caller's,
     // or scratch (then the stop rule applies while marching -- those lists serve no backward)
-    if (fwd_split_enabled() && full_comp(opt) && fwd_split_payload(tree, opt, C) &&
+    const bool fast = (flags & SVOXT_FWD_FAST_SIGMOID) != 0;
+    if (fwd_split_enabled(tree, opt) && full_comp(opt) && fwd_split_payload(tree, opt, C) &&
         (!uses_xform(tree, opt) || xform_special(tree, opt))) {
         const bool xf = uses_xform(tree, opt);
         if (lists != nullptr) {
             uint2* rec = reinterpret_cast<uint2*>(lists->rec);
             uint4* aux = reinterpret_cast<uint4*>(lists->aux);
-            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, rec, lists->max_samples, aux, xf, st)
-                      : launch_fwd_split<false, false>(tr, rd, od, out, rec, lists->max_samples, aux, xf, st);
+            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, rec, lists->max_samples, aux, xf, false, st)
+                      : launch_fwd_split<false, false>(tr, rd, od, out, rec, lists->max_samples, aux, xf, false, st);
         } else if (workspace != nullptr && rec_capacity(workspace_bytes - rec_rays(rays->Q) * 16, rays->Q) >= kRecBlock) {
             const int64_t S = rec_capacity(workspace_bytes - rec_rays(rays->Q) * 16, rays->Q);
             uint4* aux = reinterpret_cast<uint4*>(workspace);                       // aux first: rec stays 64-byte aligned
             uint2* rec = reinterpret_cast<uint2*>(reinterpret_cast<char*>(workspace) + rec_rays(rays->Q) * 16);
-            done = n2 ? launch_fwd_split<true, true>(tr, rd, od, out, rec, (int)S, aux, xf, st)
-                      : launch_fwd_split<false, true>(tr, rd, od, out, rec, (int)S, aux, xf, st);
+            done = n2 ? launch_fwd_split<true, true>(tr, rd, od, out, rec, (int)S, aux, xf, fast, st)
+                      : launch_fwd_split<false, true>(tr, rd, od, out, rec, (int)S, aux, xf, fast, st);
         }
         if (done) return check_launch(fn);
     }
@@ -2746,11 +2941,11 @@ int64_t svoxt_fwd_workspace_bytes(int64_t Q, int32_t max_samples) {
 }
 
 int svoxt_volume_render_fwd_ws(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
-                               float* out, void* workspace, int64_t workspace_bytes, void* stream) {
+                               float* out, void* workspace, int64_t workspace_bytes, int32_t flags, void* stream) {
     if (workspace_bytes < 0) return fail(SVOXT_ERR_INVALID, "%s: negative workspace size", "svoxt_volume_render_fwd_ws");
     if (workspace != nullptr && ((uintptr_t)workspace & 63u) != 0)
         return fail(SVOXT_ERR_INVALID, "%s: workspace must be 64-byte aligned", "svoxt_volume_render_fwd_ws");
-    return fwd_common(tree, rays, opt, out, nullptr, stream, "svoxt_volume_render_fwd_ws", workspace, workspace_bytes);
+    return fwd_common(tree, rays, opt, out, nullptr, stream, "svoxt_volume_render_fwd_ws", workspace, workspace_bytes, flags);
 }
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt) {
@@ -2758,7 +2953,7 @@ int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt) {
     if (opt->sigma_thresh != 0.f || opt->stop_thresh != 0.f || !full_comp(opt)) return 0;
     if (uses_xform(tree, opt)) return xform_special(tree, opt) ? 1 : 0;
     const int C = svoxt_out_data_dim(opt, tree->K) - 1;
-    if (opt->format == SVOXT_FORMAT_RGBA) return (C == 3 || C == 31) ? 1 : 0;
+    if (opt->format == SVOXT_FORMAT_RGBA) return (C == 3 || C == 7 || C == 15 || C == 31) ? 1 : 0;
     if (opt->format == SVOXT_FORMAT_SH && C == 3 && tree->K == 3 * opt->basis_dim + 1)
         return (opt->basis_dim == 1 || opt->basis_dim == 4 || opt->basis_dim == 9 || opt->basis_dim == 16 ||
                 opt->basis_dim == 25) ? 1 : 0;

@@ -42,6 +42,11 @@ def _rays_spec_from_rays(rays, image_shape=None, sort_rays=None):
     return spec
 
 
+def _will_differentiate(features) -> bool:
+    """Can a backward follow this call?  Known here, outside autograd.Function.apply."""
+    return bool(torch.is_grad_enabled() and features.requires_grad)
+
+
 def _make_camera_spec(c2w, width, height, fx, fy):
     """svox_t/renderer.py:51-58."""
     spec = _C.CameraSpec()
@@ -97,12 +102,13 @@ class _VolumeRenderFunction(autograd.Function):
     opt), the specs kept on the ctx (not save_for_backward), a gradient for argument 0 only.
     What makes the pair fast -- sample lists recorded by the forward and replayed by the backward,
     coherent ray order -- happens below these two calls (svox_t_amd.csrc, _Plan), so the
-    reference's own function gets it too.  The one addition: the forward says whether a backward
-    will follow (inside an autograd.Function the operator layer cannot see that)."""
+    reference's own function gets it too.  (Whether a backward can follow is said by the caller of
+    apply() on the spec, `need_grad`: inside an autograd.Function grad mode is off and
+    ctx.needs_input_grad ignores torch.no_grad(); without the hint the feature table's
+    requires_grad decides.)"""
 
     @staticmethod
     def forward(ctx, data, tree, rays, opt):
-        rays.need_grad = ctx.needs_input_grad[0]
         out = _C.volume_render(tree, rays, opt)
         ctx.tree = tree
         ctx.rays = rays
@@ -121,7 +127,6 @@ class _VolumeRenderImageFunction(autograd.Function):
 
     @staticmethod
     def forward(ctx, data, tree, cam, opt):
-        cam.need_grad = ctx.needs_input_grad[0]
         out = _C.volume_render_image(tree, cam, opt)
         ctx.tree = tree
         ctx.cam = cam
@@ -160,7 +165,6 @@ class _OpacityRenderFunction(autograd.Function):
 
     @staticmethod
     def forward(ctx, data, tree, rays, opt):
-        rays.need_grad = ctx.needs_input_grad[0]
         out = _C.opacity_render(tree, rays, opt)
         ctx.tree = tree
         ctx.rays = rays
@@ -226,10 +230,12 @@ class VolumeRenderer(nn.Module):
         :return: [Q, C+1]: C colour/feature channels then accumulated alpha
         """
         self._require_gpu(cuda, "forward")
+        rspec = _rays_spec_from_rays(rays, image_shape, sort_rays)
+        rspec.need_grad = _will_differentiate(features)
         return _VolumeRenderFunction.apply(
             features,
             self.tree._spec(features, transformation_matrices=transformation_matrices),
-            _rays_spec_from_rays(rays, image_shape, sort_rays),
+            rspec,
             self._get_options(fast))
 
     def render_persp(self, features, c2w, width=800, height=800, fx=1111.111, fy=None,
@@ -252,9 +258,9 @@ class VolumeRenderer(nn.Module):
         if fy is None:
             fy = fx
         c2w = c2w.to(device=self.tree.data.device, dtype=torch.float32).contiguous()
-        return _VolumeRenderImageFunction.apply(
-            features, self.tree._spec(features), _make_camera_spec(c2w, width, height, fx, fy),
-            self._get_options(fast))
+        cam = _make_camera_spec(c2w, width, height, fx, fy)
+        cam.need_grad = _will_differentiate(features)
+        return _VolumeRenderImageFunction.apply(features, self.tree._spec(features), cam, self._get_options(fast))
 
     def motion_render(self, features, rays: Rays, cuda=True, fast=False, image_shape=None):
         """First sample with sigma > sigma_thresh per ray (svox_t/renderer.py:367-375):
@@ -284,9 +290,9 @@ class VolumeRenderer(nn.Module):
     def opacity_render(self, features, rays: Rays, cuda=True, fast=False, image_shape=None, sort_rays=None):
         """[Q, 1] accumulated alpha only; differentiable wrt `features` (sort_rays: see forward)."""
         self._require_gpu(cuda, "opacity_render")
-        return _OpacityRenderFunction.apply(
-            features, self.tree._spec(features), _rays_spec_from_rays(rays, image_shape, sort_rays),
-            self._get_options(fast))
+        rspec = _rays_spec_from_rays(rays, image_shape, sort_rays)
+        rspec.need_grad = _will_differentiate(features)
+        return _OpacityRenderFunction.apply(features, self.tree._spec(features), rspec, self._get_options(fast))
 
     def _get_options(self, fast=False):
         """RenderOptions for the operator boundary (svox_t/renderer.py:408-439)."""

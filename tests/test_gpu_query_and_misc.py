@@ -366,8 +366,28 @@ def test_config4_depth9_features32_and_depth(gpu):
     sel = np.random.default_rng(0).choice(c.Q, size=60000, replace=False)
     o, d, v = (a[sel] for a in c.rays_np())
     ot = c.oracle_tree()
-    np.testing.assert_array_equal(out[sel].cpu().numpy(), O.volume_render(ot, o, d, v, c.oracle_opts()))
+    want = O.volume_render(ot, o, d, v, c.oracle_opts())
+    np.testing.assert_array_equal(out[sel].cpu().numpy(), want)
     np.testing.assert_array_equal(depth[sel].cpu().numpy(), O.render_depth(ot, o, d, v, c.oracle_opts()))
+    # the same through the one-kernel forward (the default for this payload is march + channel-lane shade)
+    import os
+    os.environ["SVOXT_FWD_SPLIT"] = "0"
+    try:
+        with torch.no_grad():
+            assert torch.equal(r(tree.features, rays), out)
+    finally:
+        del os.environ["SVOXT_FWD_SPLIT"]
+    # opt-in tolerance mode (SVOXT_FAST_SIGMOID: float quotient): 1e-5 relative, at full size
+    _C.FAST_SIGMOID = True
+    try:
+        with torch.no_grad():
+            fast = r(tree.features, rays)
+    finally:
+        _C.FAST_SIGMOID = False
+    assert not torch.equal(fast, out)
+    assert_outputs_close(fast[sel].cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    rel = ((fast - out).abs() / out.abs().clamp_min(1e-3)).max().item()
+    assert rel <= 1e-5, rel
     # depth is 0 exactly where nothing was hit, else inside the cube's extent
     dn, an = depth.cpu().numpy()[:, 0], out[:, 31].cpu().numpy()
     assert np.all((dn == 0) == (an == 0))

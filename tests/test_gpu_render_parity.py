@@ -15,6 +15,9 @@ CASES = {
     "d5_rgba4": dict(depth=5, K=4, data_format="RGBA", width=64, height=64),
     "d5_sh9": dict(depth=5, K=28, data_format="SH9", width=64, height=64),
     "d6_rgba32": dict(depth=6, K=32, data_format="RGBA", width=96, height=96),
+    # RGBA-style rows of 8 / 16 floats: channel-lane shade kernel, one-kernel forward / backward instances for C = 7 / 15
+    "d5_rgba8": dict(depth=5, K=8, data_format="RGBA", width=64, height=64),
+    "d5_rgba16": dict(depth=5, K=16, data_format="RGBA", width=56, height=56),
     "d5_sh4_world": dict(depth=5, K=13, data_format="SH4", width=64, height=64,
                          radius=[1.0, 1.2, 0.8], center=[0.1, -0.2, 0.3]),
     "d5_sh1": dict(depth=5, K=4, data_format="SH1", width=48, height=48),
@@ -238,7 +241,7 @@ def test_two_kernel_backward_extreme_coherence(gpu, kind):
 
 
 
-@pytest.mark.parametrize("name", ["d5_rgba4", "d5_sh9", "d5_sh4_world", "d4_sh16"])
+@pytest.mark.parametrize("name", ["d5_rgba4", "d5_sh9", "d5_sh4_world", "d4_sh16", "d5_rgba8", "d5_rgba16", "d6_rgba32"])
 def test_two_kernel_forward_equals_one_kernel_forward(name, gpu, monkeypatch):
     """SVOXT_FWD_SPLIT=1 (march_rec_kernel + shade_tile_kernel + tail launch, through
     svoxt_volume_render_fwd_ws and svoxt_volume_render_fwd_record) against the one-kernel forward:
