@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 10
+#define SVOXT_ABI_VERSION 11
 
 enum {
     SVOXT_OK = 0,
@@ -211,6 +211,11 @@ typedef struct svoxt_sample_lists {
                               selects the two-kernel form); -1 with coef NULL: take the per-tile route if it
                               can run as ONE kernel (no view rotations, fwd_out given: list walk and merge
                               fused, nothing goes through coef), else the one-kernel backward */
+    void*   terms;         /* device, 16-byte aligned, terms_bytes >= max_samples * ceil(Q / 64) * 64 * 16, or NULL:
+                              scratch for that ONE kernel in its exact form (fwd_out NULL).  Its first sweep
+                              over the lists then leaves each sample's attenuation and three exponentials for
+                              the second, which no longer gathers the feature row again.  Same bits either way. */
+    int64_t terms_bytes;
 } svoxt_sample_lists;
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt);

@@ -43,7 +43,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -88,7 +88,8 @@ class _COptions(ctypes.Structure):       # struct svoxt_options
 
 class _CLists(ctypes.Structure):         # struct svoxt_sample_lists
     _fields_ = [("rec", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("max_samples", ctypes.c_int32),
-                ("coef", ctypes.c_void_p), ("coef_bytes", ctypes.c_int64)]
+                ("coef", ctypes.c_void_p), ("coef_bytes", ctypes.c_int64),
+                ("terms", ctypes.c_void_p), ("terms_bytes", ctypes.c_int64)]
 
 
 _P = ctypes.POINTER
@@ -447,11 +448,14 @@ class SampleLists:
         self.S = S
         self.coef = None        # allocated by the backward when it takes the two-kernel route,
         self.consumed = False   # which rewrites `rec`: the lists then serve no second backward
+        self.terms = None       # scratch of the exact one-kernel backward (allocated there)
 
     def c_struct(self):
         return _CLists(self.rec.data_ptr(), self.aux.data_ptr(), self.S,
                        None if self.coef is None else self.coef.data_ptr(),
-                       0 if self.coef is None else self.coef.numel() * 4)
+                       0 if self.coef is None else self.coef.numel() * 4,
+                       None if self.terms is None else self.terms.data_ptr(),
+                       0 if self.terms is None else self.terms.numel() * 4)
 
 
 def can_record(tree: TreeSpec, opt: RenderOptions) -> bool:
@@ -642,6 +646,7 @@ BWD_EXACT = os.environ.get("SVOXT_BWD_EXACT", "1") not in ("", "0")
 # merge in LDS -> one atomic row per tile and feature row, include/svoxt.h
 # svoxt_sample_lists.coef) for batches declared as images; 2: whenever the payload allows
 GATHER_ALIGNED = os.environ.get("SVOXT_GATHER_ALIGNED", "1") not in ("", "0")   # 64-byte-aligned rows for the merge kernel too
+BWD_TERMS = os.environ.get("SVOXT_BWD_TERMS", "1") not in ("", "0")   # 0: the exact one-kernel backward gathers every row twice
 BWD_FUSED = os.environ.get("SVOXT_BWD_FUSED", "1") not in ("", "0")   # 0: list walk and merge as two kernels (a coef buffer is handed over)
 BWD_GATHER = int(os.environ.get("SVOXT_BWD_GATHER", "1") or 0)     # 0 never, 1 for image batches, 2 whenever possible
 
@@ -699,6 +704,10 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
                     raise RuntimeError("fwd_output must match grad_output")
                 fo = fwd_output
             fused = gather and BWD_FUSED and ct.xform is None      # (fo None: the fused kernel's exact form)
+            if fused and fo is None and BWD_TERMS:
+                # sweep 1 -> sweep 2 hand-over: 16 bytes per list slot (as large again as rec twice over;
+                # the caching allocator keeps it between steps)
+                lists.terms = torch.empty((lists.rec.shape[0] * 4,), dtype=torch.float32, device=dev)
             if gather and not fused:
                 # with view rotations a second plane holds each sample's rotated direction
                 planes = 2 if ct.xform is not None else 1

@@ -364,54 +364,57 @@ march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, uint2* __restrict__ rec, in
     const int K = tr.K;
     const float* __restrict__ sig_col = tr.features + (K - 1);
     int nrec = 0;
-    bool over = false;
+    uint32_t over = 0u;                  // kRecOverflow once the list is full
     float t_resume = 0.f;
     float light = 1.f;
     float t = r.tmin;
-    // the crossing whose sigma is in flight
-    bool pend = false;
-    float p_sigma = 0.f, p_dt = 0.f, p_t = 0.f;
+    // The crossing whose sigma is in flight.  No boolean lives across iterations (each would be a
+    // lane mask merged with scalar instructions at every branch: r02, 87 of the loop's 186
+    // instructions per crossing were such mask arithmetic): "nothing pending" is sigma = -inf,
+    // "stop marching" is t = +inf.
+    const float kNone = -__builtin_inff();
+    float p_sigma = kNone, p_dt = 0.f, p_t = 0.f;
     int32_t p_idx = 0;
-    bool done = false;
     while (t < r.tmax) {
         Sample s;
         march_step<N2, ACC>(tr, r, opt.step_size, t, s);
-        if (pend && p_sigma > opt.sigma_thresh) {
+        const float t_cur = t;
+        t = march_advance(t, s.delta_t);
+        bool keep = true;
+        if (p_sigma > opt.sigma_thresh) {
             if (nrec < S) {
                 rec_stage_put(rstage, (int)threadIdx.x, rec, tid, S, nrec, (uint32_t)p_idx, p_dt);
                 ++nrec;
+                if constexpr (STOP) {
+                    light *= pexpf(-p_dt * r.delta_scale * p_sigma);
+                    if (light <= opt.stop_thresh) { t = __builtin_inff(); keep = false; }
+                }
             } else {        // list full: whoever consumes it marches on from this crossing
-                over = true;
+                over = kRecOverflow;
                 t_resume = p_t;
-                done = true;
-                break;
-            }
-            if constexpr (STOP) {
-                light *= pexpf(-p_dt * r.delta_scale * p_sigma);
-                if (light <= opt.stop_thresh) { done = true; break; }
+                t = __builtin_inff();
+                keep = false;
             }
         }
-        pend = s.valid;
-        if (pend) {
+        p_sigma = kNone;
+        if (keep && s.valid) {
             p_sigma = sig_col[(int64_t)s.idx * K];
             p_idx = s.idx;
             p_dt = s.delta_t;
-            p_t = t;
+            p_t = t_cur;
         }
-        t = march_advance(t, s.delta_t);
     }
-    if (!done && pend && p_sigma > opt.sigma_thresh) {
+    if (p_sigma > opt.sigma_thresh) {    // the last crossing's sample
         if (nrec < S) {
             rec_stage_put(rstage, (int)threadIdx.x, rec, tid, S, nrec, (uint32_t)p_idx, p_dt);
             ++nrec;
         } else {
-            over = true;
+            over = kRecOverflow;
             t_resume = p_t;
         }
     }
     rec_stage_finish(rstage, (int)threadIdx.x, rec, tid, S, nrec);
-    aux[q] = make_uint4((uint32_t)nrec | (over ? kRecOverflow : 0u), __float_as_uint(t_resume),
-                        __float_as_uint(1.f), 0u);
+    aux[q] = make_uint4((uint32_t)nrec | over, __float_as_uint(t_resume), __float_as_uint(1.f), 0u);
 }
 
 template <int FMT, int BD, bool XF, bool STOP>
@@ -616,6 +619,70 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, const uint2* __restrict__ 
         if (stopped) a.x &= ~kRecOverflow;
         a.z = __float_as_uint(light);
         aux[q] = a;
+    }
+    out[q * K + c] = v;
+}
+
+// The tail launch for those rows: rays whose list overflowed (1.3 % at 1024 x 1024, depth 9,
+// S = 96 -- but as render_fwd_kernel<RGBA, 31, ..., RESUME> they cost 0.25 ms, a lane shading 31
+// channels per sample) continue with the same lane layout as shade_chan_kernel: the K lanes of a
+// ray march it together (the same steps in every lane: redundant, but a march is latency, not
+// work) and each shades its own channel.  State in and out as for the RESUME launch.
+template <int K, bool N2, bool FAST>
+__global__ void __launch_bounds__(256)
+tail_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, uint4* __restrict__ aux, float* __restrict__ out) {
+    constexpr int RPW = 64 / K;
+    const int lane = threadIdx.x & 63;
+    const int c = lane & (K - 1);
+    const int sig_lane = lane | (K - 1);
+    const int64_t t0 = (int64_t)rays.tile0 * 64 + ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + (lane / K);
+    const int64_t q = ray_of_thread(rays, t0);
+    uint4 a = make_uint4(0u, 0u, 0u, 0u);
+    if (q < rays.Q) a = aux[q];
+    bool alive = (a.x & kRecOverflow) != 0u;
+    if (!__any(alive)) return;
+    Ray r;
+    float light = 1.f, acc = 0.f, t = 0.f, tmax = -1.f;
+    bool stopped = false;
+    if (alive) {
+        setup_ray(tr, rays, opt, q, r);
+        t = __uint_as_float(a.y);
+        tmax = r.tmax;
+        light = out[q * K + (K - 1)];
+        if (c < K - 1) acc = out[q * K + c];
+    }
+    while (__any(alive && t < tmax)) {
+        const bool go = alive && t < tmax;
+        float x = 0.f, dt = 0.f;
+        bool valid = false;
+        if (go) {
+            Sample s;
+            march_step<N2>(tr, r, opt.step_size, t, s);
+            dt = s.delta_t;
+            valid = s.valid;
+            if (valid) x = tr.features[(int64_t)s.idx * K + c];
+            t = march_advance(t, s.delta_t);
+        }
+        const float sigma = __shfl(x, sig_lane, 64);
+        const bool active = go && valid && sigma > opt.sigma_thresh;
+        float ex = 1.f;
+        if (active) ex = pexpf(c == K - 1 ? -dt * r.delta_scale * x : -x);
+        const float att = __shfl(ex, sig_lane, 64);
+        if (active) {
+            const float weight = light * (1.f - att);
+            if constexpr (FAST) acc += weight * __builtin_amdgcn_rcpf(1.f + ex);
+            else acc = (float)((double)acc + (double)weight / (1.0 + (double)ex));
+            light *= att;
+            if (light <= opt.stop_thresh) { stopped = true; alive = false; }
+        }
+    }
+    if ((a.x & kRecOverflow) == 0u) return;
+    float v;
+    if (c < K - 1) {
+        v = stopped ? acc * (float)(1.0 / (1.0 - (double)light)) : acc + light * opt.background_brightness;
+    } else {
+        v = 1.f - light;
+        aux[q].z = __float_as_uint(light);
     }
     out[q * K + c] = v;
 }
@@ -1323,11 +1390,15 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
 // of their own value (r02, tests/test_gpu_query_and_misc.py) -- opt-in.
 // COUNT (instrumentation, svoxt_set_bwd_counters): counters[0] += 64-byte atomic requests sent,
 // counters[1] += (tile, pass, feature row) groups; the work itself is unchanged.
-template <int FMT, int BD, bool EXACT, bool COUNT = false>
-__global__ void __launch_bounds__(512)
+// TERMS (EXACT only): sweep 1 hands (att, e_0, e_1, e_2) of every sample to sweep 2 through `terms`.
+// Two workgroups per CU (77 KB of LDS each) need at most 128 registers: said to the compiler,
+// because one branch too many costs exactly that (r02: 116 -> 130 registers, 0.38 -> 0.55 ms).
+template <int FMT, int BD, bool EXACT, bool COUNT = false, bool TERMS = false>
+__global__ void __launch_bounds__(512, 4)
 grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                   const uint2* __restrict__ rec, int S, const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
-                  float* __restrict__ grad, int gstride, unsigned long long* __restrict__ counters = nullptr) {
+                  float* __restrict__ grad, int gstride, unsigned long long* __restrict__ counters = nullptr,
+                  float4* __restrict__ terms = nullptr) {
     constexpr int C = 3, W = 8, NT = 64 * W, T = 1024, R = 1024, RPP = R / (64 * W);
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     constexpr int NB = (FMT == FMT_SH) ? BD : 0;
@@ -1401,18 +1472,25 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
                 const float att = pexpf<true>(-__uint_as_float(e.y) * row[K - 1] * r.delta_scale);
                 float total_color = 0.f;
-                if constexpr (FMT == FMT_SH) {
+                float ex[C];                                  // exp(-x_c): sigmoid_d(x) = 1.0 / (1.0 + double(exp(-x)))
 #pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        float tmp = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    float x;
+                    if constexpr (FMT == FMT_SH) {
+                        x = 0.f;
 #pragma unroll
-                        for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
-                        total_color += (float)sigmoid_d<true>(tmp) * g[c];
+                        for (int i = 0; i < BD; ++i) x += basis[i] * row[c * BD + i];
+                    } else {
+                        x = row[c];
                     }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < C; ++j) total_color += (float)sigmoid_d<true>(row[j]) * g[j];
+                    ex[c] = pexpf<true>(-x);
+                    total_color += (float)(1.0 / (1.0 + (double)ex[c])) * g[c];
                 }
+                // sweep 2 needs the same attenuation and the same three exponentials: 16 bytes per
+                // sample, the 64 rays of a list position side by side, instead of gathering the row
+                // and forming them again
+                if constexpr (TERMS)
+                    terms[((int64_t)blockIdx.x * S + k) * 64 + lane] = make_float4(att, ex[0], ex[1], ex[2]);
                 const int sl = ((rd & 1) * W + wave) * 64 + lane;
                 r_w[sl] = att; r_sg[sl] = total_color;
             }
@@ -1455,10 +1533,28 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             const int slot = (rd * W + wave) * 64 + lane;
             if (k < nrec) {
                 const uint2 e = rec_get(rec + rec_index((int64_t)blockIdx.x * 64 + lane, k, S));
-                float row[K];
-                load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
                 float att, tc, cf[C];
-                sample_terms<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, att, tc, cf);
+                if constexpr (EXACT && TERMS) {
+                    const float4 tv = terms[((int64_t)blockIdx.x * S + k) * 64 + lane];
+                    const float ex[C] = {tv.y, tv.z, tv.w};
+                    att = tv.x;
+                    tc = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {             // sample_terms from here on, operation for operation
+                        const double sd = 1.0 / (1.0 + (double)ex[c]);
+                        if constexpr (FMT == FMT_SH) {
+                            const float sig = (float)sd;
+                            cf[c] = (float)((double)sig * (1.0 - (double)sig));
+                        } else {
+                            cf[c] = (float)sd;
+                        }
+                        tc = (float)((double)tc + sd * (double)g[c]);
+                    }
+                } else {
+                    float row[K];
+                    load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
+                    sample_terms<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, att, tc, cf);
+                }
                 const int32_t idx = (int32_t)e.x;
                 uint32_t h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
                 while (true) {
@@ -2553,8 +2649,10 @@ bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float
                                          tr, rays, opt, rec, S, aux, out);                                    \
             else hipLaunchKernelGGL((shade_chan_kernel<KK, STOP, false>), dim3(nbc), dim3(256), 0, st,        \
                                     tr, rays, opt, rec, S, aux, out);                                         \
-            hipLaunchKernelGGL((render_fwd_kernel<FMT_RGBA, KK - 1, 0, N2, false, false, true>), dim3(nb),    \
-                               dim3(kBlock), 0, st, tr, rays, opt, out, (uint2*)nullptr, S, aux);             \
+            if (fast) hipLaunchKernelGGL((tail_chan_kernel<KK, N2, true>), dim3(nbc), dim3(256), 0, st,       \
+                                         tr, rays, opt, aux, out);                                            \
+            else hipLaunchKernelGGL((tail_chan_kernel<KK, N2, false>), dim3(nbc), dim3(256), 0, st,           \
+                                    tr, rays, opt, aux, out);                                                 \
             return true;                                                                                      \
         }
         switch (tr.K) {
@@ -2658,7 +2756,7 @@ bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
 // (K <= 32) on N = 2 trees
 bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
                        const float* grad_out, float* grad, int gstride, uint2* rec, int S, const uint4* aux,
-                       const float* fwd_out, float4* coef, bool xf, hipStream_t st) {
+                       const float* fwd_out, float4* coef, bool xf, hipStream_t st, float4* terms = nullptr) {
     if (C != 3) return false;
     const unsigned nb = nblocks(rays.Q);
     // a caller that hands over a coef buffer asks for the two-kernel form; without one (coef_bytes < 0)
@@ -2676,6 +2774,10 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
         if (fwd_out != nullptr && ctr == nullptr)                                                             \
             hipLaunchKernelGGL((grad_fused_kernel<F, BB, false>), dim3(nb), dim3(512), 0, st,                 \
                                tr, rays, opt, grad_out, rec, S, aux, fwd_out, grad, gstride);                 \
+        else if (ctr == nullptr && terms != nullptr)                                                          \
+            hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, true>), dim3(nb), dim3(512), 0, st,     \
+                               tr, rays, opt, grad_out, rec, S, aux, fwd_out, grad, gstride,                  \
+                               (unsigned long long*)nullptr, terms);                                          \
         else if (ctr == nullptr)                                                                              \
             hipLaunchKernelGGL((grad_fused_kernel<F, BB, true>), dim3(nb), dim3(512), 0, st,                  \
                                tr, rays, opt, grad_out, rec, S, aux, fwd_out, grad, gstride);                 \
@@ -2806,8 +2908,14 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
             const bool have_coef = lists->coef != nullptr &&
                                    lists->coef_bytes >= (int64_t)lists->max_samples * rays->Q * 16;
             if (n2 && tree->K <= 32 && (have_coef || lists->coef_bytes < 0))
+            {
+                // optional scratch of the exact one-kernel form: 16 bytes per list slot
+                const bool have_terms = lists->terms != nullptr && ((uintptr_t)lists->terms & 15u) == 0 &&
+                                        lists->terms_bytes >= rec_rays(rays->Q) * (int64_t)lists->max_samples * 16;
                 done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux,
-                                         fwd_out, have_coef ? reinterpret_cast<float4*>(lists->coef) : nullptr, false, st);
+                                         fwd_out, have_coef ? reinterpret_cast<float4*>(lists->coef) : nullptr, false, st,
+                                         have_terms ? reinterpret_cast<float4*>(lists->terms) : nullptr);
+            }
             if (!done) done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux, fwd_out, st)
                       : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux, fwd_out, st);
             if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no specialised kernel for this payload", fn);
