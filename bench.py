@@ -299,6 +299,10 @@ def main():
             "us_per_crossing_unloaded": US_PER_CROSSING_UNLOADED[chain],
             "floor_ms": round(touched["longest_ray_crossings"] * US_PER_CROSSING_UNLOADED[chain] * 1e-3, 4),
             "measured_ms": round(fwd_ms, 4)}}
+        if "shade_chan" in (route_fwd or ""):
+            limits["forward"]["note"] = ("two kernels: the march is bound by this chain; shade_chan_kernel by the vector ALUs "
+                                         "(one exponential and one double-precision divide per channel and sample) and, when the "
+                                         "feature table exceeds the 256 MiB Infinity Cache, by HBM (see roofline.traffic)")
         if atomic_requests:
             limits["backward"] = {
                 "bound": "rate at which the memory side takes 64-byte float-atomic requests (exp/atomic_bench.hip: 22 G/s)",
