@@ -186,6 +186,47 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
         t = t_start;
     }
     bool stopped = false;
+    // One composited sample (rt_kernel.cu:279-319); true: the ray ends here (early termination)
+    auto shade = [&](const float (&row)[K], int32_t idx, float delta_t, float t_cur, uint32_t slot) -> bool {
+        const float sigma = row[K - 1];
+        if (!(sigma > opt.sigma_thresh)) return false;
+        if constexpr (REC) {
+            if (nrec < S) {
+                rec_stage_put(rstage, (int)threadIdx.x, rec, tid, S, nrec, (uint32_t)idx, delta_t);
+                ++nrec;
+            } else if (!over) {
+                over = true;
+                t_resume = t_cur;
+            }
+        }
+        const float att = pexpf(-delta_t * r.delta_scale * sigma);
+        const float weight = light * (1.f - att);
+        if constexpr (FMT == FMT_SH) {
+            if constexpr (XF) rotated_sh_basis<BD>(tr, idx, vd, basis);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float tmp = 0.f;
+#pragma unroll
+                for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
+                acc[c] = (float)((double)acc[c] + (double)weight / (1.0 + (double)pexpf(-tmp)));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < C; ++j)
+                acc[j] = (float)((double)acc[j] + (double)weight / (1.0 + (double)pexpf(-row[j])));
+        }
+        light *= att;
+        if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + leaf_slot<N2>(tr, r, t_cur, slot), weight);
+        if constexpr (!REC) {
+            if (light <= opt.stop_thresh) return true;
+        }
+        return false;
+    };
+    // (Measured r02 and removed: a loop two crossings ahead -- crossing k+1 located and its row
+    // requested, the grid cell of crossing k+2 requested, THEN sample k shaded -- so that a
+    // wavefront alone on its SIMD, which is what the last 100 us of this kernel consist of, has
+    // loads in flight while it shades.  Bit-identical, 132 registers, 3 wavefronts per SIMD:
+    // 0.246 -> 0.314 ms.  What it gains in the tail it loses, and more, while the CUs are full.)
     // Software pipeline: where the ray goes next depends on the leaf geometry only,
     // not on the leaf's features, so the descent of step k+1 is issued right after
     // the row load of step k and the two latencies overlap (memory operations of a
@@ -203,41 +244,7 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
         t = march_advance(t, delta_t);
         have = t < r.tmax;
         if (have) march_step<N2>(tr, r, opt.step_size, t, s);           // next descent, in flight with the row
-        if (valid) {
-            const float sigma = row[K - 1];
-            if (sigma > opt.sigma_thresh) {
-                if constexpr (REC) {
-                    if (nrec < S) {
-                        rec_stage_put(rstage, (int)threadIdx.x, rec, tid, S, nrec, (uint32_t)idx, delta_t);
-                        ++nrec;
-                    } else if (!over) {
-                        over = true;
-                        t_resume = t_cur;
-                    }
-                }
-                const float att = pexpf(-delta_t * r.delta_scale * sigma);
-                const float weight = light * (1.f - att);
-                if constexpr (FMT == FMT_SH) {
-                    if constexpr (XF) rotated_sh_basis<BD>(tr, idx, vd, basis);
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        float tmp = 0.f;
-#pragma unroll
-                        for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
-                        acc[c] = (float)((double)acc[c] + (double)weight / (1.0 + (double)pexpf(-tmp)));
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < C; ++j)
-                        acc[j] = (float)((double)acc[j] + (double)weight / (1.0 + (double)pexpf(-row[j])));
-                }
-                light *= att;
-                if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + leaf_slot<N2>(tr, r, t_cur, slot), weight);
-                if constexpr (!REC) {
-                    if (light <= opt.stop_thresh) { stopped = true; break; }
-                }
-            }
-        }
+        if (valid && shade(row, idx, delta_t, t_cur, slot)) { stopped = true; break; }
     }
     if (stopped) {
         const float scale = (float)(1.0 / (1.0 - (double)light));
