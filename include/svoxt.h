@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 11
+#define SVOXT_ABI_VERSION 12
 
 enum {
     SVOXT_OK = 0,
@@ -157,6 +157,14 @@ int64_t svoxt_fwd_workspace_bytes(int64_t Q, int32_t max_samples);
 int svoxt_volume_render_fwd_ws(const svoxt_tree* tree, const svoxt_rays* rays,
                                const svoxt_options* opt, float* out,
                                void* workspace, int64_t workspace_bytes, int32_t flags, void* stream);
+/* The same with the scratch given as a svoxt_sample_lists (declared below; rec / aux, optionally
+ * pooled through blocktab): what svoxt_volume_render_fwd_ws does with a dense workspace, for callers
+ * that want the pool.  The lists come back in an unspecified state: they serve no backward (early
+ * termination applies while they are written). */
+struct svoxt_sample_lists;
+int svoxt_volume_render_fwd_scratch(const svoxt_tree* tree, const svoxt_rays* rays,
+                                    const svoxt_options* opt, float* out,
+                                    const struct svoxt_sample_lists* scratch, int32_t flags, void* stream);
 
 /* grad_out: device [Q, grad_cols] with grad_cols = C+1.
  * grad_features: device [M, grad_stride] floats of which columns 0..K-1 are the
@@ -211,11 +219,25 @@ typedef struct svoxt_sample_lists {
                               selects the two-kernel form); -1 with coef NULL: take the per-tile route if it
                               can run as ONE kernel (no view rotations, fwd_out given: list walk and merge
                               fused, nothing goes through coef), else the one-kernel backward */
-    void*   terms;         /* device, 16-byte aligned, terms_bytes >= max_samples * ceil(Q / 64) * 64 * 16, or NULL:
+    void*   terms;         /* device, 16-byte aligned, terms_bytes >= 2 * the bytes of rec (16 per record slot), or NULL:
                               scratch for that ONE kernel in its exact form (fwd_out NULL).  Its first sweep
                               over the lists then leaves each sample's attenuation and three exponentials for
                               the second, which no longer gathers the feature row again.  Same bits either way. */
     int64_t terms_bytes;
+    /* Pooled lists (optional, ABI v12).  blocktab NULL: dense -- rec holds max_samples slots for every
+     * ray, as described above.  blocktab given: device int32 [ceil(Q / 64) * max_samples / 8]; entry
+     * (tile, b) names the 4 KB block of `rec` that holds records 8b .. 8b+7 of the tile's 64 rays
+     * (-1: none).  The forward clears the table and hands blocks out of rec's pool_blocks blocks
+     * (a positive multiple of 32: the pool is cut into 32 parts, a tile draws from part tile % 32;
+     * pool_next: device int32 [32 * 16], one counter per part, 64 bytes apart, each = blocks handed out - 1;
+     * placed right behind blocktab, table and counters are cleared with one fill) the first time a ray
+     * of a tile starts block b; a ray that finds
+     * the pool used up stops recording there exactly as one that reaches max_samples does (it marches
+     * the rest).  rec then needs pool_blocks * 4096 bytes -- the samples that exist, not the cap times
+     * the rays -- and max_samples (<= 512) only caps a single ray. */
+    void*   blocktab;
+    int64_t pool_blocks;
+    void*   pool_next;
 } svoxt_sample_lists;
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt);

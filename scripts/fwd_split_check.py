@@ -71,14 +71,19 @@ def both(name, rs, opt, record):
             assert torch.equal(auxa[:, :3], auxb[:, :3]), "aux differs"
             n = (auxa[:, 0] & 0x7fffffff).long()
             S = la.S
-            # rec[tile][k / 8][lane][k % 8] by launch thread; compare the whole buffers where a record exists
-            Qp = la.rec.shape[0] // S
-            nt = torch.zeros(Qp, dtype=torch.long)
-            nt[thread_of_ray(rs, n.numel())] = n
-            k = torch.arange(S)
-            mask = (k.view(1, S // 8, 1, 8) < nt.view(Qp // 64, 1, 64, 1)).reshape(-1)
-            ra, rb = la.rec.cpu(), lb.rec.cpu()
+            # logical records [thread, k] through the block table (rec[block][lane][8]; dense: block = tile * S/8 + b)
+            def logical(l):
+                tiles, nb = l.tiles, l.S // 8
+                tab = l.blocktab.view(tiles, nb).long() if l.pooled else torch.arange(tiles * nb, device=dev).view(tiles, nb)
+                r = l.rec.view(-1, 64, 8, 2)[tab.clamp(min=0)]                 # [tiles, nb, 64, 8, 2]
+                return r.permute(0, 2, 1, 3, 4).reshape(tiles * 64, l.S, 2), (tab >= 0)
+            ra, oka = logical(la)
+            rb, okb = logical(lb)
+            nt = torch.zeros(la.tiles * 64, dtype=torch.long, device=dev)
+            nt[thread_of_ray(rs, n.numel()).to(dev)] = n.to(dev)
+            mask = torch.arange(S, device=dev)[None, :] < nt[:, None]
             assert torch.equal(ra[mask], rb[mask]), "recorded samples differ"
+            del ra, rb
             print(f"{'':28s} lists equal: {int(n.sum())} records, {int((auxa[:, 0] < 0).sum())} overflowed rays, max {int(n.max())}")
     else:
         oa, ob = a, b

@@ -43,7 +43,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -89,7 +89,8 @@ class _COptions(ctypes.Structure):       # struct svoxt_options
 class _CLists(ctypes.Structure):         # struct svoxt_sample_lists
     _fields_ = [("rec", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("max_samples", ctypes.c_int32),
                 ("coef", ctypes.c_void_p), ("coef_bytes", ctypes.c_int64),
-                ("terms", ctypes.c_void_p), ("terms_bytes", ctypes.c_int64)]
+                ("terms", ctypes.c_void_p), ("terms_bytes", ctypes.c_int64),
+                ("blocktab", ctypes.c_void_p), ("pool_blocks", ctypes.c_int64), ("pool_next", ctypes.c_void_p)]
 
 
 _P = ctypes.POINTER
@@ -103,6 +104,7 @@ EXPORTS = {
     "svoxt_volume_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
     "svoxt_fwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
     "svoxt_volume_render_fwd_ws": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _i64, _i32, _vp]),
+    "svoxt_volume_render_fwd_scratch": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _P(_CLists), _i32, _vp]),
     "svoxt_volume_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _vp, _i64, _vp]),
     "svoxt_bwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
     "svoxt_can_record": (ctypes.c_int, [_P(_CTree), _P(_COptions)]),
@@ -435,27 +437,102 @@ FWD_LIST_SAMPLES = int(os.environ.get("SVOXT_FWD_LIST", "96"))
 FAST_SIGMOID = os.environ.get("SVOXT_FAST_SIGMOID", "0") not in ("", "0")
 
 
+# Pooled lists (include/svoxt.h, svoxt_sample_lists.blocktab): the records live in 4 KB blocks handed
+# out per (tile, 8 list positions) from a pool, so memory follows the samples that exist instead of
+# cap x rays (800x800, depth-8 SH9: 47 MB of records in a 491 MB dense buffer).  How large a pool a
+# batch needs is learned from the forward before it: its block counter is copied to pinned host
+# memory without waiting, and the next lists of the same shape are sized 1.25x what was used (twice
+# the pool if it ran dry -- a ray that finds no block stops recording and marches the rest, so a pool
+# that is too small costs time, never correctness).  SVOXT_LIST_POOL=0: dense lists.
+LIST_POOL = os.environ.get("SVOXT_LIST_POOL", "1") not in ("", "0")
+_POOL_HINT: dict = {}       # (tiles, S) -> [blocks to allocate, pending (event, pinned counter, capacity) or None, forwards seen]
+
+
+def _pool_blocks_for(tiles: int, S: int) -> int:
+    full = tiles * (S // 8)
+    ent = _POOL_HINT.setdefault((tiles, S), [min(full, tiles * 12), None, 0])
+    if ent[1] is not None and ent[1][0].query():
+        used, cap = int(ent[1][1].item()), ent[1][2]
+        ent[1] = None
+        want = min(full, cap * 2) if used >= cap else min(full, max(tiles, int(used * 1.25) + 64))
+        ent[0] = want
+    return max(1, ent[0])
+
+
+_PINNED: list = []
+
+
+def _pinned_counter():
+    """A pinned int32[1] (a small ring: pinned allocations are slow to make)."""
+    if len(_PINNED) < 8:
+        _PINNED.append(torch.empty((1,), dtype=torch.int32, pin_memory=True))
+        return _PINNED[-1]
+    _PINNED.append(_PINNED.pop(0))
+    return _PINNED[-1]
+
+
 class SampleLists:
     """Per-ray lists of composited samples recorded by a forward (see
     include/svoxt.h, svoxt_sample_lists).  Opaque to callers: pass it back to
     volume_render_backward."""
 
-    def __init__(self, Q, S, device):
+    def __init__(self, Q, S, device, pooled=None):
         S = (S + 7) // 8 * 8                                 # whole 64-byte lines of 8 records per lane
-        # rec[tile][block][lane][8] (include/svoxt.h): rays padded to whole 64-ray tiles
-        self.rec = torch.empty(((Q + 63) // 64 * S * 64, 2), dtype=torch.int32, device=device)
+        tiles = (Q + 63) // 64
+        self.pooled = (LIST_POOL if pooled is None else bool(pooled)) and S <= 512
+        self.tiles = tiles
+        if self.pooled:
+            self.pool_blocks = (_pool_blocks_for(tiles, S) + 31) // 32 * 32      # 32 equal parts, a counter each
+            nt = tiles * (S // 8)
+            both = torch.empty((nt + 32 * 16,), dtype=torch.int32, device=device)     # table, then the 32 counters
+            self.blocktab, self.pool_next = both[:nt], both[nt:]
+        else:
+            # rec[tile][block][lane][8]: every ray owns S slots
+            self.pool_blocks = tiles * (S // 8)
+            self.blocktab = self.pool_next = None
+        self.rec = torch.empty((self.pool_blocks * 512, 2), dtype=torch.int32, device=device)
         self.aux = torch.empty((Q, 4), dtype=torch.int32, device=device)
         self.S = S
         self.coef = None        # allocated by the backward when it takes the two-kernel route,
         self.consumed = False   # which rewrites `rec`: the lists then serve no second backward
         self.terms = None       # scratch of the exact one-kernel backward (allocated there)
 
+    def note_usage(self):
+        """After the forward that filled the lists was enqueued: remember how much of the pool it took
+        (read later, without waiting)."""
+        if not self.pooled:
+            return
+        ent = _POOL_HINT.get((self.tiles, self.S))
+        if ent is None or ent[1] is not None:
+            return
+        ent[2] += 1
+        if ent[2] > 2 and ent[2] % 16:          # the first forwards of a shape, then every 16th: three tiny launches each
+            return
+        host = _pinned_counter()
+        host.copy_((self.pool_next.view(32, 16)[:, 0].max().view(1) + 1) * 32, non_blocking=True)   # the fullest part sets the need
+        ev = torch.cuda.Event()
+        ev.record()
+        ent[1] = (ev, host, self.pool_blocks)
+
     def c_struct(self):
         return _CLists(self.rec.data_ptr(), self.aux.data_ptr(), self.S,
                        None if self.coef is None else self.coef.data_ptr(),
                        0 if self.coef is None else self.coef.numel() * 4,
                        None if self.terms is None else self.terms.data_ptr(),
-                       0 if self.terms is None else self.terms.numel() * 4)
+                       0 if self.terms is None else self.terms.numel() * 4,
+                       None if self.blocktab is None else self.blocktab.data_ptr(),
+                       self.pool_blocks if self.pooled else 0,
+                       None if self.pool_next is None else self.pool_next.data_ptr())
+
+
+def _list_cap(ct: "_CTree", base: int) -> int:
+    """Records a single ray may list.  Pooled lists make a high cap free (memory follows the samples
+    that exist): 192 instead of 96, so that the rays of a depth-9 tree that composite up to ~190
+    samples need no tail launch -- except with view rotations, whose two-kernel backward sizes a
+    second buffer by the cap."""
+    if LIST_POOL and base == 96 and ct.xform is None:
+        return 192
+    return base
 
 
 def can_record(tree: TreeSpec, opt: RenderOptions) -> bool:
@@ -616,17 +693,25 @@ def _volume_render(tree, rays, opt, record):
         out = torch.empty((cr.Q, get_out_data_dim(opt, ct.K)), dtype=torch.float32, device=dev)
         if record and BWD_LIST_SAMPLES > 0 and cr.Q > 0 and \
                 _lib.svoxt_can_record(ctypes.byref(ct), ctypes.byref(co)):
-            lists = SampleLists(cr.Q, BWD_LIST_SAMPLES, dev)
+            lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
             cl = lists.c_struct()
             _call("svoxt_volume_render_fwd_record", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(out), ctypes.byref(cl), _stream(dev))
+            lists.note_usage()
         elif FWD_LIST_SAMPLES > 0 and cr.Q > 0:
             # scratch for the two-kernel forward (march, then shade per tile; the library falls
             # back to the one-kernel forward for payloads it does not cover)
-            nbytes = _lib.svoxt_fwd_workspace_bytes(cr.Q, FWD_LIST_SAMPLES)
-            ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-            _call("svoxt_volume_render_fwd_ws", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
-                  _ptr(out), _ptr(ws), nbytes, 1 if FAST_SIGMOID else 0, _stream(dev))
+            if LIST_POOL:
+                scratch = SampleLists(cr.Q, _list_cap(ct, FWD_LIST_SAMPLES), dev)
+                cl = scratch.c_struct()
+                _call("svoxt_volume_render_fwd_scratch", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+                      _ptr(out), ctypes.byref(cl), 1 if FAST_SIGMOID else 0, _stream(dev))
+                scratch.note_usage()
+            else:
+                nbytes = _lib.svoxt_fwd_workspace_bytes(cr.Q, FWD_LIST_SAMPLES)
+                ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+                _call("svoxt_volume_render_fwd_ws", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
+                      _ptr(out), _ptr(ws), nbytes, 1 if FAST_SIGMOID else 0, _stream(dev))
         else:
             _call("svoxt_volume_render_fwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(out), _stream(dev))
@@ -707,7 +792,7 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
             if fused and fo is None and BWD_TERMS:
                 # sweep 1 -> sweep 2 hand-over: 16 bytes per list slot (as large again as rec twice over;
                 # the caching allocator keeps it between steps)
-                lists.terms = torch.empty((lists.rec.shape[0] * 4,), dtype=torch.float32, device=dev)
+                lists.terms = torch.empty((lists.pool_blocks * 512 * 4,), dtype=torch.float32, device=dev)
             if gather and not fused:
                 # with view rotations a second plane holds each sample's rotated direction
                 planes = 2 if ct.xform is not None else 1
@@ -787,7 +872,7 @@ def _opacity_render(tree, rays, opt, record):
     with torch.cuda.device(dev):
         out = torch.empty((cr.Q, 1), dtype=torch.float32, device=dev)
         if record and BWD_LIST_SAMPLES > 0 and cr.Q > 0 and co.sigma_thresh == 0.0 and co.stop_thresh == 0.0:
-            lists = SampleLists(cr.Q, BWD_LIST_SAMPLES, dev)
+            lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
             cl = lists.c_struct()
             _call("svoxt_opacity_render_fwd_record", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(out), ctypes.byref(cl), _stream(dev))

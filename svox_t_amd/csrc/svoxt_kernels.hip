@@ -87,30 +87,105 @@ __device__ __forceinline__ uint2 rec_get(const uint2* p) {
 // partial lines, 2.5x write amplification.  Now a lane stages 8 records in LDS and writes one
 // whole line per 8 records.)
 constexpr int kRecBlock = 8;
-__device__ __forceinline__ int64_t rec_index(int64_t tid, int k, int S) {
-    return ((((tid >> 6) * (int64_t)(S >> 3) + (k >> 3)) << 6) + (tid & 63)) * kRecBlock + (k & 7);
+constexpr int kMaxRecBlocks = 64;        // blocks per ray at most: max_samples <= 512 with a block table
+
+// The lists as the kernels see them.  A BLOCK is the 8 consecutive records of the 64 rays of a tile
+// (4 KB: 64 lines of 64 bytes).  Dense (tab == NULL): block b of tile T is block T * (S / 8) + b of
+// `rec` -- every ray owns S slots.  Pooled (r02; tab != NULL): tab[T * (S / 8) + b] names the
+// block, handed out from `rec`'s pool_blocks blocks by a counter the first time a ray of the tile
+// starts it (-1: never): memory follows the samples that exist (mean 9 per ray on the headline
+// workload against a cap of 96), S only caps a ray.
+struct RecLists {
+    uint2* __restrict__ rec;
+    int32_t* __restrict__ tab;
+    int32_t* __restrict__ pool_next;
+    int64_t pool_blocks;
+    int S;
+};
+
+__device__ __forceinline__ int64_t rec_block(const RecLists& L, int64_t tile, int b) {
+    const int64_t e = tile * (int64_t)(L.S >> 3) + b;
+    return L.tab != nullptr ? (int64_t)L.tab[e] : e;
 }
+// Kernels whose wavefronts each work on ONE tile and one block at a time keep the tile's table in a
+// register -- lane b holds block b -- and read it with readlane: no table load in front of every
+// record load (r02: the per-tile backward lost 0.02 ms to exactly that).
+__device__ __forceinline__ int32_t rec_tab_reg(const RecLists& L, int64_t tile, int lane) {
+    const int nb = L.S >> 3;
+    return (L.tab != nullptr && lane < nb) ? L.tab[tile * (int64_t)nb + lane] : -1;
+}
+__device__ __forceinline__ int64_t rec_block_u(const RecLists& L, int32_t tabreg, int64_t tile, int b /* wavefront-uniform */) {
+    if (L.tab == nullptr) return tile * (int64_t)(L.S >> 3) + b;
+    return (int64_t)__builtin_amdgcn_readlane(tabreg, __builtin_amdgcn_readfirstlane(b));
+}
+// The pool is cut into kSubPools equal parts with a counter each (64 bytes apart), chosen by the tile:
+// one counter for every hand-out was a single hot address -- 40 000 returning atomics per forward
+// of the headline workload, 0.25 -> 0.31 ms (r02).
+constexpr int kSubPools = 32;
+constexpr int kSubPoolStride = 16;       // int32 between two counters
+// where record k of the ray handled by launch thread `tid` (tile tid >> 6, lane tid & 63) lives
+__device__ __forceinline__ int64_t rec_index(const RecLists& L, int64_t tid, int k) {
+    return (((rec_block(L, tid >> 6, k >> 3) << 6) + (tid & 63)) << 3) + (k & 7);
+}
+__device__ __forceinline__ int64_t rec_index_in(int64_t block, int64_t tid, int k) {
+    return (((block << 6) + (tid & 63)) << 3) + (k & 7);
+}
+
+// Writers (one wavefront per workgroup = one tile).  ltab: the tile's block table in LDS
+// ([kMaxRecBlocks], -1 = not handed out yet; rec_tab_init).  rec_block_begin is called by the lanes
+// that are about to write the FIRST record of block b (a divergent subset of the wavefront, possibly
+// with different b): the block is taken from the table, or a leader among them takes one from the
+// pool for all.  Returns -2 when the pool is used up (the ray's list then counts as full).
+__device__ __forceinline__ void rec_tab_init(int32_t* ltab) {
+    if (threadIdx.x < kMaxRecBlocks) ltab[threadIdx.x] = -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ int64_t rec_block_begin(const RecLists& L, int32_t* ltab, int64_t tile, int b) {
+    if (L.tab == nullptr) return tile * (int64_t)(L.S >> 3) + b;
+    int id = ltab[b];
+    while (true) {
+        const unsigned long long m = __ballot(id == -1);          // lanes here whose block is not handed out yet
+        if (m == 0ull) break;
+        const int leader = __ffsll((long long)m) - 1;
+        const int bl = __shfl(b, leader, 64);
+        int nid = 0;
+        if ((int)(threadIdx.x & 63) == leader) {
+            const int sp = (int)(tile & (kSubPools - 1));
+            const int64_t per = L.pool_blocks / kSubPools;          // blocks of one part
+            nid = atomicAdd(L.pool_next + sp * kSubPoolStride, 1) + 1;     // the counters start at -1, like the table
+            nid = (int64_t)nid < per ? (int)(sp * per + nid) : -2;
+            ltab[bl] = nid;
+            if (nid >= 0) L.tab[tile * (int64_t)(L.S >> 3) + bl] = nid;
+        }
+        nid = __shfl(nid, leader, 64);
+        if (b == bl) id = nid;
+    }
+    return (int64_t)id;
+}
+
 // the staging buffer of one wavefront: [8][64] records, lane-contiguous (conflict-free ds_write_b64)
 __device__ __forceinline__ void rec_stage_flush(const uint2* __restrict__ lds, int lane, uint2* __restrict__ rec,
-                                                int64_t tid, int S, int k0) {
+                                                int64_t block) {
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-    v4u* dst = reinterpret_cast<v4u*>(rec + rec_index(tid, k0, S));      // 64-byte aligned
+    v4u* dst = reinterpret_cast<v4u*>(rec + (((block << 6) + lane) << 3));      // the lane's 64-byte line of the block
 #pragma unroll
     for (int j = 0; j < kRecBlock / 2; ++j) {
         const uint2 a = lds[(2 * j) * 64 + lane], b = lds[(2 * j + 1) * 64 + lane];
         __builtin_nontemporal_store(v4u{a.x, a.y, b.x, b.y}, dst + j);
     }
 }
-// record number k (the k-th of this ray) <- (feature row, delta_t); a full block goes out as one line
-__device__ __forceinline__ void rec_stage_put(uint2* __restrict__ lds, int lane, uint2* __restrict__ rec, int64_t tid,
-                                              int S, int k, uint32_t idx, float delta_t) {
+// record number k (the k-th of this ray) <- (feature row, delta_t), into the block rec_block_begin
+// gave for k's block; a full block goes out as one line
+__device__ __forceinline__ void rec_stage_put(uint2* __restrict__ lds, int lane, uint2* __restrict__ rec, int64_t block,
+                                              int k, uint32_t idx, float delta_t) {
     lds[(k & 7) * 64 + lane] = make_uint2(idx, __float_as_uint(delta_t));
-    if ((k & 7) == 7) rec_stage_flush(lds, lane, rec, tid, S, k & ~7);
+    if ((k & 7) == 7) rec_stage_flush(lds, lane, rec, block);
 }
 // at the end of a ray with nrec records: the partly filled last block (its unused slots carry stale values)
 __device__ __forceinline__ void rec_stage_finish(const uint2* __restrict__ lds, int lane, uint2* __restrict__ rec,
-                                                 int64_t tid, int S, int nrec) {
-    if (nrec & 7) rec_stage_flush(lds, lane, rec, tid, S, nrec & ~7);
+                                                 int64_t block, int nrec) {
+    if (nrec & 7) rec_stage_flush(lds, lane, rec, block);
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -140,11 +215,15 @@ __device__ __forceinline__ uint32_t leaf_slot(const TreeDev& tr, const Ray& r, f
 template <int FMT, int C, int BD, bool N2, bool REC, bool XF = false, bool RESUME = false>
 __global__ void __launch_bounds__(kBlock)
 render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
-                  uint2* __restrict__ rec, int S, uint4* __restrict__ aux) {
+                  RecLists L, uint4* __restrict__ aux) {
     static_assert(!XF || FMT == FMT_SH, "view rotations only matter for view-dependent formats");
     static_assert(!(RESUME && REC), "the tail launch does not record");
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     __shared__ uint2 rstage[REC ? kRecBlock * kBlock : 1];
+    __shared__ int32_t ltab[REC ? kMaxRecBlocks : 1];
+    if constexpr (REC) rec_tab_init(ltab);
+    const int S = L.S;
+    int64_t cur_block = 0;
     const int64_t tid = ((int64_t)blockIdx.x + rays.tile0) * kBlock + threadIdx.x;
     const int64_t q = ray_of_thread(rays, tid);
     if (q >= rays.Q) return;
@@ -191,8 +270,13 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
         const float sigma = row[K - 1];
         if (!(sigma > opt.sigma_thresh)) return false;
         if constexpr (REC) {
-            if (nrec < S) {
-                rec_stage_put(rstage, (int)threadIdx.x, rec, tid, S, nrec, (uint32_t)idx, delta_t);
+            bool room = nrec < S;
+            if (room && (nrec & 7) == 0) {
+                cur_block = rec_block_begin(L, ltab, tid >> 6, nrec >> 3);
+                room = cur_block >= 0;
+            }
+            if (room) {
+                rec_stage_put(rstage, (int)threadIdx.x, L.rec, cur_block, nrec, (uint32_t)idx, delta_t);
                 ++nrec;
             } else if (!over) {
                 over = true;
@@ -257,7 +341,7 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
     }
     o[C] = 1.f - light;
     if constexpr (REC) {  // + the final transmittance, for the single-march backward
-        rec_stage_finish(rstage, (int)threadIdx.x, rec, tid, S, nrec);
+        rec_stage_finish(rstage, (int)threadIdx.x, L.rec, cur_block, nrec);
         aux[q] = make_uint4((uint32_t)nrec | (over ? kRecOverflow : 0u), __float_as_uint(t_resume),
                             __float_as_uint(light), 0u);
     }
@@ -358,8 +442,12 @@ render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __re
 // the lists are for a backward, which wants every sample with sigma > 0 (:382,456).
 template <bool N2, bool STOP, int ACC>
 __global__ void __launch_bounds__(kBlock)
-march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, uint2* __restrict__ rec, int S, uint4* __restrict__ aux) {
+march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux) {
     __shared__ uint2 rstage[kRecBlock * kBlock];
+    __shared__ int32_t ltab[kMaxRecBlocks];
+    rec_tab_init(ltab);
+    const int S = L.S;
+    int64_t cur_block = 0;
     const int64_t tid = ((int64_t)blockIdx.x + rays.tile0) * kBlock + threadIdx.x;
     const int64_t q = ray_of_thread(rays, tid);
     if (q >= rays.Q) return;
@@ -389,8 +477,13 @@ march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, uint2* __restrict__ rec, in
         t = march_advance(t, s.delta_t);
         bool keep = true;
         if (p_sigma > opt.sigma_thresh) {
-            if (nrec < S) {
-                rec_stage_put(rstage, (int)threadIdx.x, rec, tid, S, nrec, (uint32_t)p_idx, p_dt);
+            bool room = nrec < S;
+            if (room && (nrec & 7) == 0) {
+                cur_block = rec_block_begin(L, ltab, tid >> 6, nrec >> 3);
+                room = cur_block >= 0;
+            }
+            if (room) {
+                rec_stage_put(rstage, (int)threadIdx.x, L.rec, cur_block, nrec, (uint32_t)p_idx, p_dt);
                 ++nrec;
                 if constexpr (STOP) {
                     light *= pexpf(-p_dt * r.delta_scale * p_sigma);
@@ -412,21 +505,26 @@ march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, uint2* __restrict__ rec, in
         }
     }
     if (p_sigma > opt.sigma_thresh) {    // the last crossing's sample
-        if (nrec < S) {
-            rec_stage_put(rstage, (int)threadIdx.x, rec, tid, S, nrec, (uint32_t)p_idx, p_dt);
+        bool room = nrec < S;
+        if (room && (nrec & 7) == 0) {
+            cur_block = rec_block_begin(L, ltab, tid >> 6, nrec >> 3);
+            room = cur_block >= 0;
+        }
+        if (room) {
+            rec_stage_put(rstage, (int)threadIdx.x, L.rec, cur_block, nrec, (uint32_t)p_idx, p_dt);
             ++nrec;
         } else {
             over = kRecOverflow;
             t_resume = p_t;
         }
     }
-    rec_stage_finish(rstage, (int)threadIdx.x, rec, tid, S, nrec);
+    rec_stage_finish(rstage, (int)threadIdx.x, L.rec, cur_block, nrec);
     aux[q] = make_uint4((uint32_t)nrec | over, __float_as_uint(t_resume), __float_as_uint(1.f), 0u);
 }
 
 template <int FMT, int BD, bool XF, bool STOP>
 __global__ void __launch_bounds__(512)
-shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, const uint2* __restrict__ rec, int S,
+shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
                   uint4* __restrict__ aux, float* __restrict__ out) {
     constexpr int C = 3, W = 8, P = W - 1;
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
@@ -444,6 +542,7 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, const uint2* __restrict__ 
     for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
     maxn = __builtin_amdgcn_readfirstlane(maxn);     // what decides the barrier count is scalar
     const int nround = (maxn + P - 1) / P;           // the same in every wavefront of the workgroup
+    const int32_t tabreg = rec_tab_reg(L, tile, lane);
 
     float delta_scale = 0.f;
     float basis[NB];
@@ -464,7 +563,7 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, const uint2* __restrict__ 
         if (wave > 0) {
             const int k = rd * P + (wave - 1);
             if (rd < nround && k < nrec) {
-                const uint2 e = rec_get(rec + rec_index(tile * 64 + lane, k, S));
+                const uint2 e = rec_get(L.rec + rec_index_in(rec_block_u(L, tabreg, tile, k >> 3), lane, k));
                 const int32_t idx = (int32_t)e.x;
                 float row[K];
                 load_row<K>(tr.features + (int64_t)idx * K, row);
@@ -543,7 +642,7 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, const uint2* __restrict__ 
 // acc += w * rcp(1 + e): each term within 2e-7 of the reference's double-precision quotient.
 template <int K, bool STOP, bool FAST>
 __global__ void __launch_bounds__(256)
-shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, const uint2* __restrict__ rec, int S,
+shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
                   uint4* __restrict__ aux, float* __restrict__ out) {
     static_assert(K == 8 || K == 16 || K == 32, "row widths with a channel-lane instance");
     constexpr int RPW = 64 / K;                                  // rays per wavefront
@@ -566,8 +665,7 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, const uint2* __restrict__ 
         setup_ray(tr, rays, opt, q, r);                          // a ray with samples hits the cube
         ds = r.delta_scale;
     }
-    const uint2* __restrict__ my = rec + rec_index(t, 0, S);     // this ray's block 0, slot 0
-    const int64_t blk = (int64_t)64 * kRecBlock;                 // records from block b to block b + 1
+    const int32_t tabreg = rec_tab_reg(L, t >> 6, lane);
     float light = 1.f, acc = 0.f;
     bool stopped = false;
     // A block of 8 records is the ray's own 64-byte line: fetch it whole, request the 8 rows it
@@ -580,8 +678,9 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, const uint2* __restrict__ 
         uint32_t idx[kRecBlock];
         float dt[kRecBlock], ex[kRecBlock];
         const int n_here = min(nrec - kb, kRecBlock);            // records of this ray in the block (<= 0: none)
+        const int64_t blk = rec_block_u(L, tabreg, t >> 6, kb >> 3);
         if (n_here > 0) {
-            const v4u* line = reinterpret_cast<const v4u*>(my + (kb >> 3) * blk);
+            const v4u* line = reinterpret_cast<const v4u*>(L.rec + rec_index_in(blk, t, kb));   // the ray's line of this block
 #pragma unroll
             for (int j = 0; j < kRecBlock / 2; ++j) {
                 const v4u w = __builtin_nontemporal_load(line + j);
@@ -899,7 +998,7 @@ __device__ __forceinline__ void sample_advance(float att, float total_color, flo
 template <int FMT, int C, int BD, bool N2, bool REPLAY, bool XF = false, bool GATHER = false>
 __global__ void __launch_bounds__(kBlock, (GATHER && !XF) ? 4 : 1)
 render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
-                  float* __restrict__ grad, int gstride, uint2* __restrict__ rec, int S,
+                  float* __restrict__ grad, int gstride, RecLists L,
                   const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
                   float4* __restrict__ coef_out = nullptr) {
     static_assert(!GATHER || (REPLAY && C == 3), "two-kernel backward: lists, 3 channels");
@@ -908,6 +1007,11 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     __shared__ float stage_all[(kBlock / 64) * 64 * KS];
     __shared__ int32_t sidx_all[kBlock];
     __shared__ uint2 rstage[REPLAY ? 1 : kRecBlock * kBlock];     // pass 1 records into the workspace lists
+    __shared__ int32_t ltab[REPLAY ? 1 : kMaxRecBlocks];
+    if constexpr (!REPLAY) rec_tab_init(ltab);
+    uint2* __restrict__ rec = L.rec;
+    const int S = L.S;
+    int64_t cur_block = 0;
 
     const int lane = threadIdx.x & 63;
     float* stage = stage_all + (threadIdx.x >> 6) * (64 * KS);
@@ -975,11 +1079,11 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 light_ray = __uint_as_float(a.z);
                 skip_pass1 = true;
                 if constexpr (XF) {
-                    if (nrec > 0) last_idx = (int32_t)rec_get(rec + rec_index(tid, nrec - 1, S)).x;
+                    if (nrec > 0) last_idx = (int32_t)rec_get(rec + rec_index(L, tid, nrec - 1)).x;
                 }
             } else {
                 for (int k = 0; k < nrec; ++k) {
-                    const uint2 e = rec_get(rec + rec_index(tid, k, S));
+                    const uint2 e = rec_get(rec + rec_index(L, tid, k));
                     float row[K];
                     load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
                     if constexpr (XF) { rotated_sh_basis<BD>(tr, (int32_t)e.x, vd, basis); last_idx = (int32_t)e.x; }
@@ -1000,8 +1104,13 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 if (row[K - 1] > 0.f) {
                     if constexpr (!REPLAY) {
                         if (S > 0) {
-                            if (nrec < S) {
-                                rec_stage_put(rstage, (int)threadIdx.x, rec, tid, S, nrec, (uint32_t)s.idx, s.delta_t);
+                            bool room = nrec < S;
+                            if (room && (nrec & 7) == 0) {
+                                cur_block = rec_block_begin(L, ltab, tid >> 6, nrec >> 3);
+                                room = cur_block >= 0;
+                            }
+                            if (room) {
+                                rec_stage_put(rstage, (int)threadIdx.x, rec, cur_block, nrec, (uint32_t)s.idx, s.delta_t);
                                 ++nrec;
                             } else if (tmax2 < 0.f) {   // list full: pass 2 marches from this step on
                                 t_resume = t;
@@ -1029,7 +1138,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             if (last_idx >= 0) rotated_sh_basis<BD>(tr, last_idx, vd, basis_last);
         }
         if constexpr (!REPLAY) {
-            if (S > 0) rec_stage_finish(rstage, (int)threadIdx.x, rec, tid, S, nrec);
+            if (S > 0) rec_stage_finish(rstage, (int)threadIdx.x, rec, cur_block, nrec);
         }
     }
 
@@ -1052,7 +1161,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         // lane-independent: no wavefront-wide synchronisation while walking the list
         if (alive) {
             for (; k < nrec; ++k) {
-                uint2* slot = rec + rec_index(tid, k, S);
+                uint2* slot = rec + rec_index(L, tid, k);
                 const uint2 e = rec_get(slot);
                 float row[K];
                 load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
@@ -1088,7 +1197,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         float delta_t = 0.f;
         float row[K];
         if (k < nrec) {
-            const uint2 e = rec_get(rec + rec_index(tid, k, S));
+            const uint2 e = rec_get(rec + rec_index(L, tid, k));
             ++k;
             idx = (int32_t)e.x;
             delta_t = __uint_as_float(e.y);
@@ -1144,9 +1253,11 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 // rotated direction the list walk stored in coef[S + k][q].
 template <int FMT, int BD, int T, int R, int W, bool XF = false>
 __global__ void __launch_bounds__(64 * W)
-grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, const uint2* __restrict__ rec,
+grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, RecLists L,
                   const float4* __restrict__ coef, const uint4* __restrict__ aux,
-                  float* __restrict__ grad, int gstride, int S = 0) {
+                  float* __restrict__ grad, int gstride) {
+    const int S = L.S;
+    const int32_t tabreg = rec_tab_reg(L, blockIdx.x, threadIdx.x & 63);
     // W wavefronts share one tile (64 rays) and its LDS: the phases below are latency
     // chains of LDS operations, and LDS -- not registers -- limits how many tiles a CU
     // holds, so the way to more wavefronts per CU is more wavefronts per tile.  Lane l of
@@ -1219,7 +1330,7 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
             c_n[u] = v4f{0.f, 0.f, 0.f, 0.f};
             d_n[u] = v4f{0.f, 0.f, 0.f, 0.f};
             if (kb + u < nrec) {
-                e_n[u] = rec_get(rec + rec_index((int64_t)blockIdx.x * 64 + lane, kb + u, S));
+                e_n[u] = rec_get(L.rec + rec_index_in(rec_block_u(L, tabreg, blockIdx.x, (kb + u) >> 3), lane, kb + u));
                 c_n[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(kb + u) * rays.Q + q)));
                 if constexpr (XF)
                     d_n[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(coef + ((int64_t)(S + kb + u) * rays.Q + q)));
@@ -1403,7 +1514,7 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
 template <int FMT, int BD, bool EXACT, bool COUNT = false, bool TERMS = false>
 __global__ void __launch_bounds__(512, 4)
 grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
-                  const uint2* __restrict__ rec, int S, const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
+                  RecLists L, const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
                   float* __restrict__ grad, int gstride, unsigned long long* __restrict__ counters = nullptr,
                   float4* __restrict__ terms = nullptr) {
     constexpr int C = 3, W = 8, NT = 64 * W, T = 1024, R = 1024, RPP = R / (64 * W);
@@ -1426,6 +1537,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* stage = stage_all + wave * 64 * KS;
     int32_t* seg = seg_all + wave * 64;
+    const int32_t tabreg = rec_tab_reg(L, blockIdx.x, lane);
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * 64 + lane);
     uint4 a = make_uint4(0u, 0u, 0u, 0u);
     if (q < rays.Q) a = aux[q];
@@ -1474,7 +1586,8 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         for (int rd = 0; rd <= nr1; ++rd) {
             const int k = rd * W + wave;
             if (rd < nr1 && k < nrec) {
-                const uint2 e = rec_get(rec + rec_index((int64_t)blockIdx.x * 64 + lane, k, S));
+                const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
+                const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
                 float row[K];
                 load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
                 const float att = pexpf<true>(-__uint_as_float(e.y) * row[K - 1] * r.delta_scale);
@@ -1497,7 +1610,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 // sample, the 64 rays of a list position side by side, instead of gathering the row
                 // and forming them again
                 if constexpr (TERMS)
-                    terms[((int64_t)blockIdx.x * S + k) * 64 + lane] = make_float4(att, ex[0], ex[1], ex[2]);
+                    terms[((blk << 3) + (k & 7)) * 64 + lane] = make_float4(att, ex[0], ex[1], ex[2]);
                 const int sl = ((rd & 1) * W + wave) * 64 + lane;
                 r_w[sl] = att; r_sg[sl] = total_color;
             }
@@ -1539,10 +1652,11 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             const int k = kb + wave;
             const int slot = (rd * W + wave) * 64 + lane;
             if (k < nrec) {
-                const uint2 e = rec_get(rec + rec_index((int64_t)blockIdx.x * 64 + lane, k, S));
+                const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
+                const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
                 float att, tc, cf[C];
                 if constexpr (EXACT && TERMS) {
-                    const float4 tv = terms[((int64_t)blockIdx.x * S + k) * 64 + lane];
+                    const float4 tv = terms[((blk << 3) + (k & 7)) * 64 + lane];
                     const float ex[C] = {tv.y, tv.z, tv.w};
                     att = tv.x;
                     tc = 0.f;
@@ -1954,8 +2068,12 @@ render_bwd_generic_staged_kernel(TreeDev tr, RaysDev rays, Opts opt, int C,
 template <bool N2, bool REC = false>
 __global__ void __launch_bounds__(kBlock)
 opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
-                   uint2* __restrict__ rec = nullptr, int S = 0, uint4* __restrict__ aux = nullptr) {
+                   RecLists L = RecLists{}, uint4* __restrict__ aux = nullptr) {
     __shared__ uint2 rstage[REC ? kRecBlock * kBlock : 1];
+    __shared__ int32_t ltab[REC ? kMaxRecBlocks : 1];
+    if constexpr (REC) rec_tab_init(ltab);
+    const int S = L.S;
+    int64_t cur_block = 0;
     const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t q = ray_of_thread(rays, tid);
     if (q >= rays.Q) return;
@@ -1977,8 +2095,13 @@ opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
             const float sigma = tr.features[(int64_t)s.idx * K + (K - 1)];
             if (sigma > opt.sigma_thresh) {
                 if constexpr (REC) {
-                    if (nrec < S) {
-                        rec_stage_put(rstage, (int)threadIdx.x, rec, tid, S, nrec, (uint32_t)s.idx, s.delta_t);
+                    bool room = nrec < S;
+                    if (room && (nrec & 7) == 0) {
+                        cur_block = rec_block_begin(L, ltab, tid >> 6, nrec >> 3);
+                        room = cur_block >= 0;
+                    }
+                    if (room) {
+                        rec_stage_put(rstage, (int)threadIdx.x, L.rec, cur_block, nrec, (uint32_t)s.idx, s.delta_t);
                         ++nrec;
                     } else if (!over) {
                         over = true;
@@ -1995,7 +2118,7 @@ opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
     }
     out[q] = 1.f - light;
     if constexpr (REC) {
-        rec_stage_finish(rstage, (int)threadIdx.x, rec, tid, S, nrec);
+        rec_stage_finish(rstage, (int)threadIdx.x, L.rec, cur_block, nrec);
         aux[q] = make_uint4((uint32_t)nrec | (over ? kRecOverflow : 0u), __float_as_uint(t_resume),
                             __float_as_uint(light), 0u);
     }
@@ -2012,7 +2135,8 @@ opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
 template <bool N2>
 __global__ void __launch_bounds__(kBlock)
 opacity_walk_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
-                    float* __restrict__ grad, int gstride, uint2* __restrict__ rec, int S, uint4* __restrict__ aux) {
+                    float* __restrict__ grad, int gstride, RecLists L, uint4* __restrict__ aux) {
+    uint2* __restrict__ rec = L.rec;
     const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t q = ray_of_thread(rays, tid);
     if (q >= rays.Q) return;
@@ -2026,7 +2150,7 @@ opacity_walk_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict_
     const float g = grad_out[q];
     float light = 1.f;
     for (int k = 0; k < nrec; ++k) {
-        uint2* slot = rec + rec_index(tid, k, S);
+        uint2* slot = rec + rec_index(L, tid, k);
         const uint2 e = rec_get(slot);
         const float delta_t = __uint_as_float(e.y);
         const float sigma = tr.features[(int64_t)(int32_t)e.x * K + (K - 1)];
@@ -2060,7 +2184,7 @@ opacity_walk_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict_
 // record is cheap, 28 were not), flushed after every pass of at most T records.
 template <int T, int W>
 __global__ void __launch_bounds__(64 * W)
-opacity_merge_kernel(RaysDev rays, const uint2* __restrict__ rec, int S, const uint4* __restrict__ aux,
+opacity_merge_kernel(RaysDev rays, RecLists L, const uint4* __restrict__ aux,
                      float* __restrict__ grad, int gstride, int col) {
     constexpr int NT = 64 * W;
     constexpr int kGroup = 2, kRound = kGroup * W, RPP = T / (64 * kRound);
@@ -2068,6 +2192,7 @@ opacity_merge_kernel(RaysDev rays, const uint2* __restrict__ rec, int S, const u
     __shared__ int32_t keys[T];
     __shared__ float vals[T];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t tabreg = rec_tab_reg(L, blockIdx.x, lane);
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * 64 + lane);
     int nrec = 0;
     float t_ray = 0.f;
@@ -2091,7 +2216,7 @@ opacity_merge_kernel(RaysDev rays, const uint2* __restrict__ rec, int S, const u
 #pragma unroll
             for (int u = 0; u < kGroup; ++u) {
                 e[u] = make_uint2(0u, 0u);
-                if (kb + u < nrec) e[u] = rec_get(rec + rec_index((int64_t)blockIdx.x * 64 + lane, kb + u, S));
+                if (kb + u < nrec) e[u] = rec_get(L.rec + rec_index_in(rec_block_u(L, tabreg, blockIdx.x, (kb + u) >> 3), lane, kb + u));
             }
 #pragma unroll
             for (int u = 0; u < kGroup; ++u) {
@@ -2522,6 +2647,25 @@ inline unsigned nblocks(int64_t Q) { return (unsigned)((Q + kBlock - 1) / kBlock
 
 // sample lists: rec[tile][block of 8][lane][8], 8 bytes per record (rec_index)
 inline int64_t rec_rays(int64_t Q) { return (Q + 63) / 64 * 64; }
+// the kernels' view of caller-owned lists / of a dense workspace region
+inline RecLists lists_dev(const svoxt_sample_lists* l, int64_t Q) {
+    RecLists L;
+    L.rec = reinterpret_cast<uint2*>(l->rec);
+    L.tab = reinterpret_cast<int32_t*>(l->blocktab);
+    L.pool_next = reinterpret_cast<int32_t*>(l->pool_next);
+    L.pool_blocks = l->blocktab != nullptr ? l->pool_blocks : rec_rays(Q) / 64 * (l->max_samples / kRecBlock);
+    L.S = l->max_samples;
+    return L;
+}
+inline RecLists dense_lists(void* rec, int64_t S, int64_t Q) {
+    RecLists L;
+    L.rec = reinterpret_cast<uint2*>(rec);
+    L.tab = nullptr;
+    L.pool_next = nullptr;
+    L.pool_blocks = rec_rays(Q) / 64 * (S / kRecBlock);
+    L.S = (int)S;
+    return L;
+}
 inline int64_t rec_capacity(int64_t bytes, int64_t Q) {       // records per ray that fit: a multiple of 8, at most 4096
     if (bytes <= 0 || Q <= 0) return 0;
     int64_t S = bytes / (8 * rec_rays(Q)) / kRecBlock * kRecBlock;
@@ -2544,12 +2688,12 @@ bool full_comp(const svoxt_options* o) {
 // specialised kernels with per-leaf view rotations: SH payloads on N = 2 trees
 template <bool REC>
 bool launch_fwd_xform(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C, float* out,
-                      uint2* rec, int S, uint4* aux, hipStream_t st) {
+                      RecLists L, uint4* aux, hipStream_t st) {
     if (opt.format != FMT_SH || C != 3) return false;
     const unsigned nb = nblocks(rays.Q);
 #define SVOXT_FWD_XF(BB)                                                                                    \
     hipLaunchKernelGGL((render_fwd_kernel<FMT_SH, 3, BB, true, REC, true>), dim3(nb), dim3(kBlock), 0, st,  \
-                       tr, rays, opt, out, rec, S, aux);                                                    \
+                       tr, rays, opt, out, L, aux);                                                    \
     return true;
     switch (opt.basis_dim) {
         case 1: SVOXT_FWD_XF(1)
@@ -2564,13 +2708,13 @@ bool launch_fwd_xform(const TreeDev& tr, const RaysDev& rays, const Opts& opt, i
 
 template <bool REPLAY>
 bool launch_bwd_xform(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
-                      const float* grad_out, float* grad, int gstride, uint2* rec, int S, const uint4* aux,
+                      const float* grad_out, float* grad, int gstride, RecLists L, const uint4* aux,
                       const float* fwd_out, hipStream_t st) {
     if (opt.format != FMT_SH || C != 3) return false;
     const unsigned nb = nblocks(rays.Q);
 #define SVOXT_BWD_XF(BB)                                                                                      \
     hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, REPLAY, true>), dim3(nb), dim3(kBlock), 0, st, \
-                       tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out);                         \
+                       tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out);                         \
     return true;
     switch (opt.basis_dim) {
         case 1: SVOXT_BWD_XF(1)
@@ -2591,11 +2735,11 @@ bool xform_special(const svoxt_tree* t, const svoxt_options* o) {
 
 template <bool N2, bool REC>
 bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C, float* out,
-                        uint2* rec, int S, uint4* aux, hipStream_t st) {
+                        RecLists L, uint4* aux, hipStream_t st) {
     const unsigned nb = nblocks(rays.Q);
 #define SVOXT_FWD(F, CC, BB)                                                                   \
     hipLaunchKernelGGL((render_fwd_kernel<F, CC, BB, N2, REC>), dim3(nb), dim3(kBlock), 0, st, \
-                       tr, rays, opt, out, rec, S, aux);                                       \
+                       tr, rays, opt, out, L, aux);                                       \
     return true;
     if (opt.format == FMT_RGBA) {
         if (C == 3) { SVOXT_FWD(FMT_RGBA, 3, 0) }
@@ -2637,14 +2781,14 @@ bool fwd_split_payload(const svoxt_tree* t, const svoxt_options* o, int C) {
 
 // The shade (+ tail) launches of one range of tiles.
 template <bool N2, bool STOP>
-bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out, uint2* rec, int S, uint4* aux,
+bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out, RecLists L, uint4* aux,
                   bool xf, bool fast, unsigned nb, hipStream_t st) {
 #define SVOXT_SPLIT(F, BB, X)                                                                                 \
     {                                                                                                         \
         hipLaunchKernelGGL((shade_tile_kernel<F, BB, X, STOP>), dim3(nb), dim3(512), 0, st, tr, rays, opt,    \
-                           rec, S, aux, out);                                                                 \
+                           L, aux, out);                                                                 \
         hipLaunchKernelGGL((render_fwd_kernel<F, 3, BB, N2, false, X, true>), dim3(nb), dim3(kBlock), 0, st,  \
-                           tr, rays, opt, out, (uint2*)nullptr, S, aux);                                      \
+                           tr, rays, opt, out, L, aux);                                      \
         return true;                                                                                          \
     }
     if (opt.format == FMT_RGBA && tr.K != 4) {
@@ -2653,9 +2797,9 @@ bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float
         {                                                                                                     \
             const unsigned nbc = (unsigned)(((int64_t)nb * 64 / (64 / KK) + 3) / 4);                          \
             if (fast) hipLaunchKernelGGL((shade_chan_kernel<KK, STOP, true>), dim3(nbc), dim3(256), 0, st,    \
-                                         tr, rays, opt, rec, S, aux, out);                                    \
+                                         tr, rays, opt, L, aux, out);                                    \
             else hipLaunchKernelGGL((shade_chan_kernel<KK, STOP, false>), dim3(nbc), dim3(256), 0, st,        \
-                                    tr, rays, opt, rec, S, aux, out);                                         \
+                                    tr, rays, opt, L, aux, out);                                         \
             if (fast) hipLaunchKernelGGL((tail_chan_kernel<KK, N2, true>), dim3(nbc), dim3(256), 0, st,       \
                                          tr, rays, opt, aux, out);                                            \
             else hipLaunchKernelGGL((tail_chan_kernel<KK, N2, false>), dim3(nbc), dim3(256), 0, st,           \
@@ -2731,7 +2875,7 @@ int fwd_split_chunks(int64_t ntiles) {
 
 template <bool N2, bool STOP>
 bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out,
-                      uint2* rec, int S, uint4* aux, bool xf, bool fast, hipStream_t st) {
+                      RecLists L, uint4* aux, bool xf, bool fast, hipStream_t st) {
     const unsigned nb = nblocks(rays.Q);
     if (xf && !N2) return false;
     const bool acc = N2 && tr.accel != nullptr;
@@ -2743,14 +2887,14 @@ bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
         const unsigned lo = (unsigned)((uint64_t)nb * c / nchunk), hi = (unsigned)((uint64_t)nb * (c + 1) / nchunk);
         RaysDev rc = rays;
         rc.tile0 = lo;
-        if (acc) hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 1>), dim3(hi - lo), dim3(kBlock), 0, st, tr, rc, opt, rec, S, aux);
-        else hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 0>), dim3(hi - lo), dim3(kBlock), 0, st, tr, rc, opt, rec, S, aux);
+        if (acc) hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 1>), dim3(hi - lo), dim3(kBlock), 0, st, tr, rc, opt, L, aux);
+        else hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 0>), dim3(hi - lo), dim3(kBlock), 0, st, tr, rc, opt, L, aux);
         if (nchunk == 1) {
-            ok = launch_shade<N2, STOP>(tr, rc, opt, out, rec, S, aux, xf, fast, hi - lo, st);
+            ok = launch_shade<N2, STOP>(tr, rc, opt, out, L, aux, xf, fast, hi - lo, st);
         } else {
             // the side stream takes over this range once its march is done
             if (hipEventRecord(ss->ev[c], st) != hipSuccess || hipStreamWaitEvent(ss->st, ss->ev[c], 0) != hipSuccess) return false;
-            ok = launch_shade<N2, STOP>(tr, rc, opt, out, rec, S, aux, xf, fast, hi - lo, ss->st);
+            ok = launch_shade<N2, STOP>(tr, rc, opt, out, L, aux, xf, fast, hi - lo, ss->st);
         }
     }
     if (nchunk > 1) {   // join: what follows on the caller's stream sees every pixel
@@ -2762,7 +2906,7 @@ bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
 // two-kernel backward: SH 1/4/9 (also with view rotations) and RGBA with 3 channels
 // (K <= 32) on N = 2 trees
 bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
-                       const float* grad_out, float* grad, int gstride, uint2* rec, int S, const uint4* aux,
+                       const float* grad_out, float* grad, int gstride, RecLists L, const uint4* aux,
                        const float* fwd_out, float4* coef, bool xf, hipStream_t st, float4* terms = nullptr) {
     if (C != 3) return false;
     const unsigned nb = nblocks(rays.Q);
@@ -2776,36 +2920,36 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
 #define SVOXT_GATHER(F, BB)                                                                                   \
     if (fused) {   /* tails of overflowed rays (a tail-only launch), then list walk and merge in one kernel */ \
         hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
-                           tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out, (float4*)nullptr);   \
+                           tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out, (float4*)nullptr);   \
         unsigned long long* ctr = reinterpret_cast<unsigned long long*>(g_bwd_counters);                      \
         if (fwd_out != nullptr && ctr == nullptr)                                                             \
             hipLaunchKernelGGL((grad_fused_kernel<F, BB, false>), dim3(nb), dim3(512), 0, st,                 \
-                               tr, rays, opt, grad_out, rec, S, aux, fwd_out, grad, gstride);                 \
+                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                 \
         else if (ctr == nullptr && terms != nullptr)                                                          \
             hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, true>), dim3(nb), dim3(512), 0, st,     \
-                               tr, rays, opt, grad_out, rec, S, aux, fwd_out, grad, gstride,                  \
+                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride,                  \
                                (unsigned long long*)nullptr, terms);                                          \
         else if (ctr == nullptr)                                                                              \
             hipLaunchKernelGGL((grad_fused_kernel<F, BB, true>), dim3(nb), dim3(512), 0, st,                  \
-                               tr, rays, opt, grad_out, rec, S, aux, fwd_out, grad, gstride);                 \
+                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                 \
         else if (fwd_out != nullptr)                                                                          \
             hipLaunchKernelGGL((grad_fused_kernel<F, BB, false, true>), dim3(nb), dim3(512), 0, st,           \
-                               tr, rays, opt, grad_out, rec, S, aux, fwd_out, grad, gstride, ctr);            \
+                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, ctr);            \
         else                                                                                                  \
             hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, true>), dim3(nb), dim3(512), 0, st,            \
-                               tr, rays, opt, grad_out, rec, S, aux, fwd_out, grad, gstride, ctr);            \
+                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, ctr);            \
         return true;                                                                                          \
     }                                                                                                         \
     hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
-                       tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out, coef);                   \
+                       tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out, coef);                   \
     hipLaunchKernelGGL((grad_merge_kernel<F, BB, 1024, 1024, 4>), dim3(nb), dim3(256), 0, st, tr, rays,      \
-                       grad_out, rec, coef, aux, grad, gstride, S);                                           \
+                       grad_out, L, coef, aux, grad, gstride);                                                \
     return true;
 #define SVOXT_GATHER_XF(BB)                                                                                       \
     hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, true, true, true>), dim3(nb), dim3(kBlock), 0, st, \
-                       tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out, coef);                       \
+                       tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out, coef);                       \
     hipLaunchKernelGGL((grad_merge_kernel<FMT_SH, BB, 1024, 512, 4, true>), dim3(nb), dim3(256), 0, st, tr, rays, \
-                       grad_out, rec, coef, aux, grad, gstride, S);                                               \
+                       grad_out, L, coef, aux, grad, gstride);                                                    \
     return true;
     if (xf) {
         if (opt.format != FMT_SH) return false;
@@ -2831,12 +2975,12 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
 
 template <bool N2, bool REPLAY>
 bool launch_bwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
-                        const float* grad_out, float* grad, int gstride, uint2* rec, int S, const uint4* aux,
+                        const float* grad_out, float* grad, int gstride, RecLists L, const uint4* aux,
                         const float* fwd_out, hipStream_t st) {
     const unsigned nb = nblocks(rays.Q);
 #define SVOXT_BWD(F, CC, BB)                                                                      \
     hipLaunchKernelGGL((render_bwd_kernel<F, CC, BB, N2, REPLAY>), dim3(nb), dim3(kBlock), 0, st, \
-                       tr, rays, opt, grad_out, grad, gstride, rec, S, aux, fwd_out);             \
+                       tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out);             \
     return true;
     if (opt.format == FMT_RGBA) {
         if (C == 3) { SVOXT_BWD(FMT_RGBA, 3, 0) }
@@ -2893,23 +3037,23 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
         if (lists != nullptr) {
             const int64_t need = (int64_t)lists->max_samples * rays->Q * 32;
             if (lists->coef != nullptr && tree->K <= 32 && lists->coef_bytes >= need)
-                done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, reinterpret_cast<uint2*>(lists->rec),
-                                         lists->max_samples, reinterpret_cast<const uint4*>(lists->aux), fwd_out,
+                done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, lists_dev(lists, rays->Q),
+                                         reinterpret_cast<const uint4*>(lists->aux), fwd_out,
                                          reinterpret_cast<float4*>(lists->coef), true, st);
             if (!done)
-                done = launch_bwd_xform<true>(tr, rd, od, C, grad_out, grad_features, gs, reinterpret_cast<uint2*>(lists->rec),
-                                              lists->max_samples, reinterpret_cast<const uint4*>(lists->aux), fwd_out, st);
+                done = launch_bwd_xform<true>(tr, rd, od, C, grad_out, grad_features, gs, lists_dev(lists, rays->Q),
+                                              reinterpret_cast<const uint4*>(lists->aux), fwd_out, st);
         }
         else
             done = launch_bwd_xform<false>(tr, rd, od, C, grad_out, grad_features, gs,
-                                           S > 0 ? reinterpret_cast<uint2*>(workspace) : nullptr, (int)S, nullptr, nullptr, st);
+                                           dense_lists(S > 0 ? workspace : nullptr, S, rays->Q), nullptr, nullptr, st);
     } else if (C > 0 && full_comp(opt) && !xf)
     {
         // per-ray sample lists: S entries of 8 bytes per ray, laid out rec[k][q]
         const int64_t S = workspace != nullptr ? rec_capacity(workspace_bytes, rays->Q) : 0;
-        uint2* rec = S > 0 ? reinterpret_cast<uint2*>(workspace) : nullptr;
+        const RecLists wl = dense_lists(S > 0 ? workspace : nullptr, S, rays->Q);
         if (lists != nullptr) {
-            uint2* lrec = reinterpret_cast<uint2*>(lists->rec);
+            const RecLists ll = lists_dev(lists, rays->Q);
             const uint4* laux = reinterpret_cast<const uint4*>(lists->aux);
             // coef_bytes < 0 (and no coef): the per-tile route if it can run fused, which needs no buffer
             const bool have_coef = lists->coef != nullptr &&
@@ -2918,17 +3062,17 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
             {
                 // optional scratch of the exact one-kernel form: 16 bytes per list slot
                 const bool have_terms = lists->terms != nullptr && ((uintptr_t)lists->terms & 15u) == 0 &&
-                                        lists->terms_bytes >= rec_rays(rays->Q) * (int64_t)lists->max_samples * 16;
-                done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux,
+                                        lists->terms_bytes >= ll.pool_blocks * (int64_t)(64 * kRecBlock * 16);
+                done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, ll, laux,
                                          fwd_out, have_coef ? reinterpret_cast<float4*>(lists->coef) : nullptr, false, st,
                                          have_terms ? reinterpret_cast<float4*>(lists->terms) : nullptr);
             }
-            if (!done) done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux, fwd_out, st)
-                      : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, gs, lrec, lists->max_samples, laux, fwd_out, st);
+            if (!done) done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, gs, ll, laux, fwd_out, st)
+                      : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, gs, ll, laux, fwd_out, st);
             if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no specialised kernel for this payload", fn);
         } else {
-            done = n2 ? launch_bwd_special<true, false>(tr, rd, od, C, grad_out, grad_features, gs, rec, (int)S, nullptr, nullptr, st)
-                      : launch_bwd_special<false, false>(tr, rd, od, C, grad_out, grad_features, gs, rec, (int)S, nullptr, nullptr, st);
+            done = n2 ? launch_bwd_special<true, false>(tr, rd, od, C, grad_out, grad_features, gs, wl, nullptr, nullptr, st)
+                      : launch_bwd_special<false, false>(tr, rd, od, C, grad_out, grad_features, gs, wl, nullptr, nullptr, st);
         }
     } else if (lists != nullptr) {
         return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists need a specialised payload", fn);
@@ -2969,14 +3113,35 @@ static int check_lists(const svoxt_sample_lists* l, const svoxt_options* opt, co
     if (l == nullptr) return fail(SVOXT_ERR_INVALID, "%s: lists is NULL", fn);
     if (l->rec == nullptr || l->aux == nullptr || l->max_samples < 8 || l->max_samples > 4096 || l->max_samples % 8 != 0)
         return fail(SVOXT_ERR_INVALID, "%s: lists need rec, aux and max_samples a multiple of 8 in [8, 4096]", fn);
+    if (l->blocktab != nullptr && (l->pool_next == nullptr || l->pool_blocks < kSubPools || l->pool_blocks % kSubPools != 0 ||
+                                   l->max_samples > kMaxRecBlocks * kRecBlock))
+        return fail(SVOXT_ERR_INVALID, "%s: pooled lists need pool_next, pool_blocks a positive multiple of 32 and max_samples <= 512", fn);
+    if (((uintptr_t)l->rec & 63u) != 0) return fail(SVOXT_ERR_INVALID, "%s: lists.rec must be 64-byte aligned", fn);
     if (opt->sigma_thresh != 0.f || opt->stop_thresh != 0.f)
         return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists require sigma_thresh == stop_thresh == 0", fn);
     return SVOXT_OK;
 }
 
+// a recording forward starts with an empty block table and pool (pooled lists only)
+static int lists_begin(const svoxt_sample_lists* l, int64_t Q, hipStream_t st, const char* fn) {
+    if (l->blocktab == nullptr) return SVOXT_OK;
+    const size_t n = (size_t)(rec_rays(Q) / 64) * (l->max_samples / kRecBlock) * sizeof(int32_t);
+    const size_t nc = sizeof(int32_t) * kSubPools * kSubPoolStride;
+    hipError_t e;
+    if (reinterpret_cast<char*>(l->blocktab) + n == reinterpret_cast<char*>(l->pool_next)) {
+        e = hipMemsetAsync(l->blocktab, 0xff, n + nc, st);       // counters right behind the table: one fill
+    } else {
+        e = hipMemsetAsync(l->blocktab, 0xff, n, st);
+        if (e == hipSuccess) e = hipMemsetAsync(l->pool_next, 0xff, nc, st);
+    }
+    if (e != hipSuccess) return fail(SVOXT_ERR_HIP, "%s: hipMemsetAsync: %s", fn, hipGetErrorString(e));
+    return SVOXT_OK;
+}
+
 static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt, float* out,
                       const svoxt_sample_lists* lists, void* stream, const char* fn,
-                      void* workspace = nullptr, int64_t workspace_bytes = 0, int32_t flags = 0) {
+                      void* workspace = nullptr, int64_t workspace_bytes = 0, int32_t flags = 0,
+                      const svoxt_sample_lists* scratch = nullptr) {
     int rc;
     if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) || (rc = check_opts(opt, tree, fn, true)))
         return rc;
@@ -2990,6 +3155,7 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
     if (opt->format != SVOXT_FORMAT_RGBA && (int64_t)C * opt->basis_dim > tree->K - 1)
         return fail(SVOXT_ERR_INVALID, "%s: data_dim is not channels * basis_dim + 1", fn);
     hipStream_t st = (hipStream_t)stream;
+    if (lists != nullptr && (rc = lists_begin(lists, rays->Q, st, fn))) return rc;
     const TreeDev tr = to_dev(tree);
     const RaysDev rd = to_dev(rays);
     const Opts od = to_dev(opt);
@@ -3002,16 +3168,20 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
         (!uses_xform(tree, opt) || xform_special(tree, opt))) {
         const bool xf = uses_xform(tree, opt);
         if (lists != nullptr) {
-            uint2* rec = reinterpret_cast<uint2*>(lists->rec);
             uint4* aux = reinterpret_cast<uint4*>(lists->aux);
-            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, rec, lists->max_samples, aux, xf, false, st)
-                      : launch_fwd_split<false, false>(tr, rd, od, out, rec, lists->max_samples, aux, xf, false, st);
+            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, xf, false, st)
+                      : launch_fwd_split<false, false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, xf, false, st);
+        } else if (scratch != nullptr) {      // caller-owned lists as scratch (dense or pooled): the stop rule applies
+            if ((rc = lists_begin(scratch, rays->Q, st, fn))) return rc;
+            uint4* aux = reinterpret_cast<uint4*>(scratch->aux);
+            done = n2 ? launch_fwd_split<true, true>(tr, rd, od, out, lists_dev(scratch, rays->Q), aux, xf, fast, st)
+                      : launch_fwd_split<false, true>(tr, rd, od, out, lists_dev(scratch, rays->Q), aux, xf, fast, st);
         } else if (workspace != nullptr && rec_capacity(workspace_bytes - rec_rays(rays->Q) * 16, rays->Q) >= kRecBlock) {
             const int64_t S = rec_capacity(workspace_bytes - rec_rays(rays->Q) * 16, rays->Q);
             uint4* aux = reinterpret_cast<uint4*>(workspace);                       // aux first: rec stays 64-byte aligned
-            uint2* rec = reinterpret_cast<uint2*>(reinterpret_cast<char*>(workspace) + rec_rays(rays->Q) * 16);
-            done = n2 ? launch_fwd_split<true, true>(tr, rd, od, out, rec, (int)S, aux, xf, fast, st)
-                      : launch_fwd_split<false, true>(tr, rd, od, out, rec, (int)S, aux, xf, fast, st);
+            const RecLists L = dense_lists(reinterpret_cast<char*>(workspace) + rec_rays(rays->Q) * 16, S, rays->Q);
+            done = n2 ? launch_fwd_split<true, true>(tr, rd, od, out, L, aux, xf, fast, st)
+                      : launch_fwd_split<false, true>(tr, rd, od, out, L, aux, xf, fast, st);
         }
         if (done) return check_launch(fn);
     }
@@ -3020,20 +3190,19 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
         // payloads on N = 2 trees, the generic kernel otherwise
         if (full_comp(opt) && xform_special(tree, opt)) {
             if (lists != nullptr)
-                done = launch_fwd_xform<true>(tr, rd, od, C, out, reinterpret_cast<uint2*>(lists->rec),
-                                              lists->max_samples, reinterpret_cast<uint4*>(lists->aux), st);
+                done = launch_fwd_xform<true>(tr, rd, od, C, out, lists_dev(lists, rays->Q),
+                                              reinterpret_cast<uint4*>(lists->aux), st);
             else
-                done = launch_fwd_xform<false>(tr, rd, od, C, out, nullptr, 0, nullptr, st);
+                done = launch_fwd_xform<false>(tr, rd, od, C, out, RecLists{}, nullptr, st);
         }
     } else if (full_comp(opt)) {
         if (lists != nullptr) {
-            uint2* rec = reinterpret_cast<uint2*>(lists->rec);
             uint4* aux = reinterpret_cast<uint4*>(lists->aux);
-            done = n2 ? launch_fwd_special<true, true>(tr, rd, od, C, out, rec, lists->max_samples, aux, st)
-                      : launch_fwd_special<false, true>(tr, rd, od, C, out, rec, lists->max_samples, aux, st);
+            done = n2 ? launch_fwd_special<true, true>(tr, rd, od, C, out, lists_dev(lists, rays->Q), aux, st)
+                      : launch_fwd_special<false, true>(tr, rd, od, C, out, lists_dev(lists, rays->Q), aux, st);
         } else {
-            done = n2 ? launch_fwd_special<true, false>(tr, rd, od, C, out, nullptr, 0, nullptr, st)
-                      : launch_fwd_special<false, false>(tr, rd, od, C, out, nullptr, 0, nullptr, st);
+            done = n2 ? launch_fwd_special<true, false>(tr, rd, od, C, out, RecLists{}, nullptr, st)
+                      : launch_fwd_special<false, false>(tr, rd, od, C, out, RecLists{}, nullptr, st);
         }
     }
     if (!done) {
@@ -3061,6 +3230,19 @@ int svoxt_volume_render_fwd_ws(const svoxt_tree* tree, const svoxt_rays* rays, c
     if (workspace != nullptr && ((uintptr_t)workspace & 63u) != 0)
         return fail(SVOXT_ERR_INVALID, "%s: workspace must be 64-byte aligned", "svoxt_volume_render_fwd_ws");
     return fwd_common(tree, rays, opt, out, nullptr, stream, "svoxt_volume_render_fwd_ws", workspace, workspace_bytes, flags);
+}
+
+int svoxt_volume_render_fwd_scratch(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
+                                    float* out, const svoxt_sample_lists* scratch, int32_t flags, void* stream) {
+    const char* fn = "svoxt_volume_render_fwd_scratch";
+    if (scratch == nullptr) return fail(SVOXT_ERR_INVALID, "%s: scratch is NULL", fn);
+    if (scratch->rec == nullptr || scratch->aux == nullptr || scratch->max_samples < 8 || scratch->max_samples % 8 != 0 ||
+        scratch->max_samples > 4096 || ((uintptr_t)scratch->rec & 63u) != 0 ||
+        (scratch->blocktab != nullptr && (scratch->pool_next == nullptr || scratch->pool_blocks < kSubPools ||
+                                          scratch->pool_blocks % kSubPools != 0 ||
+                                          scratch->max_samples > kMaxRecBlocks * kRecBlock)))
+        return fail(SVOXT_ERR_INVALID, "%s: scratch lists are malformed (see svoxt_sample_lists)", fn);
+    return fwd_common(tree, rays, opt, out, nullptr, stream, fn, nullptr, 0, flags, scratch);
 }
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt) {
@@ -3140,10 +3322,11 @@ int svoxt_opacity_render_fwd_record(const svoxt_tree* tree, const svoxt_rays* ra
     if (out == nullptr) return fail(SVOXT_ERR_INVALID, "%s: out is NULL", fn);
     hipStream_t st = (hipStream_t)stream;
     const unsigned nb = nblocks(rays->Q);
-    uint2* rec = reinterpret_cast<uint2*>(lists->rec);
+    if ((rc = lists_begin(lists, rays->Q, st, fn))) return rc;
+    const RecLists L = lists_dev(lists, rays->Q);
     uint4* aux = reinterpret_cast<uint4*>(lists->aux);
-    if (tree->N == 2) hipLaunchKernelGGL((opacity_fwd_kernel<true, true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), out, rec, lists->max_samples, aux);
-    else hipLaunchKernelGGL((opacity_fwd_kernel<false, true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), out, rec, lists->max_samples, aux);
+    if (tree->N == 2) hipLaunchKernelGGL((opacity_fwd_kernel<true, true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), out, L, aux);
+    else hipLaunchKernelGGL((opacity_fwd_kernel<false, true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), out, L, aux);
     return check_launch(fn);
 }
 
@@ -3166,11 +3349,11 @@ int svoxt_opacity_render_bwd_replay(const svoxt_tree* tree, const svoxt_rays* ra
     if (rays->Q == 0 || tree->M == 0) return SVOXT_OK;
     const unsigned nb = nblocks(rays->Q);
     const RaysDev rd = to_dev(rays);
-    uint2* rec = reinterpret_cast<uint2*>(lists->rec);
+    const RecLists L = lists_dev(lists, rays->Q);
     uint4* aux = reinterpret_cast<uint4*>(lists->aux);
-    if (tree->N == 2) hipLaunchKernelGGL((opacity_walk_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), rd, to_dev(opt), grad_out, grad_features, gs, rec, lists->max_samples, aux);
-    else hipLaunchKernelGGL((opacity_walk_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), rd, to_dev(opt), grad_out, grad_features, gs, rec, lists->max_samples, aux);
-    hipLaunchKernelGGL((opacity_merge_kernel<1024, 4>), dim3(nb), dim3(256), 0, st, rd, rec, lists->max_samples, aux, grad_features, gs, (int)tree->K - 1);
+    if (tree->N == 2) hipLaunchKernelGGL((opacity_walk_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), rd, to_dev(opt), grad_out, grad_features, gs, L, aux);
+    else hipLaunchKernelGGL((opacity_walk_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), rd, to_dev(opt), grad_out, grad_features, gs, L, aux);
+    hipLaunchKernelGGL((opacity_merge_kernel<1024, 4>), dim3(nb), dim3(256), 0, st, rd, L, aux, grad_features, gs, (int)tree->K - 1);
     return check_launch(fn);
 }
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_C.EXPORTS)          # the ctypes table and the header agree
-    assert lib.svoxt_abi_version() == _C.ABI_VERSION == 11
+    assert lib.svoxt_abi_version() == _C.ABI_VERSION == 12
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -67,8 +67,8 @@ def test_validation_codes_without_touching_the_gpu():
     t = _C._CTree()
     assert lib.svoxt_render_depth(ctypes.byref(t), None, None, None, None) == 1
     assert b"NULL" in lib.svoxt_last_error()
-    buf = (ctypes.c_float * 64)()
-    p = ctypes.cast(buf, ctypes.c_void_p)
+    buf = (ctypes.c_float * 96)()
+    p = ctypes.c_void_p((ctypes.addressof(buf) + 63) & ~63)        # list records must sit on 64-byte lines
     t = _C._CTree(features=p, M=1, K=13, N=3, data=p, child=p, n_internal=1, offset=p, scaling=p, xform=p, xform_dim=3)
     # sample lists combine with per-leaf view rotations only for SH payloads on N = 2 trees
     o = _C._COptions(format=1, basis_dim=4, min_comp=0, max_comp=3)
