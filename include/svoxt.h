@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 12
+#define SVOXT_ABI_VERSION 13
 
 enum {
     SVOXT_OK = 0,
@@ -220,9 +220,12 @@ typedef struct svoxt_sample_lists {
                               can run as ONE kernel (no view rotations, fwd_out given: list walk and merge
                               fused, nothing goes through coef), else the one-kernel backward */
     void*   terms;         /* device, 16-byte aligned, terms_bytes >= 2 * the bytes of rec (16 per record slot), or NULL:
-                              scratch for that ONE kernel in its exact form (fwd_out NULL).  Its first sweep
-                              over the lists then leaves each sample's attenuation and three exponentials for
-                              the second, which no longer gathers the feature row again.  Same bits either way. */
+                              (att, e_0, e_1, e_2) of every 3-channel sample as the exact backward (fwd_out NULL,
+                              the ONE-kernel form) needs them.  Given to svoxt_volume_render_fwd_record, the
+                              one-kernel forward fills it (svoxt_fwd_fills_terms says whether it will); the
+                              backward, told so by terms_state = 2, then gathers no feature row and forms no
+                              exponential in either of its sweeps.  terms_state = 0: scratch only -- the
+                              backward's first sweep fills it for the second.  Same bits every way. */
     int64_t terms_bytes;
     /* Pooled lists (optional, ABI v12).  blocktab NULL: dense -- rec holds max_samples slots for every
      * ray, as described above.  blocktab given: device int32 [ceil(Q / 64) * max_samples / 8]; entry
@@ -238,9 +241,12 @@ typedef struct svoxt_sample_lists {
     void*   blocktab;
     int64_t pool_blocks;
     void*   pool_next;
+    int32_t terms_state;   /* see terms */
 } svoxt_sample_lists;
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt);
+/* 1 if svoxt_volume_render_fwd_record, given lists with `terms`, fills them for this tree / options */
+int svoxt_fwd_fills_terms(const svoxt_tree* tree, const svoxt_options* opt);
 int svoxt_volume_render_fwd_record(const svoxt_tree* tree, const svoxt_rays* rays,
                                    const svoxt_options* opt, float* out,
                                    const svoxt_sample_lists* lists, void* stream);

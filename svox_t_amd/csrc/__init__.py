@@ -43,7 +43,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -90,7 +90,8 @@ class _CLists(ctypes.Structure):         # struct svoxt_sample_lists
     _fields_ = [("rec", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("max_samples", ctypes.c_int32),
                 ("coef", ctypes.c_void_p), ("coef_bytes", ctypes.c_int64),
                 ("terms", ctypes.c_void_p), ("terms_bytes", ctypes.c_int64),
-                ("blocktab", ctypes.c_void_p), ("pool_blocks", ctypes.c_int64), ("pool_next", ctypes.c_void_p)]
+                ("blocktab", ctypes.c_void_p), ("pool_blocks", ctypes.c_int64), ("pool_next", ctypes.c_void_p),
+                ("terms_state", ctypes.c_int32)]
 
 
 _P = ctypes.POINTER
@@ -108,6 +109,7 @@ EXPORTS = {
     "svoxt_volume_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _vp, _i64, _vp]),
     "svoxt_bwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
     "svoxt_can_record": (ctypes.c_int, [_P(_CTree), _P(_COptions)]),
+    "svoxt_fwd_fills_terms": (ctypes.c_int, [_P(_CTree), _P(_COptions)]),
     "svoxt_compact_rows": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "svoxt_query_leaves_workspace_bytes": (ctypes.c_int64, [_i64]),
     "svoxt_query_leaves": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
@@ -495,7 +497,8 @@ class SampleLists:
         self.S = S
         self.coef = None        # allocated by the backward when it takes the two-kernel route,
         self.consumed = False   # which rewrites `rec`: the lists then serve no second backward
-        self.terms = None       # scratch of the exact one-kernel backward (allocated there)
+        self.terms = None       # (att, e0, e1, e2) per record slot for the exact one-kernel backward
+        self.terms_state = 0    # 2: filled by the forward; 0: scratch (the backward's first sweep fills it)
 
     def note_usage(self):
         """After the forward that filled the lists was enqueued: remember how much of the pool it took
@@ -522,7 +525,8 @@ class SampleLists:
                        0 if self.terms is None else self.terms.numel() * 4,
                        None if self.blocktab is None else self.blocktab.data_ptr(),
                        self.pool_blocks if self.pooled else 0,
-                       None if self.pool_next is None else self.pool_next.data_ptr())
+                       None if self.pool_next is None else self.pool_next.data_ptr(),
+                       self.terms_state)
 
 
 def _list_cap(ct: "_CTree", base: int) -> int:
@@ -694,6 +698,11 @@ def _volume_render(tree, rays, opt, record):
         if record and BWD_LIST_SAMPLES > 0 and cr.Q > 0 and \
                 _lib.svoxt_can_record(ctypes.byref(ct), ctypes.byref(co)):
             lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
+            if BWD_EXACT and BWD_TERMS and BWD_FUSED and BWD_GATHER and \
+                    _lib.svoxt_fwd_fills_terms(ctypes.byref(ct), ctypes.byref(co)):
+                # the exact per-tile backward will want (att, e0, e1, e2) of every sample: this forward has them
+                lists.terms = torch.empty((lists.pool_blocks * 512 * 4,), dtype=torch.float32, device=dev)
+                lists.terms_state = 2
             cl = lists.c_struct()
             _call("svoxt_volume_render_fwd_record", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(out), ctypes.byref(cl), _stream(dev))
@@ -789,10 +798,10 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
                     raise RuntimeError("fwd_output must match grad_output")
                 fo = fwd_output
             fused = gather and BWD_FUSED and ct.xform is None      # (fo None: the fused kernel's exact form)
-            if fused and fo is None and BWD_TERMS:
-                # sweep 1 -> sweep 2 hand-over: 16 bytes per list slot (as large again as rec twice over;
-                # the caching allocator keeps it between steps)
+            if fused and fo is None and BWD_TERMS and lists.terms is None:
+                # sweep 1 -> sweep 2 hand-over: 16 bytes per list slot (when the forward did not leave them)
                 lists.terms = torch.empty((lists.pool_blocks * 512 * 4,), dtype=torch.float32, device=dev)
+                lists.terms_state = 0
             if gather and not fused:
                 # with view rotations a second plane holds each sample's rotated direction
                 planes = 2 if ct.xform is not None else 1

@@ -101,7 +101,15 @@ struct RecLists {
     int32_t* __restrict__ pool_next;
     int64_t pool_blocks;
     int S;
+    // optional: 16 bytes per record slot, (att, e_0, e_1, e_2) of a 3-channel sample as the BACKWARD
+    // needs them -- att = exp(-delta_t * sigma * delta_scale) in the backward's association
+    // (rt_kernel.cu:397), e_c = exp(-x_c).  Layout [block][k / 4 % 2][lane][k % 4]: the 4 consecutive
+    // entries of a ray are one 64-byte line (written whole by the recording forward, terms_index).
+    float4* __restrict__ terms;
 };
+__device__ __forceinline__ int64_t terms_index(int64_t block, int lane, int k) {
+    return ((((block << 1) + ((k >> 2) & 1)) << 6) + lane) * 4 + (k & 3);
+}
 
 __device__ __forceinline__ int64_t rec_block(const RecLists& L, int64_t tile, int b) {
     const int64_t e = tile * (int64_t)(L.S >> 3) + b;
@@ -188,6 +196,18 @@ __device__ __forceinline__ void rec_stage_finish(const uint2* __restrict__ lds, 
     if (nrec & 7) rec_stage_flush(lds, lane, rec, block);
 }
 
+// the lane's line of four staged (att, e_0, e_1, e_2) entries, the one that holds list position k
+__device__ __forceinline__ void terms_flush(const float4* __restrict__ lds, int lane, float4* __restrict__ terms,
+                                            int64_t block, int k) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f* dst = reinterpret_cast<v4f*>(terms + terms_index(block, lane, k & ~3));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 v = lds[j * 64 + lane];
+        __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, dst + j);
+    }
+}
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -221,6 +241,8 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     __shared__ uint2 rstage[REC ? kRecBlock * kBlock : 1];
     __shared__ int32_t ltab[REC ? kMaxRecBlocks : 1];
+    // (att, e_0, e_1, e_2) of the last <= 4 recorded samples of each ray, for the backward (C == 3)
+    __shared__ float4 tstage[(REC && C == 3 && !XF) ? 4 * kBlock : 1];
     if constexpr (REC) rec_tab_init(ltab);
     const int S = L.S;
     int64_t cur_block = 0;
@@ -269,12 +291,14 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
     auto shade = [&](const float (&row)[K], int32_t idx, float delta_t, float t_cur, uint32_t slot) -> bool {
         const float sigma = row[K - 1];
         if (!(sigma > opt.sigma_thresh)) return false;
+        bool recorded = false;
         if constexpr (REC) {
             bool room = nrec < S;
             if (room && (nrec & 7) == 0) {
                 cur_block = rec_block_begin(L, ltab, tid >> 6, nrec >> 3);
                 room = cur_block >= 0;
             }
+            recorded = room;
             if (room) {
                 rec_stage_put(rstage, (int)threadIdx.x, L.rec, cur_block, nrec, (uint32_t)idx, delta_t);
                 ++nrec;
@@ -285,6 +309,7 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
         }
         const float att = pexpf(-delta_t * r.delta_scale * sigma);
         const float weight = light * (1.f - att);
+        float ex[C];
         if constexpr (FMT == FMT_SH) {
             if constexpr (XF) rotated_sh_basis<BD>(tr, idx, vd, basis);
 #pragma unroll
@@ -292,12 +317,27 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
                 float tmp = 0.f;
 #pragma unroll
                 for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
-                acc[c] = (float)((double)acc[c] + (double)weight / (1.0 + (double)pexpf(-tmp)));
+                ex[c] = pexpf(-tmp);
+                acc[c] = (float)((double)acc[c] + (double)weight / (1.0 + (double)ex[c]));
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < C; ++j)
-                acc[j] = (float)((double)acc[j] + (double)weight / (1.0 + (double)pexpf(-row[j])));
+            for (int j = 0; j < C; ++j) {
+                ex[j] = pexpf(-row[j]);
+                acc[j] = (float)((double)acc[j] + (double)weight / (1.0 + (double)ex[j]));
+            }
+        }
+        if constexpr (REC && C == 3 && !XF) {
+            // what the backward would otherwise gather the row and form again (both of its sweeps):
+            // its own attenuation (exponent associated as in rt_kernel.cu:397) and the three exponentials.
+            // (Measured r02: handing over sigma instead and letting the backward form its attenuation,
+            // with cached instead of non-temporal stores: the forward saves nothing, the backward loses 0.02 ms.)
+            if (recorded && L.terms != nullptr) {
+                const int k = nrec - 1;
+                tstage[(k & 3) * kBlock + threadIdx.x] =
+                    make_float4(pexpf(-delta_t * sigma * r.delta_scale), ex[0], ex[1], ex[2]);
+                if ((k & 3) == 3) terms_flush(tstage, (int)threadIdx.x, L.terms, cur_block, k);
+            }
         }
         light *= att;
         if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + leaf_slot<N2>(tr, r, t_cur, slot), weight);
@@ -342,6 +382,9 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
     o[C] = 1.f - light;
     if constexpr (REC) {  // + the final transmittance, for the single-march backward
         rec_stage_finish(rstage, (int)threadIdx.x, L.rec, cur_block, nrec);
+        if constexpr (C == 3 && !XF) {
+            if (L.terms != nullptr && (nrec & 3)) terms_flush(tstage, (int)threadIdx.x, L.terms, cur_block, nrec - 1);
+        }
         aux[q] = make_uint4((uint32_t)nrec | (over ? kRecOverflow : 0u), __float_as_uint(t_resume),
                             __float_as_uint(light), 0u);
     }
@@ -1508,15 +1551,17 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
 // of their own value (r02, tests/test_gpu_query_and_misc.py) -- opt-in.
 // COUNT (instrumentation, svoxt_set_bwd_counters): counters[0] += 64-byte atomic requests sent,
 // counters[1] += (tile, pass, feature row) groups; the work itself is unchanged.
-// TERMS (EXACT only): sweep 1 hands (att, e_0, e_1, e_2) of every sample to sweep 2 through `terms`.
+// TERMS (EXACT only): 1 = sweep 1 hands (att, e_0, e_1, e_2) of every sample to sweep 2 through
+// L.terms; 2 = the recording forward left them there (render_fwd_kernel): neither sweep gathers a
+// feature row or forms an exponential.
 // Two workgroups per CU (77 KB of LDS each) need at most 128 registers: said to the compiler,
 // because one branch too many costs exactly that (r02: 116 -> 130 registers, 0.38 -> 0.55 ms).
-template <int FMT, int BD, bool EXACT, bool COUNT = false, bool TERMS = false>
+template <int FMT, int BD, bool EXACT, bool COUNT = false, int TERMS = 0>
 __global__ void __launch_bounds__(512, 4)
 grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                   RecLists L, const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
-                  float* __restrict__ grad, int gstride, unsigned long long* __restrict__ counters = nullptr,
-                  float4* __restrict__ terms = nullptr) {
+                  float* __restrict__ grad, int gstride, unsigned long long* __restrict__ counters = nullptr) {
+    float4* __restrict__ terms = L.terms;
     constexpr int C = 3, W = 8, NT = 64 * W, T = 1024, R = 1024, RPP = R / (64 * W);
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     constexpr int NB = (FMT == FMT_SH) ? BD : 0;
@@ -1587,30 +1632,34 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             const int k = rd * W + wave;
             if (rd < nr1 && k < nrec) {
                 const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
-                const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
-                float row[K];
-                load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
-                const float att = pexpf<true>(-__uint_as_float(e.y) * row[K - 1] * r.delta_scale);
-                float total_color = 0.f;
-                float ex[C];                                  // exp(-x_c): sigmoid_d(x) = 1.0 / (1.0 + double(exp(-x)))
+                float att, ex[C];                             // exp(-x_c): sigmoid_d(x) = 1.0 / (1.0 + double(exp(-x)))
+                if constexpr (TERMS == 2) {
+                    const float4 tv = terms[terms_index(blk, lane, k)];
+                    att = tv.x; ex[0] = tv.y; ex[1] = tv.z; ex[2] = tv.w;
+                } else {
+                    const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
+                    float row[K];
+                    load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
+                    att = pexpf<true>(-__uint_as_float(e.y) * row[K - 1] * r.delta_scale);
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    float x;
-                    if constexpr (FMT == FMT_SH) {
-                        x = 0.f;
+                    for (int c = 0; c < C; ++c) {
+                        float x;
+                        if constexpr (FMT == FMT_SH) {
+                            x = 0.f;
 #pragma unroll
-                        for (int i = 0; i < BD; ++i) x += basis[i] * row[c * BD + i];
-                    } else {
-                        x = row[c];
+                            for (int i = 0; i < BD; ++i) x += basis[i] * row[c * BD + i];
+                        } else {
+                            x = row[c];
+                        }
+                        ex[c] = pexpf<true>(-x);
                     }
-                    ex[c] = pexpf<true>(-x);
-                    total_color += (float)(1.0 / (1.0 + (double)ex[c])) * g[c];
+                    // sweep 2 needs the same attenuation and the same three exponentials: 16 bytes per
+                    // sample instead of gathering the row and forming them again
+                    if constexpr (TERMS == 1) terms[terms_index(blk, lane, k)] = make_float4(att, ex[0], ex[1], ex[2]);
                 }
-                // sweep 2 needs the same attenuation and the same three exponentials: 16 bytes per
-                // sample, the 64 rays of a list position side by side, instead of gathering the row
-                // and forming them again
-                if constexpr (TERMS)
-                    terms[((blk << 3) + (k & 7)) * 64 + lane] = make_float4(att, ex[0], ex[1], ex[2]);
+                float total_color = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) total_color += (float)(1.0 / (1.0 + (double)ex[c])) * g[c];
                 const int sl = ((rd & 1) * W + wave) * 64 + lane;
                 r_w[sl] = att; r_sg[sl] = total_color;
             }
@@ -1655,8 +1704,8 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
                 const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
                 float att, tc, cf[C];
-                if constexpr (EXACT && TERMS) {
-                    const float4 tv = terms[((blk << 3) + (k & 7)) * 64 + lane];
+                if constexpr (EXACT && TERMS != 0) {
+                    const float4 tv = terms[terms_index(blk, lane, k)];
                     const float ex[C] = {tv.y, tv.z, tv.w};
                     att = tv.x;
                     tc = 0.f;
@@ -2655,6 +2704,10 @@ inline RecLists lists_dev(const svoxt_sample_lists* l, int64_t Q) {
     L.pool_next = reinterpret_cast<int32_t*>(l->pool_next);
     L.pool_blocks = l->blocktab != nullptr ? l->pool_blocks : rec_rays(Q) / 64 * (l->max_samples / kRecBlock);
     L.S = l->max_samples;
+    // 16 bytes per record slot, 16-byte aligned, or not at all
+    const bool have_terms = l->terms != nullptr && ((uintptr_t)l->terms & 15u) == 0 &&
+                            l->terms_bytes >= L.pool_blocks * (int64_t)(64 * kRecBlock * 16);
+    L.terms = have_terms ? reinterpret_cast<float4*>(l->terms) : nullptr;
     return L;
 }
 inline RecLists dense_lists(void* rec, int64_t S, int64_t Q) {
@@ -2664,6 +2717,7 @@ inline RecLists dense_lists(void* rec, int64_t S, int64_t Q) {
     L.pool_next = nullptr;
     L.pool_blocks = rec_rays(Q) / 64 * (S / kRecBlock);
     L.S = (int)S;
+    L.terms = nullptr;
     return L;
 }
 inline int64_t rec_capacity(int64_t bytes, int64_t Q) {       // records per ray that fit: a multiple of 8, at most 4096
@@ -2907,7 +2961,7 @@ bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
 // (K <= 32) on N = 2 trees
 bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
                        const float* grad_out, float* grad, int gstride, RecLists L, const uint4* aux,
-                       const float* fwd_out, float4* coef, bool xf, hipStream_t st, float4* terms = nullptr) {
+                       const float* fwd_out, float4* coef, bool xf, hipStream_t st, int terms_state = 0) {
     if (C != 3) return false;
     const unsigned nb = nblocks(rays.Q);
     // a caller that hands over a coef buffer asks for the two-kernel form; without one (coef_bytes < 0)
@@ -2925,10 +2979,12 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
         if (fwd_out != nullptr && ctr == nullptr)                                                             \
             hipLaunchKernelGGL((grad_fused_kernel<F, BB, false>), dim3(nb), dim3(512), 0, st,                 \
                                tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                 \
-        else if (ctr == nullptr && terms != nullptr)                                                          \
-            hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, true>), dim3(nb), dim3(512), 0, st,     \
-                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride,                  \
-                               (unsigned long long*)nullptr, terms);                                          \
+        else if (ctr == nullptr && L.terms != nullptr && terms_state == 2)                                    \
+            hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 2>), dim3(nb), dim3(512), 0, st,        \
+                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                      \
+        else if (ctr == nullptr && L.terms != nullptr)                                                        \
+            hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 1>), dim3(nb), dim3(512), 0, st,        \
+                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                      \
         else if (ctr == nullptr)                                                                              \
             hipLaunchKernelGGL((grad_fused_kernel<F, BB, true>), dim3(nb), dim3(512), 0, st,                  \
                                tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                 \
@@ -3059,14 +3115,10 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
             const bool have_coef = lists->coef != nullptr &&
                                    lists->coef_bytes >= (int64_t)lists->max_samples * rays->Q * 16;
             if (n2 && tree->K <= 32 && (have_coef || lists->coef_bytes < 0))
-            {
-                // optional scratch of the exact one-kernel form: 16 bytes per list slot
-                const bool have_terms = lists->terms != nullptr && ((uintptr_t)lists->terms & 15u) == 0 &&
-                                        lists->terms_bytes >= ll.pool_blocks * (int64_t)(64 * kRecBlock * 16);
+                // (ll.terms: the exact one-kernel form's hand-over buffer; terms_state 2 = the forward filled it)
                 done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, ll, laux,
                                          fwd_out, have_coef ? reinterpret_cast<float4*>(lists->coef) : nullptr, false, st,
-                                         have_terms ? reinterpret_cast<float4*>(lists->terms) : nullptr);
-            }
+                                         lists->terms_state == 2 ? 2 : 1);
             if (!done) done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, gs, ll, laux, fwd_out, st)
                       : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, gs, ll, laux, fwd_out, st);
             if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no specialised kernel for this payload", fn);
@@ -3243,6 +3295,15 @@ int svoxt_volume_render_fwd_scratch(const svoxt_tree* tree, const svoxt_rays* ra
                                           scratch->max_samples > kMaxRecBlocks * kRecBlock)))
         return fail(SVOXT_ERR_INVALID, "%s: scratch lists are malformed (see svoxt_sample_lists)", fn);
     return fwd_common(tree, rays, opt, out, nullptr, stream, fn, nullptr, 0, flags, scratch);
+}
+
+int svoxt_fwd_fills_terms(const svoxt_tree* tree, const svoxt_options* opt) {
+    if (tree == nullptr || opt == nullptr || !svoxt_can_record(tree, opt)) return 0;
+    if (uses_xform(tree, opt)) return 0;
+    const int C = svoxt_out_data_dim(opt, tree->K) - 1;
+    if (C != 3) return 0;
+    // the two-kernel forward does not form them (its shade kernels would have to write them scattered)
+    return (fwd_split_enabled(tree, opt) && fwd_split_payload(tree, opt, C)) ? 0 : 1;
 }
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt) {
