@@ -273,12 +273,17 @@ def main():
             "rays": 36 * Q, "pixels_written": 4 * (C + 1) * Q,
             "feature_rows_read": 4 * K * touched["rows_valid"], "tree_words_read": tree_bytes,
             "records_written": 8 * A if recording else 0, "aux_written": 16 * Q if recording else 0,
+            # (att, e0, e1, e2) per sample, left by the recording forward for the exact backward
+            "backward_terms_written": 16 * A if (recording and _C.LAST_ROUTE.get("forward_terms")) else 0,
         }
         bwd_parts = None
         if not args.forward_only:
             bwd_parts = {
                 "grad_memset": 4 * M * stride, "upstream_gradient_read": 4 * (C + 1) * Q, "aux_read": 16 * Q,
-                "rays": 36 * cnt[0], "records_read": 8 * A, "feature_rows_read": 4 * K * touched["rows_composited"],
+                "rays": 36 * cnt[0], "records_read": 8 * A,
+                # with the forward's hand-over the backward reads 16 B per sample instead of the feature rows
+                "feature_rows_read": 0 if _C.LAST_ROUTE.get("forward_terms") else 4 * K * touched["rows_composited"],
+                "terms_read": 16 * A if _C.LAST_ROUTE.get("forward_terms") else 0,
                 "atomic_requests_64B": 64 * atomic_requests if atomic_requests else 4 * K * A,
                 "row_compaction": (4 * M * stride + 4 * M * K) if stride != K else 0,
             }

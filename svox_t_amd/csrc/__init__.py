@@ -679,7 +679,7 @@ def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bo
 
 
 # which kernels the last volume_render / volume_render_backward took (for bench.py's labels)
-LAST_ROUTE = {"forward": None, "backward": None}
+LAST_ROUTE = {"forward": None, "backward": None, "forward_terms": False}
 
 
 def _volume_render(tree, rays, opt, record):
@@ -689,6 +689,7 @@ def _volume_render(tree, rays, opt, record):
     env = os.environ.get("SVOXT_FWD_SPLIT", "")
     wide = co.format == FORMAT_RGBA and ct.K in (8, 16, 32)
     split = (env not in ("", "0")) if env != "" else wide
+    LAST_ROUTE["forward_terms"] = False
     LAST_ROUTE["forward"] = (("march_rec_kernel + shade_chan_kernel (two-kernel forward, channels on lanes"
                               + (", float quotient)" if FAST_SIGMOID and not record else ")") if wide else
                               "march_rec_kernel + shade_tile_kernel (two-kernel forward)") if split
@@ -707,6 +708,7 @@ def _volume_render(tree, rays, opt, record):
             _call("svoxt_volume_render_fwd_record", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(out), ctypes.byref(cl), _stream(dev))
             lists.note_usage()
+            LAST_ROUTE["forward_terms"] = lists.terms_state == 2
         elif FWD_LIST_SAMPLES > 0 and cr.Q > 0:
             # scratch for the two-kernel forward (march, then shade per tile; the library falls
             # back to the one-kernel forward for payloads it does not cover)

@@ -780,60 +780,74 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
 template <int K, bool N2, bool FAST>
 __global__ void __launch_bounds__(256)
 tail_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, uint4* __restrict__ aux, float* __restrict__ out) {
+    // One workgroup (four wavefronts) per 64-ray tile; with lists that hold every sample -- the
+    // usual case since they are pooled -- the launch is one look at the tile's 64 aux entries.
     constexpr int RPW = 64 / K;
-    const int lane = threadIdx.x & 63;
+    __shared__ int any_over;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x + rays.tile0;
+    if (wave == 0) {
+        const int64_t q0 = ray_of_thread(rays, tile * 64 + lane);
+        const bool ov = q0 < rays.Q && (aux[q0].x & kRecOverflow) != 0u;
+        const bool a0 = __any(ov);
+        if (lane == 0) any_over = a0 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!any_over) return;
     const int c = lane & (K - 1);
     const int sig_lane = lane | (K - 1);
-    const int64_t t0 = (int64_t)rays.tile0 * 64 + ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + (lane / K);
-    const int64_t q = ray_of_thread(rays, t0);
-    uint4 a = make_uint4(0u, 0u, 0u, 0u);
-    if (q < rays.Q) a = aux[q];
-    bool alive = (a.x & kRecOverflow) != 0u;
-    if (!__any(alive)) return;
-    Ray r;
-    float light = 1.f, acc = 0.f, t = 0.f, tmax = -1.f;
-    bool stopped = false;
-    if (alive) {
-        setup_ray(tr, rays, opt, q, r);
-        t = __uint_as_float(a.y);
-        tmax = r.tmax;
-        light = out[q * K + (K - 1)];
-        if (c < K - 1) acc = out[q * K + c];
-    }
-    while (__any(alive && t < tmax)) {
-        const bool go = alive && t < tmax;
-        float x = 0.f, dt = 0.f;
-        bool valid = false;
-        if (go) {
-            Sample s;
-            march_step<N2>(tr, r, opt.step_size, t, s);
-            dt = s.delta_t;
-            valid = s.valid;
-            if (valid) x = tr.features[(int64_t)s.idx * K + c];
-            t = march_advance(t, s.delta_t);
+    for (int grp = wave; grp < 64 / RPW; grp += 4) {          // RPW rays per wavefront and turn
+        const int64_t t0 = tile * 64 + grp * RPW + (lane / K);
+        const int64_t q = ray_of_thread(rays, t0);
+        uint4 a = make_uint4(0u, 0u, 0u, 0u);
+        if (q < rays.Q) a = aux[q];
+        bool alive = (a.x & kRecOverflow) != 0u;
+        if (!__any(alive)) continue;
+        Ray r;
+        float light = 1.f, acc = 0.f, t = 0.f, tmax = -1.f;
+        bool stopped = false;
+        if (alive) {
+            setup_ray(tr, rays, opt, q, r);
+            t = __uint_as_float(a.y);
+            tmax = r.tmax;
+            light = out[q * K + (K - 1)];
+            if (c < K - 1) acc = out[q * K + c];
         }
-        const float sigma = __shfl(x, sig_lane, 64);
-        const bool active = go && valid && sigma > opt.sigma_thresh;
-        float ex = 1.f;
-        if (active) ex = pexpf(c == K - 1 ? -dt * r.delta_scale * x : -x);
-        const float att = __shfl(ex, sig_lane, 64);
-        if (active) {
-            const float weight = light * (1.f - att);
-            if constexpr (FAST) acc += weight * __builtin_amdgcn_rcpf(1.f + ex);
-            else acc = (float)((double)acc + (double)weight / (1.0 + (double)ex));
-            light *= att;
-            if (light <= opt.stop_thresh) { stopped = true; alive = false; }
+        while (__any(alive && t < tmax)) {
+            const bool go = alive && t < tmax;
+            float x = 0.f, dt = 0.f;
+            bool valid = false;
+            if (go) {
+                Sample s;
+                march_step<N2>(tr, r, opt.step_size, t, s);
+                dt = s.delta_t;
+                valid = s.valid;
+                if (valid) x = tr.features[(int64_t)s.idx * K + c];
+                t = march_advance(t, s.delta_t);
+            }
+            const float sigma = __shfl(x, sig_lane, 64);
+            const bool active = go && valid && sigma > opt.sigma_thresh;
+            float ex = 1.f;
+            if (active) ex = pexpf(c == K - 1 ? -dt * r.delta_scale * x : -x);
+            const float att = __shfl(ex, sig_lane, 64);
+            if (active) {
+                const float weight = light * (1.f - att);
+                if constexpr (FAST) acc += weight * __builtin_amdgcn_rcpf(1.f + ex);
+                else acc = (float)((double)acc + (double)weight / (1.0 + (double)ex));
+                light *= att;
+                if (light <= opt.stop_thresh) { stopped = true; alive = false; }
+            }
         }
+        if ((a.x & kRecOverflow) == 0u) continue;
+        float v;
+        if (c < K - 1) {
+            v = stopped ? acc * (float)(1.0 / (1.0 - (double)light)) : acc + light * opt.background_brightness;
+        } else {
+            v = 1.f - light;
+            aux[q].z = __float_as_uint(light);
+        }
+        out[q * K + c] = v;
     }
-    if ((a.x & kRecOverflow) == 0u) return;
-    float v;
-    if (c < K - 1) {
-        v = stopped ? acc * (float)(1.0 / (1.0 - (double)light)) : acc + light * opt.background_brightness;
-    } else {
-        v = 1.f - light;
-        aux[q].z = __float_as_uint(light);
-    }
-    out[q * K + c] = v;
 }
 
 // ---------------------------------------------------------------------------
@@ -2854,9 +2868,9 @@ bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float
                                          tr, rays, opt, L, aux, out);                                    \
             else hipLaunchKernelGGL((shade_chan_kernel<KK, STOP, false>), dim3(nbc), dim3(256), 0, st,        \
                                     tr, rays, opt, L, aux, out);                                         \
-            if (fast) hipLaunchKernelGGL((tail_chan_kernel<KK, N2, true>), dim3(nbc), dim3(256), 0, st,       \
+            if (fast) hipLaunchKernelGGL((tail_chan_kernel<KK, N2, true>), dim3(nb), dim3(256), 0, st,        \
                                          tr, rays, opt, aux, out);                                            \
-            else hipLaunchKernelGGL((tail_chan_kernel<KK, N2, false>), dim3(nbc), dim3(256), 0, st,           \
+            else hipLaunchKernelGGL((tail_chan_kernel<KK, N2, false>), dim3(nb), dim3(256), 0, st,            \
                                     tr, rays, opt, aux, out);                                                 \
             return true;                                                                                      \
         }
