@@ -223,7 +223,8 @@ typedef struct svoxt_sample_lists {
                               (att, e_0, e_1, e_2) of every 3-channel sample as the exact backward (fwd_out NULL,
                               the ONE-kernel form) needs them.  Given to svoxt_volume_render_fwd_record, the
                               one-kernel forward fills it (svoxt_fwd_fills_terms says whether it will); the
-                              backward, told so by terms_state = 2, then gathers no feature row and forms no
+                              backward, told so by terms_state = 2 or 3 (what svoxt_fwd_fills_terms returned:
+                              the layout the forward wrote), then gathers no feature row and forms no
                               exponential in either of its sweeps.  terms_state = 0: scratch only -- the
                               backward's first sweep fills it for the second.  Same bits every way. */
     int64_t terms_bytes;
@@ -245,7 +246,8 @@ typedef struct svoxt_sample_lists {
 } svoxt_sample_lists;
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt);
-/* 1 if svoxt_volume_render_fwd_record, given lists with `terms`, fills them for this tree / options */
+/* What svoxt_volume_render_fwd_record does with lists that carry `terms` for this tree / options: 0 = nothing,
+ * 2 / 3 = fills them (in the layout of that number: pass it back as terms_state to the backward) */
 int svoxt_fwd_fills_terms(const svoxt_tree* tree, const svoxt_options* opt);
 int svoxt_volume_render_fwd_record(const svoxt_tree* tree, const svoxt_rays* rays,
                                    const svoxt_options* opt, float* out,

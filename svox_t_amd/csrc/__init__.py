@@ -699,16 +699,19 @@ def _volume_render(tree, rays, opt, record):
         if record and BWD_LIST_SAMPLES > 0 and cr.Q > 0 and \
                 _lib.svoxt_can_record(ctypes.byref(ct), ctypes.byref(co)):
             lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
-            if BWD_EXACT and BWD_TERMS and BWD_FUSED and BWD_GATHER and \
-                    _lib.svoxt_fwd_fills_terms(ctypes.byref(ct), ctypes.byref(co)):
+            fills = _lib.svoxt_fwd_fills_terms(ctypes.byref(ct), ctypes.byref(co)) \
+                if (BWD_EXACT and BWD_TERMS and BWD_FUSED and BWD_GATHER) else 0
+            if fills:
                 # the exact per-tile backward will want (att, e0, e1, e2) of every sample: this forward has them
                 lists.terms = torch.empty((lists.pool_blocks * 512 * 4,), dtype=torch.float32, device=dev)
-                lists.terms_state = 2
+                lists.terms_state = fills
             cl = lists.c_struct()
             _call("svoxt_volume_render_fwd_record", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(out), ctypes.byref(cl), _stream(dev))
             lists.note_usage()
-            LAST_ROUTE["forward_terms"] = lists.terms_state == 2
+            LAST_ROUTE["forward_terms"] = lists.terms_state in (2, 3)
+            if lists.terms_state == 3 and os.environ.get("SVOXT_FWD_SPLIT", "") == "":
+                LAST_ROUTE["forward"] = "march_rec_kernel + shade_tile_kernel (two-kernel forward), recording sample lists"
         elif FWD_LIST_SAMPLES > 0 and cr.Q > 0:
             # scratch for the two-kernel forward (march, then shade per tile; the library falls
             # back to the one-kernel forward for payloads it does not cover)
@@ -804,6 +807,15 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
                 # sweep 1 -> sweep 2 hand-over: 16 bytes per list slot (when the forward did not leave them)
                 lists.terms = torch.empty((lists.pool_blocks * 512 * 4,), dtype=torch.float32, device=dev)
                 lists.terms_state = 0
+            wide = co.format == FORMAT_RGBA and grad_output.shape[1] in (8, 16, 32) and K == grad_output.shape[1]
+            # ... per tile (grad_wide_kernel) for coherent batches on N = 2 trees, else per ray (render_bwd_kernel<ONEPASS>)
+            wide_tile = wide and fo is None and BWD_TERMS and BWD_FUSED and ct.N == 2 and ct.xform is None and \
+                (BWD_GATHER == 2 or (BWD_GATHER == 1 and coherent))
+            if wide and fo is None and BWD_TERMS and not gather:
+                # one sigmoid pass instead of two: the first sweep leaves a float per list slot for the second
+                if lists.terms is None or lists.terms.numel() < lists.pool_blocks * 512:
+                    lists.terms = torch.empty((lists.pool_blocks * 512,), dtype=torch.float32, device=dev)
+                lists.terms_state = 0
             if gather and not fused:
                 # with view rotations a second plane holds each sample's rotated direction
                 planes = 2 if ct.xform is not None else 1
@@ -814,8 +826,12 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
                 ("grad_fused_kernel<EXACT> (two sweeps over the lists + per-tile merge)" if fo is None else
                  "grad_fused_kernel (one sweep over the lists + per-tile merge; accum from the forward's output)") if fused else
                 "render_bwd_kernel<GATHER> + grad_merge_kernel (list walk, then per-tile merge)" if gather else
+                "grad_wide_kernel (two sweeps over the lists, sigmoids per record once + once per distinct row; per-tile merge)"
+                if wide_tile else
+                "render_bwd_kernel<ONEPASS> (two list walks, sigmoids formed once; one atomic row + one sigma atomic per sample)"
+                if (wide and fo is None and BWD_TERMS) else
                 "render_bwd_kernel<REPLAY> (list walk, one atomic row per sample)")
-            if fused:
+            if fused or wide_tile:
                 cl.coef_bytes = -1            # list walk and merge as one kernel: no buffer, rec stays as recorded
             _call("svoxt_volume_render_bwd_replay", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(grad_output), grad_output.shape[1], _ptr(buf), stride, ctypes.byref(cl), _ptr(fo),

@@ -110,6 +110,11 @@ struct RecLists {
 __device__ __forceinline__ int64_t terms_index(int64_t block, int lane, int k) {
     return ((((block << 1) + ((k >> 2) & 1)) << 6) + lane) * 4 + (k & 3);
 }
+// ... or position-major, [block][k % 8][lane]: what kernels that hold one list position of the 64 rays
+// of a tile per wavefront write and read as 1 KB at a time (shade_tile_kernel, grad_fused_kernel)
+__device__ __forceinline__ int64_t terms_index_pm(int64_t block, int lane, int k) {
+    return ((block << 3) + (k & 7)) * 64 + lane;
+}
 
 __device__ __forceinline__ int64_t rec_block(const RecLists& L, int64_t tile, int b) {
     const int64_t e = tile * (int64_t)(L.S >> 3) + b;
@@ -565,7 +570,10 @@ march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
     aux[q] = make_uint4((uint32_t)nrec | over, __float_as_uint(t_resume), __float_as_uint(1.f), 0u);
 }
 
-template <int FMT, int BD, bool XF, bool STOP>
+// WTERMS (recording forwards, no view rotations): the wavefronts that form a sample's exponentials also
+// leave them, with the attenuation in the backward's association (rt_kernel.cu:397), in L.terms
+// (position-major: 1 KB per wavefront and list position) for the exact backward.
+template <int FMT, int BD, bool XF, bool STOP, bool WTERMS = false>
 __global__ void __launch_bounds__(512)
 shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
                   uint4* __restrict__ aux, float* __restrict__ out) {
@@ -606,7 +614,8 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
         if (wave > 0) {
             const int k = rd * P + (wave - 1);
             if (rd < nround && k < nrec) {
-                const uint2 e = rec_get(L.rec + rec_index_in(rec_block_u(L, tabreg, tile, k >> 3), lane, k));
+                const int64_t blk = rec_block_u(L, tabreg, tile, k >> 3);
+                const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
                 const int32_t idx = (int32_t)e.x;
                 float row[K];
                 load_row<K>(tr.features + (int64_t)idx * K, row);
@@ -627,6 +636,12 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
                     tv.y = pexpf(-row[0]); tv.z = pexpf(-row[1]); tv.w = pexpf(-row[2]);
                 }
                 terms[rd & 1][wave - 1][lane] = tv;
+                if constexpr (WTERMS) {
+                    typedef float v4g __attribute__((ext_vector_type(4)));
+                    const float att_b = pexpf(-__uint_as_float(e.y) * row[K - 1] * delta_scale);
+                    __builtin_nontemporal_store(v4g{att_b, tv.y, tv.z, tv.w},
+                                                reinterpret_cast<v4g*>(L.terms + terms_index_pm(blk, lane, k)));
+                }
             }
         } else if (rd > 0) {
             const int kb = (rd - 1) * P;
@@ -955,6 +970,32 @@ __device__ __forceinline__ void accum_sample(const float (&row)[K], const float*
     accum += weight * total_color;
 }
 
+// ONEPASS (RGBA-style rows, lists): everything of a listed sample that needs its sigmoids, formed
+// ONCE -- the colour entries the reference scatters in its first pass (rt_kernel.cu:419-425), that
+// pass's total_color (float sigmoids, :424) and the second pass's (double quotients, :470) --
+// instead of once per pass: with 31 channels the two passes are 62 double-precision quotients and
+// exponentials per sample and bound the kernel (r02: 3.4 ms at 1024 x 1024, depth 9).
+template <int C, int K>
+__device__ __forceinline__ void stage_colour(const float (&row)[K], const float* g, float delta_t,
+                                             float delta_scale, float& light, float& accum,
+                                             float* __restrict__ st, float& total2) {
+    const float att = pexpf(-delta_t * row[K - 1] * delta_scale);
+    const float weight = light * (1.f - att);
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const double sd = sigmoid_d(row[j]);
+        const float sig = (float)sd;
+        st[j] = weight * sig * (1.f - sig) * g[j];
+        t1 += sig * g[j];
+        t2 = (float)((double)t2 + sd * (double)g[j]);
+    }
+    st[K - 1] = 0.f;               // the sigma entry follows in the second sweep, when accum is complete
+    light *= att;
+    accum += weight * t1;
+    total2 = t2;
+}
+
 // A sample's contribution in factored form, for the two-kernel backward: the colour
 // entry (c, i) is ((weight * basis_i) * coef_c) * g_c with coef_c = sigmoid'(.) for SH,
 // or coef_c itself for RGBA; `sg` is the sigma entry.  Same operations as stage_sample.
@@ -1052,13 +1093,21 @@ __device__ __forceinline__ void sample_advance(float att, float total_color, flo
 // here; their factored contributions overwrite the list -- rec[k][q] = (row, sigma
 // entry), coef[k][q] = (weight, c0, c1, c2) -- and grad_merge_kernel adds them up per
 // 8x8 tile.  Samples past the list (overflowed rays) still go out as shaped atomics.
-template <int FMT, int C, int BD, bool N2, bool REPLAY, bool XF = false, bool GATHER = false>
-__global__ void __launch_bounds__(kBlock, (GATHER && !XF) ? 4 : 1)
+// ONEPASS (RGBA-style rows, lists, L.terms = one float per list slot): see stage_colour.  Sweep 1
+// walks the lists wave-synchronously and sends the colour entries out as shaped atomic rows; it
+// leaves the second pass's total_color of every listed sample in L.terms (position-major, 256
+// contiguous bytes per wavefront and list position).  Sweep 2 is scalar work per listed sample --
+// sigma gather, attenuation, accum -= weight * total_color -- and one atomic on the sigma column.
+// Per-contribution values are the reference's; only where the additions happen differs.
+template <int FMT, int C, int BD, bool N2, bool REPLAY, bool XF = false, bool GATHER = false, bool ONEPASS = false>
+__global__ void __launch_bounds__(kBlock, (GATHER && !XF && C == 3) ? 4 : 1)
 render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                   float* __restrict__ grad, int gstride, RecLists L,
                   const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
                   float4* __restrict__ coef_out = nullptr) {
-    static_assert(!GATHER || (REPLAY && C == 3), "two-kernel backward: lists, 3 channels");
+    // (C > 3: only as the tail-only launch, coef_out == NULL, in front of grad_wide_kernel)
+    static_assert(!GATHER || (REPLAY && (C == 3 || FMT == FMT_RGBA)), "per-tile backward: lists; 3 channels or RGBA-style rows");
+    static_assert(!ONEPASS || (REPLAY && FMT == FMT_RGBA && !XF && !GATHER), "one sigmoid pass: RGBA-style rows, lists");
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     constexpr int KS = K | 1;                         // odd LDS row stride: conflict-free column writes
     __shared__ float stage_all[(kBlock / 64) * 64 * KS];
@@ -1105,6 +1154,33 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 
     float accum = 0.f;
     float light_ray = 1.f;
+    float light1 = 1.f;           // ONEPASS: the transmittance behind the listed samples
+    float* __restrict__ tot2 = reinterpret_cast<float*>(L.terms);
+    // a record's slot in the position-major hand-over, from its place in rec[block][lane][k % 8]
+    auto pm_of = [](int64_t ri) { return ((ri >> 9) << 9) + ((ri & 7) << 6) + ((ri >> 3) & 63); };
+    if constexpr (ONEPASS) {      // sweep 1 over the lists, all lanes of the wavefront in step
+        int n1 = 0;
+        if (alive) n1 = (int)(aux[q].x & ~kRecOverflow);
+        int maxn = n1;
+        for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
+        maxn = __builtin_amdgcn_readfirstlane(maxn);
+        for (int k1 = 0; k1 < maxn; ++k1) {
+            const bool active = k1 < n1;
+            const unsigned long long amask = __ballot(active);
+            if (active) {
+                const int64_t ri = rec_index(L, tid, k1);
+                const uint2 e = rec_get(rec + ri);
+                float row[K];
+                load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
+                const int slot = __popcll(amask & lane_lt);
+                sidx[slot] = (int32_t)e.x;
+                float t2;
+                stage_colour<C, K>(row, g, __uint_as_float(e.y), r.delta_scale, light1, accum, stage + slot * KS, t2);
+                tot2[pm_of(ri)] = t2;
+            }
+            flush_staged<K, KS>(stage, sidx, __popcll(amask), lane, grad, gstride);
+        }
+    }
     int nrec = 0;                 // samples recorded for this ray
     float t_resume = 0.f;         // where pass 2 resumes marching
     float tmax2 = -1.f;           // ... and until where (-1: nothing left to march)
@@ -1138,6 +1214,8 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 if constexpr (XF) {
                     if (nrec > 0) last_idx = (int32_t)rec_get(rec + rec_index(L, tid, nrec - 1)).x;
                 }
+            } else if constexpr (ONEPASS) {
+                light = light1;                  // the lists were walked above; a tail marches on from here
             } else {
                 for (int k = 0; k < nrec; ++k) {
                     const uint2 e = rec_get(rec + rec_index(L, tid, k));
@@ -1243,6 +1321,27 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                     __builtin_nontemporal_store(v4f{w, cf[0], cf[1], cf[2]},
                                                 reinterpret_cast<v4f*>(coef_out + ((int64_t)k * rays.Q + q)));
                 }
+            }
+        }
+        k = nrec;
+    }
+    if constexpr (ONEPASS) {
+        // sweep 2 over the lists: the sigma entries (rt_kernel.cu:456-490), no sigmoid formed again
+        if (alive) {
+            for (; k < nrec; ++k) {
+                const int64_t ri = rec_index(L, tid, k);
+                const uint2 e = rec_get(rec + ri);
+                const int32_t idx = (int32_t)e.x;
+                const float delta_t = __uint_as_float(e.y);
+                const float sigma = tr.features[(int64_t)idx * K + (K - 1)];
+                const float att = pexpf(-delta_t * sigma * r.delta_scale);
+                const float weight = light * (1.f - att);
+                const float total_color = tot2[pm_of(ri)];
+                light *= att;
+                accum -= weight * total_color;
+                const float sg = delta_t * r.delta_scale * (total_color * light - accum)
+                               + delta_t * r.delta_scale * g[C] * light_ray;
+                atomicAdd(grad + (int64_t)idx * gstride + (K - 1), sg);
             }
         }
         k = nrec;
@@ -1566,8 +1665,9 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
 // COUNT (instrumentation, svoxt_set_bwd_counters): counters[0] += 64-byte atomic requests sent,
 // counters[1] += (tile, pass, feature row) groups; the work itself is unchanged.
 // TERMS (EXACT only): 1 = sweep 1 hands (att, e_0, e_1, e_2) of every sample to sweep 2 through
-// L.terms; 2 = the recording forward left them there (render_fwd_kernel): neither sweep gathers a
-// feature row or forms an exponential.
+// L.terms (position-major); 2 / 3 = the recording forward left them there (render_fwd_kernel:
+// lane-major lines; shade_tile_kernel: position-major): neither sweep gathers a feature row or forms
+// an exponential.
 // Two workgroups per CU (77 KB of LDS each) need at most 128 registers: said to the compiler,
 // because one branch too many costs exactly that (r02: 116 -> 130 registers, 0.38 -> 0.55 ms).
 template <int FMT, int BD, bool EXACT, bool COUNT = false, int TERMS = 0>
@@ -1647,8 +1747,8 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             if (rd < nr1 && k < nrec) {
                 const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
                 float att, ex[C];                             // exp(-x_c): sigmoid_d(x) = 1.0 / (1.0 + double(exp(-x)))
-                if constexpr (TERMS == 2) {
-                    const float4 tv = terms[terms_index(blk, lane, k)];
+                if constexpr (TERMS >= 2) {
+                    const float4 tv = terms[TERMS == 2 ? terms_index(blk, lane, k) : terms_index_pm(blk, lane, k)];
                     att = tv.x; ex[0] = tv.y; ex[1] = tv.z; ex[2] = tv.w;
                 } else {
                     const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
@@ -1669,7 +1769,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                     }
                     // sweep 2 needs the same attenuation and the same three exponentials: 16 bytes per
                     // sample instead of gathering the row and forming them again
-                    if constexpr (TERMS == 1) terms[terms_index(blk, lane, k)] = make_float4(att, ex[0], ex[1], ex[2]);
+                    if constexpr (TERMS == 1) terms[terms_index_pm(blk, lane, k)] = make_float4(att, ex[0], ex[1], ex[2]);
                 }
                 float total_color = 0.f;
 #pragma unroll
@@ -1719,7 +1819,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
                 float att, tc, cf[C];
                 if constexpr (EXACT && TERMS != 0) {
-                    const float4 tv = terms[terms_index(blk, lane, k)];
+                    const float4 tv = terms[TERMS == 2 ? terms_index(blk, lane, k) : terms_index_pm(blk, lane, k)];
                     const float ex[C] = {tv.y, tv.z, tv.w};
                     att = tv.x;
                     tc = 0.f;
@@ -1879,6 +1979,351 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             }
         }
         if (k0 + RPP * W >= maxn) break;                 // last pass (scalar condition)
+        __syncthreads();
+        for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
+        for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
+        __syncthreads();
+    }
+}
+
+// The backward of an image for RGBA-style rows of 8 / 16 / 32 floats (C = K - 1 = 7 / 15 / 31
+// channels), exact, per 64-ray tile like grad_fused_kernel -- but a lane cannot keep 31 channels
+// of a ray (render_bwd_kernel<RGBA, 31>: 238 registers, 1.2 wavefronts per SIMD in flight, 3 ms
+// at 1024 x 1024 on a depth-9 tree, VALU 27 % busy: r02 PMC), and 40 M atomic requests (a row
+// per sample) are 2 ms at the memory side's 22 G requests/s whatever the kernel does.  Here:
+//   sweep 1  (rt_kernel.cu:365-437 without its atomics) per window of 16 list positions: the
+//            records are compacted; lane = RECORD forms the C sigmoids of its row ONCE -- every
+//            lane busy, the row as K / 4 loads, upstream gradients from LDS -- and from them both
+//            total_colors the reference forms (float sigmoids :424, double quotients :470);
+//            wavefront 0 then runs along the rays (weight, transmittance, accum).  The second
+//            pass's total_color goes to L.terms, one float per record (position-major).
+//   sweep 2  (:439-494 + the colour entries :419-425) per window: lane = ray forms the attenuation
+//            again (sigma gather) and enters the record's feature row in a hash table; wavefront
+//            0 runs along the rays (accum -= weight * total_color; sigma entries); counting sort
+//            by feature row; then lane = COLUMN: a group of K lanes takes one distinct row, forms
+//            the sigmoid of its column once per (tile, window, row), adds up the row's records
+//            -- ((weight * sig) * (1 - sig)) * g_c of the record's ray, the reference's order --
+//            and sends ONE atomic row: sigmoid work and requests divided by the reuse (2.0-2.6x
+//            at 1024 x 1024 / depth 9, exp/reuse_probe.py).
+// Rays whose list overflowed: a tail-only launch of render_bwd_kernel<..., GATHER> in front
+// (aux.z / .w carry its pass-1 results), as for grad_fused_kernel<EXACT>.
+template <int K>
+__global__ void __launch_bounds__(512, 6)
+grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
+                 RecLists L, const uint4* __restrict__ aux, float* __restrict__ grad, int gstride) {
+    static_assert(K == 8 || K == 16 || K == 32, "row widths with an instance");
+    constexpr int C = K - 1, W = 8, NT = 64 * W, T = 1024, R = 1024, RPP = R / (64 * W);
+    constexpr int KG = K | 1;                                // odd stride: conflict-free gradient rows
+    constexpr int SPW = 64 / K;                              // distinct rows a wavefront reduces at a time
+    static_assert(RPP == 2, "sizes");
+    __shared__ int32_t keys[T];
+    __shared__ int32_t cnt[T];
+    __shared__ uint16_t order[R];                // sweep 1: the window's records, compacted; sweep 2: sorted by row
+    __shared__ uint16_t slots[T];                // sweep 2: the occupied table entries
+    __shared__ uint32_t r_sl[R];                 // sweep 1: feature row; sweep 2: table entry << 6 | lane, ~0: no record
+    __shared__ float r_w[R], r_sg[R], r_t1[R], r_dt[R];   // (sweep 2: r_t1 / r_dt hold weight / sigma entry in sorted order)
+    __shared__ uint8_t s_ray[R];                 // sweep 2: the ray of the sorted record
+    __shared__ float gl[64 * KG];
+    __shared__ float dsl[64];
+    __shared__ int32_t s_nb, s_ns;
+    float* __restrict__ tot2 = reinterpret_cast<float*>(L.terms);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t tabreg = rec_tab_reg(L, blockIdx.x, lane);
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * 64 + lane);
+    uint4 a = make_uint4(0u, 0u, 0u, 0u);
+    if (q < rays.Q) a = aux[q];
+    const int nrec = (int)(a.x & ~kRecOverflow);
+    int maxn = nrec;
+    for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
+    maxn = __builtin_amdgcn_readfirstlane(maxn);             // everything that decides barriers is scalar
+    if (maxn == 0) return;                                   // the same in every wavefront of the workgroup
+
+    float ds = 0.f, g_sig = 0.f;
+    if (nrec > 0) {
+        Ray r;
+        setup_ray(tr, rays, opt, q, r);                      // for delta_scale (a ray with samples hits the cube)
+        ds = r.delta_scale;
+        g_sig = grad_out[q * K + C];
+    }
+    if (wave == 0) {
+        dsl[lane] = ds;
+#pragma unroll 1
+        for (int j = 0; j < C; ++j) gl[lane * KG + j] = nrec > 0 ? grad_out[q * K + j] : 0.f;
+    }
+    if (threadIdx.x == 0) { s_nb = 0; s_ns = 0; }
+    __syncthreads();
+
+    // ---- sweep 1
+    float light1 = 1.f, accum = 0.f, light_ray = 1.f;
+    for (int k0 = 0; k0 < maxn; k0 += RPP * W) {
+        // records of the window, compacted in (position, lane) order within a wavefront's round
+        {
+            uint2 e[RPP];
+            bool have[RPP];
+#pragma unroll
+            for (int rd = 0; rd < RPP; ++rd) {
+                const int k = k0 + rd * W + wave;
+                have[rd] = k < nrec;
+                e[rd] = make_uint2(0u, 0u);
+                if (have[rd]) e[rd] = rec_get(L.rec + rec_index_in(rec_block_u(L, tabreg, blockIdx.x, k >> 3), lane, k));
+            }
+#pragma unroll
+            for (int rd = 0; rd < RPP; ++rd) {
+                const unsigned long long m = __ballot(have[rd]);
+                if (m != 0ull) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_nb, __popcll(m));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (have[rd]) {
+                        const int slot = (rd * W + wave) * 64 + lane;
+                        r_sl[slot] = e[rd].x;
+                        r_dt[slot] = __uint_as_float(e[rd].y);
+                        order[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)slot;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int nb1 = __builtin_amdgcn_readfirstlane(s_nb);
+        // G = K / 8 neighbouring lanes per record, 8 row columns each: four times the busy lanes and a
+        // quarter of the dependent work per lane (a window holds a few hundred records for 512 lanes);
+        // the sums over the channels run in the reference's order, handed from lane to lane
+        constexpr int G = K / 8;
+        const int gq = threadIdx.x & (G - 1);
+        for (int p0 = wave * (64 / G); p0 < nb1; p0 += NT / G) {      // (scalar bounds: every lane takes part in the shuffles)
+            const int p = p0 + (lane / G);
+            const bool on = p < nb1;
+            const int slot = on ? (int)order[p] : 0;
+            const int ray = slot & 63;
+            float row[8];
+            float a1[8];
+            double a2[8];
+            if (on) {
+                load_row<8>(tr.features + (int64_t)(int32_t)r_sl[slot] * K + 8 * gq, row);
+                const float* __restrict__ gr = gl + ray * KG + 8 * gq;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (8 * gq + j < C) {                      // (the last lane's eighth column is sigma)
+                        const double sd = sigmoid_d<true>(row[j]);
+                        const float gj = gr[j];
+                        a1[j] = (float)sd * gj;
+                        a2[j] = sd * (double)gj;
+                    } else {
+                        a1[j] = 0.f; a2[j] = 0.0;
+                    }
+                }
+            }
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < G; ++rr) {
+                float c1 = 0.f, c2 = 0.f;
+                if (rr > 0) { c1 = __shfl_up(t1, 1, 64); c2 = __shfl_up(t2, 1, 64); }
+                if (on && gq == rr) {
+                    t1 = c1; t2 = c2;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (rr * 8 + j < C) {
+                            t1 += a1[j];
+                            t2 = (float)((double)t2 + a2[j]);
+                        }
+                    }
+                }
+            }
+            if (on && gq == G - 1) {
+                r_w[slot] = pexpf<true>(-r_dt[slot] * row[7] * dsl[ray]);
+                r_t1[slot] = t1;
+                r_sg[slot] = t2;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_nb = 0;
+        // along the rays (wavefront 0); everybody: the hand-over, 256 contiguous bytes per position
+#pragma unroll 1
+        for (int rd = 0; rd < RPP; ++rd) {
+            const int k = k0 + rd * W + wave;
+            if (k < nrec) {
+                const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
+                tot2[terms_index_pm(blk, lane, k)] = r_sg[(rd * W + wave) * 64 + lane];
+            }
+        }
+        if (wave == 0) {
+            // (the operands of eight positions at a time first: the dependent part is then two multiplies and an add per step)
+#pragma unroll
+            for (int j0 = 0; j0 < RPP * W; j0 += 8) {
+                float av[8], tv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { av[j] = r_w[(j0 + j) * 64 + lane]; tv[j] = r_t1[(j0 + j) * 64 + lane]; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (k0 + j0 + j < nrec) {
+                        const float weight = light1 * (1.f - av[j]);
+                        light1 *= av[j];
+                        accum += weight * tv[j];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        if (a.x & kRecOverflow) {                            // list + tail: from the tail-only launch in front
+            light_ray = __uint_as_float(a.z);
+            accum = __uint_as_float(a.w);
+        } else {
+            float total_grad = 0.f;
+#pragma unroll 1
+            for (int j = 0; j < C; ++j) total_grad += gl[lane * KG + j];
+            accum += light1 * opt.background_brightness * total_grad;
+            light_ray = light1;
+        }
+    }
+
+    // ---- sweep 2
+    float light = 1.f;
+    for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
+    for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
+    __syncthreads();
+    for (int k0 = 0; k0 < maxn; k0 += RPP * W) {
+        {   // the window's two rounds together: records and hand-over first, then the sigma gathers, then the table
+            uint2 e[RPP];
+            float t2[RPP], sigma[RPP];
+            bool have[RPP];
+#pragma unroll
+            for (int rd = 0; rd < RPP; ++rd) {
+                const int k = k0 + rd * W + wave;
+                have[rd] = k < nrec;
+                e[rd] = make_uint2(0u, 0u);
+                t2[rd] = 0.f;
+                if (have[rd]) {
+                    const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
+                    e[rd] = rec_get(L.rec + rec_index_in(blk, lane, k));
+                    t2[rd] = tot2[terms_index_pm(blk, lane, k)];
+                }
+            }
+#pragma unroll
+            for (int rd = 0; rd < RPP; ++rd) {
+                sigma[rd] = 0.f;
+                if (have[rd]) sigma[rd] = tr.features[(int64_t)(int32_t)e[rd].x * K + (K - 1)];
+            }
+#pragma unroll
+            for (int rd = 0; rd < RPP; ++rd) {
+                if (have[rd]) {
+                    const int32_t idx = (int32_t)e[rd].x;
+                    uint32_t h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
+                    while (true) {
+                        const int32_t old = atomicCAS(keys + h, -1, idx);
+                        if (old == -1 || old == idx) break;
+                        h = (h + 1u) & (uint32_t)(T - 1);
+                    }
+                    atomicAdd(cnt + h, 1);
+                    const int slot = (rd * W + wave) * 64 + lane;
+                    r_sl[slot] = (h << 6) | (uint32_t)lane;
+                    r_w[slot] = pexpf<true>(-__uint_as_float(e[rd].y) * sigma[rd] * ds);
+                    r_sg[slot] = t2[rd];
+                    r_dt[slot] = __uint_as_float(e[rd].y);
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {                                     // along the rays: (att, total_color) -> (weight, sigma entry)
+#pragma unroll
+            for (int j0 = 0; j0 < RPP * W; j0 += 8) {        // eight positions' operands at a time
+                float av[8], tv[8], dv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int s2 = (j0 + j) * 64 + lane;
+                    av[j] = r_w[s2]; tv[j] = r_sg[s2]; dv[j] = r_dt[s2];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (k0 + j0 + j < nrec) {
+                        const int s2 = (j0 + j) * 64 + lane;
+                        const float weight = light * (1.f - av[j]);
+                        light *= av[j];
+                        accum -= weight * tv[j];
+                        r_w[s2] = weight;
+                        r_sg[s2] = dv[j] * ds * (tv[j] * light - accum) + dv[j] * ds * g_sig * light_ray;
+                    }
+                }
+            }
+        } else if (wave == 1) {                              // meanwhile: where each row's records go, and which entries are in use
+            constexpr int PER = T / 64;
+            int mine[PER], sum = 0, used = 0;
+#pragma unroll
+            for (int j2 = 0; j2 < PER; ++j2) { mine[j2] = cnt[lane * PER + j2]; sum += mine[j2]; used += mine[j2] > 0 ? 1 : 0; }
+            int incl = sum, uincl = used;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off, 64);
+                const int u = __shfl_up(uincl, off, 64);
+                if (lane >= off) { incl += v; uincl += u; }
+            }
+            int run = incl - sum, urun = uincl - used;
+#pragma unroll
+            for (int j2 = 0; j2 < PER; ++j2) {
+                cnt[lane * PER + j2] = run;
+                run += mine[j2];
+                if (mine[j2] > 0) slots[urun++] = (uint16_t)(lane * PER + j2);
+            }
+            if (lane == 63) { s_nb = incl; s_ns = uincl; }
+        }
+        __syncthreads();
+        for (int rr = threadIdx.x; rr < R; rr += NT) {
+            const uint32_t v = r_sl[rr];
+            if (v != 0xffffffffu) {
+                const int pos = atomicAdd(cnt + (v >> 6), 1);
+                r_t1[pos] = r_w[rr];                         // (r_dt was consumed by the chain above)
+                r_dt[pos] = r_sg[rr];
+                s_ray[pos] = (uint8_t)(v & 63u);
+            }
+        }
+        __syncthreads();
+        // ---- reduce: lane = column; after the scatter cnt[h] is where the records of entry h END
+        const int ns = __builtin_amdgcn_readfirstlane(s_ns);
+        const int col = lane & (K - 1), sub = lane / K;
+        constexpr int D = 4;                                 // rows in flight per lane: a row gather is ~1 us, its use ~0.3 us
+        for (int i0 = wave * SPW; i0 < ns; i0 += D * W * SPW) {
+            int32_t idxs[D];
+            int ps[D], pes[D];
+            float xs[D];
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int i = i0 + u * W * SPW + sub;
+                idxs[u] = -1; ps[u] = 0; pes[u] = 0; xs[u] = 0.f;
+                if (i < ns) {
+                    const int h = (int)slots[i];
+                    idxs[u] = keys[h];
+                    pes[u] = cnt[h];
+                    // the entry's records start where the previous occupied entry's end (table order = sorted order)
+                    if (i > 0) ps[u] = cnt[(int)slots[i - 1]];
+                    xs[u] = tr.features[(int64_t)idxs[u] * K + col];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                if (i0 + u * W * SPW >= ns) break;           // (scalar)
+                const int32_t idx = idxs[u];
+                const int p = ps[u];
+                float sig = 0.f, om = 0.f;
+                if (idx >= 0 && col < C) {
+                    sig = (float)sigmoid_d<true>(xs[u]);
+                    om = 1.f - sig;
+                }
+                float acc = 0.f;
+                int n_here = pes[u] - p, n_max = n_here;
+                for (int off = 32; off >= K; off >>= 1) n_max = max(n_max, __shfl_xor(n_max, off, 64));
+                n_max = __builtin_amdgcn_readfirstlane(n_max);
+                for (int t = 0; t < n_max; ++t) {
+                    if (t < n_here) {
+                        float val;
+                        if (col == C) val = r_dt[p + t];
+                        else val = r_t1[p + t] * sig * om * gl[(int)s_ray[p + t] * KG + col];
+                        acc += val;
+                    }
+                }
+                if (idx >= 0) atomicAdd(grad + (int64_t)idx * gstride + col, acc);
+            }
+        }
+        if (k0 + RPP * W >= maxn) break;                     // last window (scalar condition)
         __syncthreads();
         for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
         for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
@@ -2711,16 +3156,16 @@ inline unsigned nblocks(int64_t Q) { return (unsigned)((Q + kBlock - 1) / kBlock
 // sample lists: rec[tile][block of 8][lane][8], 8 bytes per record (rec_index)
 inline int64_t rec_rays(int64_t Q) { return (Q + 63) / 64 * 64; }
 // the kernels' view of caller-owned lists / of a dense workspace region
-inline RecLists lists_dev(const svoxt_sample_lists* l, int64_t Q) {
+inline RecLists lists_dev(const svoxt_sample_lists* l, int64_t Q, int term_bytes = 16) {
     RecLists L;
     L.rec = reinterpret_cast<uint2*>(l->rec);
     L.tab = reinterpret_cast<int32_t*>(l->blocktab);
     L.pool_next = reinterpret_cast<int32_t*>(l->pool_next);
     L.pool_blocks = l->blocktab != nullptr ? l->pool_blocks : rec_rays(Q) / 64 * (l->max_samples / kRecBlock);
     L.S = l->max_samples;
-    // 16 bytes per record slot, 16-byte aligned, or not at all
+    // term_bytes (16; 4 for the one-sigmoid-pass backward of wide rows) per record slot, 16-byte aligned, or not at all
     const bool have_terms = l->terms != nullptr && ((uintptr_t)l->terms & 15u) == 0 &&
-                            l->terms_bytes >= L.pool_blocks * (int64_t)(64 * kRecBlock * 16);
+                            l->terms_bytes >= L.pool_blocks * (int64_t)(64 * kRecBlock) * term_bytes;
     L.terms = have_terms ? reinterpret_cast<float4*>(l->terms) : nullptr;
     return L;
 }
@@ -2832,10 +3277,14 @@ bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
 // 1024 x 1024 depth-9 K = 32), off for the 3-channel payloads (shade_tile_kernel:
 // 800x800 depth-8 SH9 0.156 + 0.123 ms against 0.247 ms for the one-kernel forward).
 // SVOXT_FWD_SPLIT=0 / 1 forces it off / on where a shade kernel exists.
-bool fwd_split_enabled(const svoxt_tree* t, const svoxt_options* o) {   // read per call: tests compare both in one process
+// with_terms: a recording forward that is to leave the backward's (att, e_c) -- the tile shade kernel
+// writes them 1 KB at a time for nothing, the one-kernel forward pays 0.06 ms for its scattered lines
+// (r02: 0.145 + 0.13 ms against 0.316 ms) -- so then the two kernels are the default for 3 channels too.
+bool fwd_split_enabled(const svoxt_tree* t, const svoxt_options* o, bool with_terms = false) {   // read per call
     const char* e = getenv("SVOXT_FWD_SPLIT");
     if (e != nullptr && *e != 0) return atoi(e) != 0;
-    return o->format == SVOXT_FORMAT_RGBA && (t->K == 8 || t->K == 16 || t->K == 32);
+    if (o->format == SVOXT_FORMAT_RGBA && (t->K == 8 || t->K == 16 || t->K == 32)) return true;
+    return with_terms && t->xform == nullptr && t->weight_accum == nullptr;
 }
 
 bool fwd_split_payload(const svoxt_tree* t, const svoxt_options* o, int C) {
@@ -2853,6 +3302,10 @@ bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float
                   bool xf, bool fast, unsigned nb, hipStream_t st) {
 #define SVOXT_SPLIT(F, BB, X)                                                                                 \
     {                                                                                                         \
+        if (!STOP && !X && L.terms != nullptr)                                                                \
+            hipLaunchKernelGGL((shade_tile_kernel<F, BB, false, STOP, !STOP>), dim3(nb), dim3(512), 0, st,    \
+                               tr, rays, opt, L, aux, out);                                                   \
+        else                                                                                                  \
         hipLaunchKernelGGL((shade_tile_kernel<F, BB, X, STOP>), dim3(nb), dim3(512), 0, st, tr, rays, opt,    \
                            L, aux, out);                                                                 \
         hipLaunchKernelGGL((render_fwd_kernel<F, 3, BB, N2, false, X, true>), dim3(nb), dim3(kBlock), 0, st,  \
@@ -2976,8 +3429,26 @@ bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
 bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
                        const float* grad_out, float* grad, int gstride, RecLists L, const uint4* aux,
                        const float* fwd_out, float4* coef, bool xf, hipStream_t st, int terms_state = 0) {
-    if (C != 3) return false;
     const unsigned nb = nblocks(rays.Q);
+    if (C > 3) {
+        // RGBA-style rows of 8 / 16 / 32 floats: the exact per-tile form only (one kernel, a float per
+        // list slot in L.terms); tails of overflowed rays first, as for the 3-channel fused kernel
+        if (opt.format != FMT_RGBA || coef != nullptr || xf || fwd_out != nullptr || L.terms == nullptr) return false;
+#define SVOXT_WIDE(KK)                                                                                        \
+    {                                                                                                         \
+        hipLaunchKernelGGL((render_bwd_kernel<FMT_RGBA, KK - 1, 0, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
+                           tr, rays, opt, grad_out, grad, gstride, L, aux, (const float*)nullptr, (float4*)nullptr); \
+        hipLaunchKernelGGL((grad_wide_kernel<KK>), dim3(nb), dim3(512), 0, st, tr, rays, opt, grad_out, L, aux, \
+                           grad, gstride);                                                                    \
+        return true;                                                                                          \
+    }
+        if (C == 7 && tr.K == 8) SVOXT_WIDE(8)
+        if (C == 15 && tr.K == 16) SVOXT_WIDE(16)
+        if (C == 31 && tr.K == 32) SVOXT_WIDE(32)
+#undef SVOXT_WIDE
+        return false;
+    }
+    if (C != 3) return false;
     // a caller that hands over a coef buffer asks for the two-kernel form; without one (coef_bytes < 0)
     // the per-tile route runs if it can run as ONE kernel.  (The choice is the caller's alone: the
     // Python layer reads SVOXT_BWD_FUSED, the library reads no environment for this.)
@@ -2995,6 +3466,9 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
                                tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                 \
         else if (ctr == nullptr && L.terms != nullptr && terms_state == 2)                                    \
             hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 2>), dim3(nb), dim3(512), 0, st,        \
+                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                      \
+        else if (ctr == nullptr && L.terms != nullptr && terms_state == 3)                                    \
+            hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 3>), dim3(nb), dim3(512), 0, st,        \
                                tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                      \
         else if (ctr == nullptr && L.terms != nullptr)                                                        \
             hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 1>), dim3(nb), dim3(512), 0, st,        \
@@ -3052,8 +3526,20 @@ bool launch_bwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
     hipLaunchKernelGGL((render_bwd_kernel<F, CC, BB, N2, REPLAY>), dim3(nb), dim3(kBlock), 0, st, \
                        tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out);             \
     return true;
+#define SVOXT_BWD1(CC)                                                                                          \
+    hipLaunchKernelGGL((render_bwd_kernel<FMT_RGBA, CC, 0, N2, true, false, false, true>), dim3(nb), dim3(kBlock), \
+                       0, st, tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out);                         \
+    return true;
     if (opt.format == FMT_RGBA) {
         if (C == 3) { SVOXT_BWD(FMT_RGBA, 3, 0) }
+        if constexpr (REPLAY) {
+            // lists + a float per slot + the exact form asked for: one sigmoid pass instead of two
+            if (L.terms != nullptr && fwd_out == nullptr) {
+                if (C == 7) { SVOXT_BWD1(7) }
+                if (C == 15) { SVOXT_BWD1(15) }
+                if (C == 31) { SVOXT_BWD1(31) }
+            }
+        }
         if (C == 7) { SVOXT_BWD(FMT_RGBA, 7, 0) }
         if (C == 15) { SVOXT_BWD(FMT_RGBA, 15, 0) }
         if (C == 31) { SVOXT_BWD(FMT_RGBA, 31, 0) }
@@ -3067,6 +3553,7 @@ bool launch_bwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
         }
     }
 #undef SVOXT_BWD
+#undef SVOXT_BWD1
     return false;
 }
 
@@ -3123,7 +3610,8 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
         const int64_t S = workspace != nullptr ? rec_capacity(workspace_bytes, rays->Q) : 0;
         const RecLists wl = dense_lists(S > 0 ? workspace : nullptr, S, rays->Q);
         if (lists != nullptr) {
-            const RecLists ll = lists_dev(lists, rays->Q);
+            const bool wide = opt->format == SVOXT_FORMAT_RGBA && C > 3;     // one float per slot (render_bwd_kernel<ONEPASS>)
+            const RecLists ll = lists_dev(lists, rays->Q, wide ? 4 : 16);
             const uint4* laux = reinterpret_cast<const uint4*>(lists->aux);
             // coef_bytes < 0 (and no coef): the per-tile route if it can run fused, which needs no buffer
             const bool have_coef = lists->coef != nullptr &&
@@ -3132,7 +3620,7 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
                 // (ll.terms: the exact one-kernel form's hand-over buffer; terms_state 2 = the forward filled it)
                 done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, ll, laux,
                                          fwd_out, have_coef ? reinterpret_cast<float4*>(lists->coef) : nullptr, false, st,
-                                         lists->terms_state == 2 ? 2 : 1);
+                                         (lists->terms_state == 2 || lists->terms_state == 3) ? lists->terms_state : 1);
             if (!done) done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, gs, ll, laux, fwd_out, st)
                       : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, gs, ll, laux, fwd_out, st);
             if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no specialised kernel for this payload", fn);
@@ -3230,7 +3718,8 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
     // two kernels (march, shade per tile) where there is room for the lists: the caller's,
     // or scratch (then the stop rule applies while marching -- those lists serve no backward)
     const bool fast = (flags & SVOXT_FWD_FAST_SIGMOID) != 0;
-    if (fwd_split_enabled(tree, opt) && full_comp(opt) && fwd_split_payload(tree, opt, C) &&
+    const bool want_terms = lists != nullptr && lists->terms != nullptr && C == 3;
+    if (fwd_split_enabled(tree, opt, want_terms) && full_comp(opt) && fwd_split_payload(tree, opt, C) &&
         (!uses_xform(tree, opt) || xform_special(tree, opt))) {
         const bool xf = uses_xform(tree, opt);
         if (lists != nullptr) {
@@ -3316,8 +3805,8 @@ int svoxt_fwd_fills_terms(const svoxt_tree* tree, const svoxt_options* opt) {
     if (uses_xform(tree, opt)) return 0;
     const int C = svoxt_out_data_dim(opt, tree->K) - 1;
     if (C != 3) return 0;
-    // the two-kernel forward does not form them (its shade kernels would have to write them scattered)
-    return (fwd_split_enabled(tree, opt) && fwd_split_payload(tree, opt, C)) ? 0 : 1;
+    // 3: the two-kernel forward (tile shade kernel, position-major); 2: the one-kernel forward (lane-major lines)
+    return (fwd_split_enabled(tree, opt, true) && full_comp(opt) && fwd_split_payload(tree, opt, C)) ? 3 : 2;
 }
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt) {

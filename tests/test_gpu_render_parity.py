@@ -352,3 +352,42 @@ def test_plain_calls_hand_the_forwards_lists_to_the_backward(name, gpu, monkeypa
     np.testing.assert_array_equal(out2.cpu().numpy(), want_out)
     _C.volume_render(tree._spec(tree.features.detach()), rs2, opt)
     assert rs2._svoxt_plan is None
+
+
+@pytest.mark.parametrize("K", [8, 16, 32])
+@pytest.mark.parametrize("cap", [None, 8, 24])     # 8 / 24: most lists overflow -> the tails by the tail-only launch
+def test_wide_rows_backward_routes(gpu, K, cap, monkeypatch):
+    """RGBA-style rows of 8 / 16 / 32 floats: the per-tile backward of an image (grad_wide_kernel:
+    sigmoids once per record in sweep 1 and once per distinct row of a tile window in sweep 2, merged
+    atomic rows), the per-ray one-sigmoid-pass backward (render_bwd_kernel<ONEPASS>) and the plain
+    list replay all give the reference's contributions: every entry within 1e-5 of the TIGHT scale
+    (accum priced by the reference's own sequential addends)."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd import synth
+    if cap is not None:
+        monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", cap)
+    c = Case(depth=5, K=K, data_format="RGBA", width=64, height=56)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    g = synth.grad_output(c.Q, K)
+    want, _, tight = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.numpy(), want_abs="both")
+    routes = []
+    for gather, terms, expect in ((1, True, "grad_wide_kernel"), (0, True, "render_bwd_kernel<ONEPASS>"),
+                                  (0, False, "render_bwd_kernel<REPLAY>")):
+        monkeypatch.setattr(_C, "BWD_GATHER", gather)
+        monkeypatch.setattr(_C, "BWD_TERMS", terms)
+        tree.features.grad = None
+        out = r(tree.features, c.rays_gpu(gpu), image_shape=(56, 64))
+        out.backward(g.to(gpu))
+        assert _C.LAST_ROUTE["backward"].startswith(expect), _C.LAST_ROUTE
+        assert_grads_close(tree.features.grad.cpu().numpy(), want, tight, what=expect)
+        routes.append(tree.features.grad.clone())
+    # a second backward over the same forward (the lists are not rewritten by these routes)
+    monkeypatch.setattr(_C, "BWD_GATHER", 1)
+    monkeypatch.setattr(_C, "BWD_TERMS", True)
+    tree.features.grad = None
+    out = r(tree.features, c.rays_gpu(gpu), image_shape=(56, 64))
+    out.backward(g.to(gpu), retain_graph=True)
+    tree.features.grad = None
+    out.backward(g.to(gpu))
+    assert_grads_close(tree.features.grad.cpu().numpy(), want, tight, what="second backward")
