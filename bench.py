@@ -287,8 +287,14 @@ def main():
                 "atomic_requests_64B": 64 * atomic_requests if atomic_requests else 4 * K * A,
                 "row_compaction": (4 * M * stride + 4 * M * K) if stride != K else 0,
             }
+            if "grad_wide_kernel" in (route_bwd or "") or "ONEPASS" in (route_bwd or ""):
+                # sweep 1 -> sweep 2: the second pass's total_color, 4 bytes per sample, written and read
+                bwd_parts["sweep_handover"] = 8 * A
+            if atomic_requests is None or not atomic_requests:
+                bwd_parts["atomic_requests_note"] = "one row per sample (not counted on the device for this route; " \
+                    "grad_wide_kernel merges rows per tile and window of 16 list positions: exp/reuse_probe.py)"
         fwd_bytes = sum(fwd_parts.values())
-        bwd_bytes = sum(bwd_parts.values()) if bwd_parts else 0
+        bwd_bytes = sum(v for v in bwd_parts.values() if not isinstance(v, str)) if bwd_parts else 0
         if args.forward_only or fwd_ms >= bwd_ms:
             dom, dom_kernel, dom_ms, dom_bytes, dom_ref = "forward", route_fwd, fwd_ms, fwd_bytes, ref_fwd
         else:
