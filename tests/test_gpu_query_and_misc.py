@@ -394,6 +394,27 @@ def test_config4_depth9_features32_and_depth(gpu):
     assert dn.max() < 1.6 + 0.9
 
 
+def test_config4_backward_full_size(gpu, monkeypatch):
+    """BASELINE configs[3] forward + backward at full size (1 048 576 rays, 13.4 M samples of 31
+    channels): the per-tile backward for wide rows (grad_wide_kernel) and the per-ray one-sigmoid-pass
+    form against the oracle's two-pass backward, every entry within 1e-5 of the TIGHT scale (accum
+    priced by the reference's own sequential addends)."""
+    c = Case(depth=9, K=32, data_format="RGBA", width=1024, height=1024)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    gout = synth.grad_output(c.Q, 32)
+    want, _, tight = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), gout.numpy(),
+                                              want_abs="both")
+    for gather, expect in ((1, "grad_wide_kernel"), (0, "render_bwd_kernel<ONEPASS>")):
+        monkeypatch.setattr(_C, "BWD_GATHER", gather)
+        tree.features.grad = None
+        out = r(tree.features, c.rays_gpu(gpu), image_shape=(1024, 1024))
+        out.backward(gout.to(gpu))
+        assert _C.LAST_ROUTE["backward"].startswith(expect), _C.LAST_ROUTE
+        assert_grads_close(tree.features.grad.cpu().numpy(), want, tight, what=expect)
+        tree.features.grad = None
+
+
 @pytest.mark.parametrize("width,height,ndc", [(64, 48, False), (50, 37, False), (64, 48, True), (33, 40, True)])
 def test_render_persp_generates_the_reference_rays_in_kernel(gpu, width, height, ndc):
     """render_persp -> volume_render_image with a CameraSpec: the kernels generate
