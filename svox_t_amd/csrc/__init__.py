@@ -306,7 +306,7 @@ def _pack_tree(tree: TreeSpec) -> _CTree:
 _ACCEL_CACHE: dict = {}     # id(child tensor) -> (weakref to it, ...); entries are dropped when the tensor dies
 
 
-def _accel_log2_for(n_internal: int, N: int) -> int:
+def _accel_log2_for(n_internal: int, N: int, feature_bytes: int = 0) -> int:
     env = os.environ.get("SVOXT_ACCEL_LOG2")
     if env is not None:
         return max(0, min(8, int(env)))
@@ -314,15 +314,21 @@ def _accel_log2_for(n_internal: int, N: int) -> int:
         return 0
     slots = n_internal * 8
     # the smallest grid with at least as many cells as the tree has leaf slots
-    # (D=8 shell tree: 128^3 cells = 16 MiB against 7.6 MiB of topology), capped at
-    # 128^3; measured on the headline workload: 64^3 -> 490, 128^3 -> 500,
-    # 256^3 (134 MiB) -> 510 Mrays/s
-    g = -(-slots.bit_length() // 3)
-    return max(4, min(7, g))
+    # (D=8 shell tree: 128^3 cells = 16 MiB against 7.6 MiB of topology) ...
+    g = max(4, min(7, -(-slots.bit_length() // 3)))
+    # ... and one level finer (256^3 = 128 MiB at most) while cells, node pairs and the feature table
+    # still fit the 256 MiB Infinity Cache together: every leaf crossing of a depth-8 tree is then ONE
+    # dependent load instead of two (r02, 800x800 on the depth-8 tree: forward 0.246 -> 0.226 ms;
+    # with a backward behind it no change, 972 Mrays/s either way).  Past the cache the finer grid
+    # loses (depth 9, 578 MB of features: 805 -> 794 Mrays/s forward).
+    finer = 8 * (1 << (3 * (g + 1))) + 64 * n_internal
+    if g + 1 <= 8 and feature_bytes > 0 and finer + feature_bytes <= 224 * (1 << 20):
+        g += 1
+    return g
 
 
 def _accel_for(tree: TreeSpec, ct: _CTree):
-    g = _accel_log2_for(ct.n_internal, ct.N)
+    g = _accel_log2_for(ct.n_internal, ct.N, tree.features.numel() * tree.features.element_size())
     if g == 0 or ct.N != 2:
         return None, 0
     key = id(tree.child)
