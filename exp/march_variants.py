@@ -33,7 +33,7 @@ def build():
 def run():
     # one subprocess per variant / grid size (the library is loaded at import)
     for name in V:
-        for g in ("7", "6"):
+        for g in ("7",) if os.environ.get("VAR_WORKLOAD") == "d9" else ("7", "6"):
             env = dict(os.environ, SVOXT_LIB=os.path.join(ROOT, "exp", f"libsvoxt_var{name}.so"), SVOXT_ACCEL_LOG2=g)
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "one"], env=env, capture_output=True, text=True, timeout=120)
             print(f"variant {name} grid 2^{g}: {r.stdout.strip()} {r.stderr.strip()[-200:] if r.returncode else ''}", flush=True)
@@ -45,11 +45,12 @@ def one():
     from svox_t_amd import synth
     from svox_t_amd.renderer import _rays_spec_from_rays
     dev = torch.device("cuda:0")
-    st = synth.shell_tree(8)
-    feats = synth.shell_features(st.n_features, 28)
-    tree = svox.N3Tree.from_arrays(st.child, st.data, st.parent_depth, feats, data_format="SH9", device=dev)
+    d9 = os.environ.get("VAR_WORKLOAD") == "d9"      # BASELINE configs[3]: the feature table leaves the Infinity Cache
+    st = synth.shell_tree(9 if d9 else 8)
+    feats = synth.shell_features(st.n_features, 32 if d9 else 28)
+    tree = svox.N3Tree.from_arrays(st.child, st.data, st.parent_depth, feats, data_format="RGBA" if d9 else "SH9", device=dev)
     r = svox.VolumeRenderer(tree)
-    W = H = 800
+    W = H = 1024 if d9 else 800
     o, d, v = synth.pinhole_rays(W, H)
     rays = svox.Rays(o.to(dev), d.to(dev), v.to(dev))
     spec = tree._spec(tree.features); rsh = _rays_spec_from_rays(rays, (H, W)); opt = r._get_options()
@@ -64,6 +65,7 @@ def one():
         for _ in range(n): fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
+    os.environ.setdefault("SVOXT_FWD_SPLIT", "1")
     ms = timeit(lambda: _C.volume_render(spec, rsh, opt))
     print(f"split forward {ms:.4f} ms")
 

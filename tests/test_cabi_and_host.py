@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_C.EXPORTS)          # the ctypes table and the header agree
-    assert lib.svoxt_abi_version() == _C.ABI_VERSION == 13
+    assert lib.svoxt_abi_version() == _C.ABI_VERSION == 14
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -39,14 +39,16 @@ def test_struct_layouts_match_header(tmp_path):
                    'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu ", sizeof(svoxt_options), sizeof(svoxt_rays),'
                    ' sizeof(svoxt_tree), sizeof(svoxt_sample_lists), offsetof(svoxt_rays, c2w), offsetof(svoxt_rays, fy),'
                    ' offsetof(svoxt_tree, accel_log2)); printf("%zu %zu\\n", offsetof(svoxt_tree, xform_dim),'
-                   ' sizeof(svoxt_motion)); printf(" %zu\\n", offsetof(svoxt_sample_lists, coef_bytes)); return 0;}\n')
+                   ' sizeof(svoxt_motion)); printf(" %zu %zu\\n", offsetof(svoxt_sample_lists, coef_bytes),'
+                   ' offsetof(svoxt_tree, sigma_mask_thresh)); return 0;}\n')
     exe = tmp_path / "probe"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert got == [ctypes.sizeof(_C._COptions), ctypes.sizeof(_C._CRays), ctypes.sizeof(_C._CTree),
                    ctypes.sizeof(_C._CLists), _C._CRays.c2w.offset, _C._CRays.fy.offset, _C._CTree.accel_log2.offset,
-                   _C._CTree.xform_dim.offset, ctypes.sizeof(_C._CMotion), _C._CLists.coef_bytes.offset]
-    assert got[:3] == [44, 56, 112]
+                   _C._CTree.xform_dim.offset, ctypes.sizeof(_C._CMotion), _C._CLists.coef_bytes.offset,
+                   _C._CTree.sigma_mask_thresh.offset]
+    assert got[:3] == [44, 56, 128]
 
 
 def test_out_data_dim():

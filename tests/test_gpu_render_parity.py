@@ -391,3 +391,52 @@ def test_wide_rows_backward_routes(gpu, K, cap, monkeypatch):
     tree.features.grad = None
     out.backward(g.to(gpu))
     assert_grads_close(tree.features.grad.cpu().numpy(), want, tight, what="second backward")
+
+
+@pytest.mark.parametrize("name", ["d5_rgba8", "d5_rgba16", "d5_sh9"])
+def test_sigma_bitmask_changes_nothing(name, gpu, monkeypatch):
+    """svoxt_tree.sigma_mask (one bit per feature row: sigma > sigma_thresh) lets the two-kernel forward's
+    march skip its sigma gather.  A pure cache: forwards with it -- scratch lists (no stop rule needed at
+    stop_thresh = 0), recorded lists and the backward that replays them, a non-zero sigma_thresh -- equal
+    the oracle bit for bit, and it follows an in-place change of the features."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd import synth
+    from svox_t_amd.renderer import _rays_spec_from_rays
+    monkeypatch.setattr(_C, "SIGMA_MASK", "1")
+    monkeypatch.setenv("SVOXT_FWD_SPLIT", "1")               # the march + shade forward for every payload that has one
+    c = Case(**CASES[name])
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    rays = c.rays_gpu(gpu)
+    shape = (CASES[name]["height"], CASES[name]["width"])
+    ot = c.oracle_tree()
+    assert (ot.features[:, -1] <= 0).any() and (ot.features[:, -1] > 0).any()      # rows on both sides of the threshold
+    want = O.volume_render(ot, *c.rays_np(), c.oracle_opts())
+    with torch.no_grad():
+        got = r(tree.features, rays, image_shape=shape)
+    assert "march_rec_kernel" in _C.LAST_ROUTE["forward"]
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    assert len(_C._SIGMA_CACHE) >= 1
+    # recording forward + backward (the mask is rebuilt, not taken from the cache)
+    g = synth.grad_output(c.Q, want.shape[1])
+    out = r(tree.features, rays, image_shape=shape)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
+    out.backward(g.to(gpu))
+    gw, _, tight = O.volume_render_backward(ot, *c.rays_np(), c.oracle_opts(), g.numpy(), want_abs="both")
+    assert_grads_close(tree.features.grad.cpu().numpy(), gw, tight)
+    # sigma_thresh > 0 with stop_thresh = 0: the bits are taken against that threshold
+    opt = r._get_options()
+    opt.sigma_thresh = 0.5
+    oo = O.make_options(format=c.format, basis_dim=c.basis_dim, sigma_thresh=0.5, stop_thresh=0.0)
+    with torch.no_grad():
+        got = _C.volume_render(tree._spec(tree.features), _rays_spec_from_rays(rays, shape), opt)
+    np.testing.assert_array_equal(got.cpu().numpy(), O.volume_render(ot, *c.rays_np(), oo))
+    # an in-place change of the features: the cached mask must not survive it
+    with torch.no_grad():
+        tree.features[:, -1] *= -1.0
+        got = r(tree.features, rays, image_shape=shape)
+    f2 = ot.features.copy()
+    f2[:, -1] *= -1.0
+    want2 = O.volume_render(O.Tree(f2, ot.data, ot.child, offset=ot.offset, scaling=ot.scaling), *c.rays_np(), c.oracle_opts())
+    np.testing.assert_array_equal(got.cpu().numpy(), want2)
+    assert not np.array_equal(want2, want)
