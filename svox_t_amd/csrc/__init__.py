@@ -369,17 +369,16 @@ def _pack_tree_accel(tree: TreeSpec) -> _CTree:
 # (tensor object + torch version counter) for forwards nobody differentiates; a forward that records
 # for a backward belongs to a training step whose features have just changed, so it builds the mask
 # afresh every time (inside whatever the caller times) instead of pretending the cache would hit.
-# SVOXT_SIGMA_MASK: 0 never, 1 always, auto (default): when the feature table is too large for the
-# Infinity Cache (>= 192 MiB) -- below that the gather it replaces hits the cache and costs nothing
-# (r02: depth 8 / 66 MB no change; depth 9 / 578 MB forward 1.29 -> 1.09 ms).
-# ---------------------------------------------------------------------------
+# SVOXT_SIGMA_MASK=0: never.  Default: whenever the forward about to run is the two-kernel one and its
+# march can use it (r02: depth 9 / 578 MB of features, forward 1.29 -> 1.05 ms; depth 8 / 66 MB, where the
+# gather still hits the Infinity Cache, forward+backward 955 -> 972 Mrays/s with the rebuild inside the step).
 SIGMA_MASK = os.environ.get("SVOXT_SIGMA_MASK", "auto")
 _SIGMA_CACHE: dict = {}
 
 
 def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool) -> None:
     f = tree.features
-    if SIGMA_MASK == "0" or ct.M == 0 or (SIGMA_MASK != "1" and f.numel() * f.element_size() < 192 * (1 << 20)):
+    if SIGMA_MASK == "0" or ct.M == 0:
         return
     key = id(f)
     mask = None
@@ -729,12 +728,19 @@ LAST_ROUTE = {"forward": None, "backward": None, "forward_terms": False}
 
 def _volume_render(tree, rays, opt, record):
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
-    _attach_sigma_mask(tree, ct, float(co.sigma_thresh), keep=not record)
     dev = tree.features.device
     lists = None
     env = os.environ.get("SVOXT_FWD_SPLIT", "")
     wide = co.format == FORMAT_RGBA and ct.K in (8, 16, 32)
     split = (env not in ("", "0")) if env != "" else wide
+    will_record = bool(record and BWD_LIST_SAMPLES > 0 and cr.Q > 0 and
+                       _lib.svoxt_can_record(ctypes.byref(ct), ctypes.byref(co)))
+    fills = _lib.svoxt_fwd_fills_terms(ctypes.byref(ct), ctypes.byref(co)) \
+        if (will_record and BWD_EXACT and BWD_TERMS and BWD_FUSED and BWD_GATHER) else 0
+    # the march of the two-kernel forward reads a bit per row instead of gathering sigma -- where that
+    # forward is what runs and the stop rule (which needs sigma itself) does not apply
+    if ((split or fills == 3) and env != "0") if will_record else (split and co.stop_thresh == 0.0):
+        _attach_sigma_mask(tree, ct, float(co.sigma_thresh), keep=not will_record)
     LAST_ROUTE["forward_terms"] = False
     LAST_ROUTE["forward"] = (("march_rec_kernel + shade_chan_kernel (two-kernel forward, channels on lanes"
                               + (", float quotient)" if FAST_SIGMOID and not record else ")") if wide else
@@ -742,11 +748,8 @@ def _volume_render(tree, rays, opt, record):
                              else "render_fwd_kernel") + (", recording sample lists" if record else "")
     with torch.cuda.device(dev):
         out = torch.empty((cr.Q, get_out_data_dim(opt, ct.K)), dtype=torch.float32, device=dev)
-        if record and BWD_LIST_SAMPLES > 0 and cr.Q > 0 and \
-                _lib.svoxt_can_record(ctypes.byref(ct), ctypes.byref(co)):
+        if will_record:
             lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
-            fills = _lib.svoxt_fwd_fills_terms(ctypes.byref(ct), ctypes.byref(co)) \
-                if (BWD_EXACT and BWD_TERMS and BWD_FUSED and BWD_GATHER) else 0
             if fills:
                 # the exact per-tile backward will want (att, e0, e1, e2) of every sample: this forward has them
                 lists.terms = torch.empty((lists.pool_blocks * 512 * 4,), dtype=torch.float32, device=dev)
