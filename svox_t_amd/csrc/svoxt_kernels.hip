@@ -1794,14 +1794,19 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 r_w[sl] = att; r_sg[sl] = total_color;
             }
             if (wave == 0 && rd > 0) {
+                // (the operands of the round's eight positions first, then what depends on the step before)
+                float av[W], tv[W];
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    const int sl = (((rd - 1) & 1) * W + j) * 64 + lane;
+                    av[j] = r_w[sl]; tv[j] = r_sg[sl];
+                }
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
                     if ((rd - 1) * W + j < nrec) {
-                        const int sl = (((rd - 1) & 1) * W + j) * 64 + lane;
-                        const float att = r_w[sl];
-                        const float weight = light1 * (1.f - att);
-                        light1 *= att;
-                        accum += weight * r_sg[sl];
+                        const float weight = light1 * (1.f - av[j]);
+                        light1 *= av[j];
+                        accum += weight * tv[j];
                     }
                 }
             }
@@ -1869,13 +1874,20 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             }
             __syncthreads();
             if (wave == 0) {
+                float av[W], tv[W], dv[W];
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    const int s2 = (rd * W + j) * 64 + lane;
+                    av[j] = r_w[s2]; tv[j] = r_sg[s2]; dv[j] = r_dt[s2];
+                }
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
                     if (kb + j < nrec) {
                         const int s2 = (rd * W + j) * 64 + lane;
-                        float cf[C] = {r_c[s2], r_c[R + s2], r_c[2 * R + s2]};
+                        float cf[C] = {0.f, 0.f, 0.f};
+                        if constexpr (FMT == FMT_RGBA) { cf[0] = r_c[s2]; cf[1] = r_c[R + s2]; cf[2] = r_c[2 * R + s2]; }
                         float wgt, sg;
-                        sample_advance<FMT, C>(r_w[s2], r_sg[s2], cf, g, r_dt[s2], r.delta_scale, light_ray, light, accum, wgt, sg);
+                        sample_advance<FMT, C>(av[j], tv[j], cf, g, dv[j], r.delta_scale, light_ray, light, accum, wgt, sg);
                         r_w[s2] = wgt; r_sg[s2] = sg;
                         if constexpr (FMT == FMT_RGBA) { r_c[s2] = cf[0]; r_c[R + s2] = cf[1]; r_c[2 * R + s2] = cf[2]; }
                     }
