@@ -5,6 +5,7 @@ recorded), C the gather reads a compact [M] column's access pattern (values are 
 only).  `run` times march_rec_kernel in each (HIP events around volume_render minus nothing --
 use the rocprof line for kernel-only numbers) -- GPU box."""
 import os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "svox_t_amd", "csrc")
 V = {"A": None,
@@ -12,7 +13,8 @@ V = {"A": None,
      "C": ("p_sigma = sig_col[(int64_t)s.idx * K];", "p_sigma = tr.features[s.idx];")}
 
 def build():
-    src0 = open(os.path.join(CSRC, "svoxt_kernels.hip")).read()
+    from _flatten import flat_source
+    src0 = flat_source()
     for name, sub in V.items():
         src = src0
         if sub:

@@ -6,7 +6,8 @@ exp/libsvoxt_trace.so; use with SVOXT_LIB=exp/libsvoxt_trace.so (exp/trace_run.p
 import os, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "svox_t_amd", "csrc")
-src = open(os.path.join(CSRC, "svoxt_kernels.hip")).read()
+from _flatten import flat_source
+src = flat_source()
 pre = '''
 constexpr int kTraceN = 65536;
 __device__ unsigned long long g_trace[3][3 * kTraceN];

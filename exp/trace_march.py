@@ -10,7 +10,8 @@ OUT = os.path.join(ROOT, "exp", "libsvoxt_trace.so")
 NS = 16   # stamps per workgroup
 
 def build():
-    src = open(os.path.join(CSRC, "svoxt_kernels.hip")).read()
+    from _flatten import flat_source
+    src = flat_source()
     pre = f'''
 constexpr int kTraceN = 16384;
 __device__ unsigned long long g_mtrace[kTraceN * {NS}];
@@ -18,7 +19,7 @@ __device__ unsigned long long g_mtrace[kTraceN * {NS}];
     marker = "// STOP: apply the early-termination rule"
     assert marker in src
     src = src.replace(marker, pre + marker, 1)
-    a = src.index("march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, uint2* __restrict__ rec, int S, uint4* __restrict__ aux) {")
+    a = src.index("march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux,")
     b = src.index("{\n", a) + 2
     src = src[:b] + f'''    unsigned long long* mt = g_mtrace + (size_t)(blockIdx.x < kTraceN ? blockIdx.x : 0) * {NS};
     if (threadIdx.x == 0) mt[0] = wall_clock64();
@@ -30,7 +31,7 @@ __device__ unsigned long long g_mtrace[kTraceN * {NS}];
     src = src[:w2] + f'''        ++trace_it;
         if ((trace_it & 15) == 0 && (trace_it >> 4) < {NS - 2}) atomicMax(mt + 1 + (trace_it >> 4), (unsigned long long)wall_clock64());
 ''' + src[w2:]
-    e = src.index("    aux[q] = make_uint4((uint32_t)nrec | (over ? kRecOverflow : 0u), __float_as_uint(t_resume),\n                        __float_as_uint(1.f), 0u);\n}", w)
+    e = src.index("    aux[q] = make_uint4((uint32_t)nrec | over, __float_as_uint(t_resume), __float_as_uint(1.f), 0u);\n}", w)
     src = src[:e] + f"    atomicMax(mt + 1, (unsigned long long)wall_clock64());\n    atomicMax(mt + {NS - 1}, (unsigned long long)trace_it);\n" + src[e:]
     src += f'''
 extern "C" int svoxt_mtrace_read(void* host_out, int reset) {{

@@ -17,7 +17,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_NAME = "libsvoxt_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
 SOURCES = ["svoxt_kernels.hip", "svoxt_build.hip", "svoxt_motion.hip", "svoxt_order.hip"]
-HEADERS = ["svoxt_device.h", "svoxt_host.h", os.path.join("..", "..", "include", "svoxt.h")]
+HEADERS = ["svoxt_device.h", "svoxt_host.h", "svoxt_lists.h", "svoxt_fwd_kernels.h", "svoxt_bwd_kernels.h",
+           "svoxt_misc_kernels.h", os.path.join("..", "..", "include", "svoxt.h")]
 
 # -ffp-contract=off is part of the numerical contract (svoxt_device.h): the
 # stepping arithmetic must not be fused into FMAs.

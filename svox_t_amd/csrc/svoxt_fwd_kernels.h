@@ -1,0 +1,679 @@
+// svoxt_fwd_kernels.h -- volume_render forward (trace_ray, rt_kernel.cu:222-328): the one-kernel
+// forward (optionally recording sample lists), the generic fallback, and the forward as two kernels
+// (march, then shade per tile / with channels on lanes, plus their tail launches).  See the file
+// header of svoxt_kernels.hip and DESIGN.md 5.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "svoxt_device.h"
+#include "svoxt_lists.h"
+
+#pragma clang fp contract(off)
+
+namespace svoxt {
+
+// The packed leaf id (node * N^3 + u * N^2 + v * N + w, common.cuh:90-93) of the crossing at t, for
+// tree.weight_accum (rt_kernel.cu:266-267, 309-311).  The acceleration grid does not carry it
+// for leaves it resolves by itself (slot = ~0): those take the root descent -- only for samples
+// that are composited, i.e. for the few coarse leaves that hold data.
+template <bool N2>
+__device__ __forceinline__ uint32_t leaf_slot(const TreeDev& tr, const Ray& r, float t, uint32_t slot) {
+    if (slot != 0xffffffffu) return slot;
+    Leaf lf;
+    locate<N2>(tr, r.ox + t * r.dx, r.oy + t * r.dy, r.oz + t * r.dz, lf);
+    return lf.slot;
+}
+
+// XF (SH only): per-leaf view rotations (tree.xform): the basis is re-evaluated
+// for every composited sample with the leaf's matrix (rt_kernel.cu:283-291).
+// RESUME (tail launch of the two-kernel forward, see shade_tile_kernel): only rays whose sample
+// list overflowed (aux[q].x bit 31) do anything; they pick up the compositing state the shade
+// kernel left in `out` (colour sums, transmittance in the alpha slot) and march on from
+// aux[q].y, then finalise the pixel and the recorded final transmittance.
+template <int FMT, int C, int BD, bool N2, bool REC, bool XF = false, bool RESUME = false>
+__global__ void __launch_bounds__(kBlock)
+render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
+                  RecLists L, uint4* __restrict__ aux) {
+    static_assert(!XF || FMT == FMT_SH, "view rotations only matter for view-dependent formats");
+    static_assert(!(RESUME && REC), "the tail launch does not record");
+    constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
+    __shared__ uint2 rstage[REC ? kRecBlock * kBlock : 1];
+    __shared__ int32_t ltab[REC ? kMaxRecBlocks : 1];
+    // (att, e_0, e_1, e_2) of the last <= 4 recorded samples of each ray, for the backward (C == 3)
+    __shared__ float4 tstage[(REC && C == 3 && !XF) ? 4 * kBlock : 1];
+    if constexpr (REC) rec_tab_init(ltab);
+    const int S = L.S;
+    int64_t cur_block = 0;
+    const int64_t tid = ((int64_t)blockIdx.x + rays.tile0) * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, tid);
+    if (q >= rays.Q) return;
+    float* o = out + q * (C + 1);
+    float t_start = 0.f;
+    if constexpr (RESUME) {
+        const uint4 a = aux[q];
+        if ((a.x & kRecOverflow) == 0u) return;
+        t_start = __uint_as_float(a.y);
+    }
+
+    Ray r;
+    if (!setup_ray(tr, rays, opt, q, r)) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) o[j] = opt.background_brightness;
+        o[C] = 0.f;
+        if constexpr (REC) aux[q] = make_uint4(0u, 0u, __float_as_uint(1.f), 0u);
+        return;
+    }
+    int nrec = 0;
+    bool over = false;
+    float t_resume = 0.f;
+    float basis[BD > 0 ? BD : 1];
+    float vd[3] = {0.f, 0.f, 0.f};
+    if constexpr (FMT == FMT_SH) {
+        load_vdir(rays, q, vd);
+        if constexpr (!XF) precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
+    }
+    float acc[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) acc[j] = 0.f;
+
+    float light = 1.f;
+    float t = r.tmin;
+    if constexpr (RESUME) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) acc[j] = o[j];
+        light = o[C];
+        t = t_start;
+    }
+    bool stopped = false;
+    // One composited sample (rt_kernel.cu:279-319); true: the ray ends here (early termination)
+    auto shade = [&](const float (&row)[K], int32_t idx, float delta_t, float t_cur, uint32_t slot) -> bool {
+        const float sigma = row[K - 1];
+        if (!(sigma > opt.sigma_thresh)) return false;
+        bool recorded = false;
+        if constexpr (REC) {
+            bool room = nrec < S;
+            if (room && (nrec & 7) == 0) {
+                cur_block = rec_block_begin(L, ltab, tid >> 6, nrec >> 3);
+                room = cur_block >= 0;
+            }
+            recorded = room;
+            if (room) {
+                rec_stage_put(rstage, (int)threadIdx.x, L.rec, cur_block, nrec, (uint32_t)idx, delta_t);
+                ++nrec;
+            } else if (!over) {
+                over = true;
+                t_resume = t_cur;
+            }
+        }
+        const float att = pexpf(-delta_t * r.delta_scale * sigma);
+        const float weight = light * (1.f - att);
+        float ex[C];
+        if constexpr (FMT == FMT_SH) {
+            if constexpr (XF) rotated_sh_basis<BD>(tr, idx, vd, basis);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float tmp = 0.f;
+#pragma unroll
+                for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
+                ex[c] = pexpf(-tmp);
+                acc[c] = (float)((double)acc[c] + (double)weight / (1.0 + (double)ex[c]));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                ex[j] = pexpf(-row[j]);
+                acc[j] = (float)((double)acc[j] + (double)weight / (1.0 + (double)ex[j]));
+            }
+        }
+        if constexpr (REC && C == 3 && !XF) {
+            // what the backward would otherwise gather the row and form again (both of its sweeps):
+            // its own attenuation (exponent associated as in rt_kernel.cu:397) and the three exponentials.
+            // (Measured r02: handing over sigma instead and letting the backward form its attenuation,
+            // with cached instead of non-temporal stores: the forward saves nothing, the backward loses 0.02 ms.)
+            if (recorded && L.terms != nullptr) {
+                const int k = nrec - 1;
+                tstage[(k & 3) * kBlock + threadIdx.x] =
+                    make_float4(pexpf(-delta_t * sigma * r.delta_scale), ex[0], ex[1], ex[2]);
+                if ((k & 3) == 3) terms_flush(tstage, (int)threadIdx.x, L.terms, cur_block, k);
+            }
+        }
+        light *= att;
+        if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + leaf_slot<N2>(tr, r, t_cur, slot), weight);
+        if constexpr (!REC) {
+            if (light <= opt.stop_thresh) return true;
+        }
+        return false;
+    };
+    // (Measured r02 and removed: a loop two crossings ahead -- crossing k+1 located and its row
+    // requested, the grid cell of crossing k+2 requested, THEN sample k shaded -- so that a
+    // wavefront alone on its SIMD, which is what the last 100 us of this kernel consist of, has
+    // loads in flight while it shades.  Bit-identical, 132 registers, 3 wavefronts per SIMD:
+    // 0.246 -> 0.314 ms.  What it gains in the tail it loses, and more, while the CUs are full.)
+    // Software pipeline: where the ray goes next depends on the leaf geometry only,
+    // not on the leaf's features, so the descent of step k+1 is issued right after
+    // the row load of step k and the two latencies overlap (memory operations of a
+    // wavefront return in order: waiting for the younger descent load covers the row).
+    Sample s;
+    bool have = t < r.tmax;
+    if (have) march_step<N2>(tr, r, opt.step_size, t, s);
+    while (have) {
+        float row[K];
+        const bool valid = s.valid;
+        if (valid) load_row<K>(tr.features + (int64_t)s.idx * K, row);   // whole row at once: sigma is its last element
+        const float t_cur = t, delta_t = s.delta_t;
+        const int32_t idx = s.idx;
+        const uint32_t slot = s.leaf.slot;
+        t = march_advance(t, delta_t);
+        have = t < r.tmax;
+        if (have) march_step<N2>(tr, r, opt.step_size, t, s);           // next descent, in flight with the row
+        if (valid && shade(row, idx, delta_t, t_cur, slot)) { stopped = true; break; }
+    }
+    if (stopped) {
+        const float scale = (float)(1.0 / (1.0 - (double)light));
+#pragma unroll
+        for (int j = 0; j < C; ++j) o[j] = acc[j] * scale;
+    } else {
+        const float bg = light * opt.background_brightness;
+#pragma unroll
+        for (int j = 0; j < C; ++j) o[j] = acc[j] + bg;
+    }
+    o[C] = 1.f - light;
+    if constexpr (REC) {  // + the final transmittance, for the single-march backward
+        rec_stage_finish(rstage, (int)threadIdx.x, L.rec, cur_block, nrec);
+        if constexpr (C == 3 && !XF) {
+            if (L.terms != nullptr && (nrec & 3)) terms_flush(tstage, (int)threadIdx.x, L.terms, cur_block, nrec - 1);
+        }
+        aux[q] = make_uint4((uint32_t)nrec | (over ? kRecOverflow : 0u), __float_as_uint(t_resume),
+                            __float_as_uint(light), 0u);
+    }
+    if constexpr (RESUME) aux[q].z = __float_as_uint(light);
+}
+
+// Generic fallback: any K, any format, component sub-range; accumulators in
+// global memory exactly as the reference keeps them.
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __restrict__ out) {
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+    if (q >= rays.Q) return;
+    float* o = out + q * (C + 1);
+    const int K = tr.K;
+
+    Ray r;
+    if (!setup_ray(tr, rays, opt, q, r)) {
+        for (int j = 0; j < C; ++j) o[j] = opt.background_brightness;
+        o[C] = 0.f;
+        return;
+    }
+    for (int j = 0; j < C; ++j) o[j] = 0.f;
+    float basis[25];
+    float vd[3];
+    load_vdir(rays, q, vd);
+    precalc_basis<0>(opt.format, opt.basis_dim, tr, vd[0], vd[1], vd[2], basis);
+    float light = 1.f;
+    float t = r.tmin;
+    while (t < r.tmax) {
+        Sample s;
+        march_step<N2>(tr, r, opt.step_size, t, s);
+        if (s.valid) {
+            const float* row = tr.features + (int64_t)s.idx * K;
+            const float sigma = row[K - 1];
+            if (sigma > opt.sigma_thresh) {
+                const float att = pexpf(-s.delta_t * r.delta_scale * sigma);
+                const float weight = light * (1.f - att);
+                if (tr.xform != nullptr) rotated_basis(tr, opt.format, opt.basis_dim, s.idx, vd, basis);
+                if (opt.format != FMT_RGBA) {
+                    for (int c = 0; c < C; ++c) {
+                        const int off = c * opt.basis_dim;
+                        float tmp = 0.f;
+                        for (int i = opt.min_comp; i <= opt.max_comp; ++i) tmp += basis[i] * row[off + i];
+                        o[c] = (float)((double)o[c] + (double)weight / (1.0 + (double)pexpf(-tmp)));
+                    }
+                } else {
+                    for (int j = 0; j < C; ++j)
+                        o[j] = (float)((double)o[j] + (double)weight / (1.0 + (double)pexpf(-row[j])));
+                }
+                light *= att;
+                if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + leaf_slot<N2>(tr, r, t, s.leaf.slot), weight);
+                if (light <= opt.stop_thresh) {
+                    const float scale = (float)(1.0 / (1.0 - (double)light));
+                    for (int j = 0; j < C; ++j) o[j] *= scale;
+                    o[C] = 1.f - light;
+                    return;
+                }
+            }
+        }
+        t = march_advance(t, s.delta_t);
+    }
+    for (int j = 0; j < C; ++j) o[j] += light * opt.background_brightness;
+    o[C] = 1.f - light;
+}
+
+// ---------------------------------------------------------------------------
+// Forward as two kernels: march, then shade per tile (trace_ray, rt_kernel.cu:222-328)
+// ---------------------------------------------------------------------------
+//
+// render_fwd_kernel is as long as its longest wavefront: the 8x8 tile whose rays graze the
+// shell makes ~140 leaf crossings, and every crossing carries the whole shading of a sample
+// (row gather, basis products, four exponentials, three double-precision divisions: ~450
+// instructions, r02 ISA) in one dependent chain -- 1.8 us per crossing, 250 us for that
+// wavefront while the bulk of the grid is done after 70 us.  Where a ray goes next depends on
+// the leaf geometry alone, so the chain that must be sequential is the stepping: it gets a
+// kernel of its own, and the shading becomes throughput work.
+//
+//   march_rec_kernel   one ray per lane: locate leaf, step, nothing else.  The sigma of a
+//                      crossing (one 4-byte gather) is requested and looked at one crossing
+//                      later -- memory operations of a wavefront return in order, so it has
+//                      arrived with the next crossing's tree words and costs the chain nothing.
+//                      Samples that pass (sigma > sigma_thresh) are recorded as (feature row,
+//                      delta_t) in rec[k][q], the same lists the backward replays.
+//   shade_tile_kernel  one workgroup of eight wavefronts per 64 rays (lane l of each = ray l).
+//                      Per round, wavefronts 1..7 each take one list position of the 64 rays and
+//                      form what depends on the sample alone: att = exp(-delta_t ds sigma) and
+//                      e_c = exp(-x_c) (row gather, basis products, four exponentials); wavefront
+//                      0 then runs what is sequential along a ray -- weight = T (1 - att),
+//                      acc_c = float(double(acc_c) + double(weight) / (1.0 + double(e_c))),
+//                      T *= att -- through the round's positions in list order, one round behind
+//                      the others (double-buffered LDS, one barrier per round).  Operation for
+//                      operation render_fwd_kernel: outputs are bit-identical.
+//   render_fwd_kernel<..., RESUME>   rays whose list overflowed continue from where it ends.
+
+// STOP: apply the early-termination rule (T <= stop_thresh ends the ray, rt_kernel.cu:313-319)
+// while marching, with the transmittance formed exactly as the shade kernel forms it.  Off when
+// the lists are for a backward, which wants every sample with sigma > 0 (:382,456).
+// One bit per feature row: sigma > thresh (svoxt_sigma_mask_build).  A wavefront's 64 rows are one 8-byte word.
+__global__ void __launch_bounds__(256)
+sigma_mask_kernel(const float* __restrict__ features, int64_t M, int K, float thresh, unsigned long long* __restrict__ mask) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool on = row < M && features[row * K + (K - 1)] > thresh;
+    const unsigned long long b = __ballot(on);
+    if ((threadIdx.x & 63) == 0 && (row >> 6) < (M + 63) / 64) mask[row >> 6] = b;
+}
+
+// MASK (no stop rule): whether a row's sigma exceeds sigma_thresh comes from one bit per feature row
+// (svoxt_sigma_mask_build: M / 8 bytes, resident in L2) instead of a 4-byte gather that pulls a
+// 64-byte line of the feature table -- half of this kernel's traffic, and HBM traffic once the table
+// has left the Infinity Cache (r02, depth 9 / 32-float rows: forward 1.29 -> 1.15 ms with no gather at all).
+template <bool N2, bool STOP, int ACC, bool MASK = false>
+__global__ void __launch_bounds__(kBlock)
+march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux,
+                 const uint32_t* __restrict__ sigma_mask = nullptr) {
+    static_assert(!(MASK && STOP), "the stop rule needs sigma itself");
+    __shared__ uint2 rstage[kRecBlock * kBlock];
+    __shared__ int32_t ltab[kMaxRecBlocks];
+    rec_tab_init(ltab);
+    const int S = L.S;
+    int64_t cur_block = 0;
+    const int64_t tid = ((int64_t)blockIdx.x + rays.tile0) * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, tid);
+    if (q >= rays.Q) return;
+    Ray r;
+    if (!setup_ray(tr, rays, opt, q, r)) {
+        aux[q] = make_uint4(0u, 0u, __float_as_uint(1.f), 0u);
+        return;
+    }
+    const int K = tr.K;
+    const float* __restrict__ sig_col = tr.features + (K - 1);
+    int nrec = 0;
+    uint32_t over = 0u;                  // kRecOverflow once the list is full
+    float t_resume = 0.f;
+    float light = 1.f;
+    float t = r.tmin;
+    // The crossing whose sigma is in flight.  No boolean lives across iterations (each would be a
+    // lane mask merged with scalar instructions at every branch: r02, 87 of the loop's 186
+    // instructions per crossing were such mask arithmetic): "nothing pending" is sigma = -inf,
+    // "stop marching" is t = +inf.
+    const float kNone = -__builtin_inff();
+    float p_sigma = kNone, p_dt = 0.f, p_t = 0.f;
+    int32_t p_idx = 0;
+    while (t < r.tmax) {
+        Sample s;
+        march_step<N2, ACC>(tr, r, opt.step_size, t, s);
+        const float t_cur = t;
+        t = march_advance(t, s.delta_t);
+        bool keep = true;
+        if (p_sigma > opt.sigma_thresh) {
+            bool room = nrec < S;
+            if (room && (nrec & 7) == 0) {
+                cur_block = rec_block_begin(L, ltab, tid >> 6, nrec >> 3);
+                room = cur_block >= 0;
+            }
+            if (room) {
+                rec_stage_put(rstage, (int)threadIdx.x, L.rec, cur_block, nrec, (uint32_t)p_idx, p_dt);
+                ++nrec;
+                if constexpr (STOP) {
+                    light *= pexpf(-p_dt * r.delta_scale * p_sigma);
+                    if (light <= opt.stop_thresh) { t = __builtin_inff(); keep = false; }
+                }
+            } else {        // list full: whoever consumes it marches on from this crossing
+                over = kRecOverflow;
+                t_resume = p_t;
+                t = __builtin_inff();
+                keep = false;
+            }
+        }
+        p_sigma = kNone;
+        if (keep && s.valid) {
+            if constexpr (MASK) p_sigma = ((sigma_mask[s.idx >> 5] >> (s.idx & 31)) & 1u) ? __builtin_inff() : kNone;
+            else p_sigma = sig_col[(int64_t)s.idx * K];
+            p_idx = s.idx;
+            p_dt = s.delta_t;
+            p_t = t_cur;
+        }
+    }
+    if (p_sigma > opt.sigma_thresh) {    // the last crossing's sample
+        bool room = nrec < S;
+        if (room && (nrec & 7) == 0) {
+            cur_block = rec_block_begin(L, ltab, tid >> 6, nrec >> 3);
+            room = cur_block >= 0;
+        }
+        if (room) {
+            rec_stage_put(rstage, (int)threadIdx.x, L.rec, cur_block, nrec, (uint32_t)p_idx, p_dt);
+            ++nrec;
+        } else {
+            over = kRecOverflow;
+            t_resume = p_t;
+        }
+    }
+    rec_stage_finish(rstage, (int)threadIdx.x, L.rec, cur_block, nrec);
+    aux[q] = make_uint4((uint32_t)nrec | over, __float_as_uint(t_resume), __float_as_uint(1.f), 0u);
+}
+
+// WTERMS (recording forwards, no view rotations): the wavefronts that form a sample's exponentials also
+// leave them, with the attenuation in the backward's association (rt_kernel.cu:397), in L.terms
+// (position-major: 1 KB per wavefront and list position) for the exact backward.
+template <int FMT, int BD, bool XF, bool STOP, bool WTERMS = false>
+__global__ void __launch_bounds__(512)
+shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
+                  uint4* __restrict__ aux, float* __restrict__ out) {
+    constexpr int C = 3, W = 8, P = W - 1;
+    constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
+    constexpr int NB = (FMT == FMT_SH) ? BD : 1;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __shared__ v4f terms[2][P][64];              // (att, e_0, e_1, e_2) of a list position, per ray
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x + rays.tile0;
+    const int64_t q = ray_of_thread(rays, tile * 64 + lane);
+    const bool inb = q < rays.Q;
+    uint4 a = make_uint4(0u, 0u, 0u, 0u);
+    if (inb) a = aux[q];
+    const int nrec = (int)(a.x & ~kRecOverflow);
+    int maxn = nrec;
+    for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
+    maxn = __builtin_amdgcn_readfirstlane(maxn);     // what decides the barrier count is scalar
+    const int nround = (maxn + P - 1) / P;           // the same in every wavefront of the workgroup
+    const int32_t tabreg = rec_tab_reg(L, tile, lane);
+
+    float delta_scale = 0.f;
+    float basis[NB];
+    float vd[3] = {0.f, 0.f, 0.f};
+    if (wave > 0 && nrec > 0) {
+        Ray r;
+        setup_ray(tr, rays, opt, q, r);               // a ray with samples hits the cube
+        delta_scale = r.delta_scale;
+        if constexpr (FMT == FMT_SH) {
+            load_vdir(rays, q, vd);
+            if constexpr (!XF) precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
+        }
+    }
+    float light = 1.f, acc[C] = {0.f, 0.f, 0.f};
+    bool stopped = false;
+
+    for (int rd = 0; rd <= nround; ++rd) {
+        if (wave > 0) {
+            const int k = rd * P + (wave - 1);
+            if (rd < nround && k < nrec) {
+                const int64_t blk = rec_block_u(L, tabreg, tile, k >> 3);
+                const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
+                const int32_t idx = (int32_t)e.x;
+                float row[K];
+                load_row<K>(tr.features + (int64_t)idx * K, row);
+                v4f tv;
+                tv.x = pexpf(-__uint_as_float(e.y) * delta_scale * row[K - 1]);
+                if constexpr (FMT == FMT_SH) {
+                    if constexpr (XF) rotated_sh_basis<BD>(tr, idx, vd, basis);
+                    float ex[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        float tmp = 0.f;
+#pragma unroll
+                        for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
+                        ex[c] = pexpf(-tmp);
+                    }
+                    tv.y = ex[0]; tv.z = ex[1]; tv.w = ex[2];
+                } else {
+                    tv.y = pexpf(-row[0]); tv.z = pexpf(-row[1]); tv.w = pexpf(-row[2]);
+                }
+                terms[rd & 1][wave - 1][lane] = tv;
+                if constexpr (WTERMS) {
+                    typedef float v4g __attribute__((ext_vector_type(4)));
+                    const float att_b = pexpf(-__uint_as_float(e.y) * row[K - 1] * delta_scale);
+                    __builtin_nontemporal_store(v4g{att_b, tv.y, tv.z, tv.w},
+                                                reinterpret_cast<v4g*>(L.terms + terms_index_pm(blk, lane, k)));
+                }
+            }
+        } else if (rd > 0) {
+            const int kb = (rd - 1) * P;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                if (kb + j < nrec && !stopped) {
+                    const v4f tv = terms[(rd - 1) & 1][j][lane];
+                    const float weight = light * (1.f - tv.x);
+                    acc[0] = (float)((double)acc[0] + (double)weight / (1.0 + (double)tv.y));
+                    acc[1] = (float)((double)acc[1] + (double)weight / (1.0 + (double)tv.z));
+                    acc[2] = (float)((double)acc[2] + (double)weight / (1.0 + (double)tv.w));
+                    light *= tv.x;
+                    if constexpr (STOP) {
+                        if (light <= opt.stop_thresh) stopped = true;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0 && inb) {
+        float* o = out + q * (C + 1);
+        if (stopped) {
+            const float scale = (float)(1.0 / (1.0 - (double)light));
+#pragma unroll
+            for (int j = 0; j < C; ++j) o[j] = acc[j] * scale;
+            o[C] = 1.f - light;
+            a.x &= ~kRecOverflow;                    // nothing left for the tail launch
+        } else if (a.x & kRecOverflow) {             // state for render_fwd_kernel<..., RESUME>
+#pragma unroll
+            for (int j = 0; j < C; ++j) o[j] = acc[j];
+            o[C] = light;
+        } else {
+            const float bg = light * opt.background_brightness;
+#pragma unroll
+            for (int j = 0; j < C; ++j) o[j] = acc[j] + bg;
+            o[C] = 1.f - light;
+        }
+        a.z = __float_as_uint(light);                // the final transmittance, for the single-march backward
+        aux[q] = a;
+    }
+}
+
+// The shade kernel for RGBA-style rows of K = 8, 16 or 32 floats (C = K - 1 feature channels and
+// sigma: BASELINE configs[3] is K = 32): CHANNELS on lanes.  A wavefront takes 64 / K rays; lane
+// (g, c) is channel c of ray g.  Per list position a lane reads ITS float of the sample's row --
+// the K lanes of a ray read one contiguous row -- and forms one exponential; the sigma lane
+// (c = K - 1) forms the attenuation instead and hands it to its group (one cross-lane read), then
+// every channel lane runs its own chain  acc = float(double(acc) + double(T (1 - att)) / (1.0 +
+// double(e)))  along the ray: the same operations in the same order as render_fwd_kernel, bit for
+// bit, with every lane busy, ~30 registers, no LDS, no barrier.  (render_fwd_kernel<RGBA, 31>
+// keeps 31 accumulators and the 32-float row per lane: 1.1 wavefronts per SIMD on average and the
+// VALU half idle at 1024 x 1024, depth 9 -- r02 PMC -- because a wavefront shades all 31
+// channels of whichever of its 64 rays have a sample.)
+// FAST (opt-in tolerance mode): the quotient in float with the hardware reciprocal,
+// acc += w * rcp(1 + e): each term within 2e-7 of the reference's double-precision quotient.
+template <int K, bool STOP, bool FAST>
+__global__ void __launch_bounds__(256)
+shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
+                  uint4* __restrict__ aux, float* __restrict__ out) {
+    static_assert(K == 8 || K == 16 || K == 32, "row widths with a channel-lane instance");
+    constexpr int RPW = 64 / K;                                  // rays per wavefront
+    const int lane = threadIdx.x & 63;
+    const int c = lane & (K - 1);
+    const int sig_lane = lane | (K - 1);                         // the sigma lane of this lane's ray
+    // t: the launch thread of march_rec_kernel that holds this ray (tile t >> 6, lane t & 63)
+    const int64_t t = (int64_t)rays.tile0 * 64 + ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + (lane / K);
+    const int64_t q = ray_of_thread(rays, t);
+    const bool inb = q < rays.Q;
+    uint4 a = make_uint4(0u, 0u, 0u, 0u);
+    if (inb) a = aux[q];
+    const int nrec = (int)(a.x & ~kRecOverflow);
+    int maxn = nrec;
+    for (int off = 32; off >= K; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
+    maxn = __builtin_amdgcn_readfirstlane(maxn);
+    float ds = 0.f;
+    if (nrec > 0) {
+        Ray r;
+        setup_ray(tr, rays, opt, q, r);                          // a ray with samples hits the cube
+        ds = r.delta_scale;
+    }
+    const int32_t tabreg = rec_tab_reg(L, t >> 6, lane);
+    float light = 1.f, acc = 0.f;
+    bool stopped = false;
+    // A block of 8 records is the ray's own 64-byte line: fetch it whole, request the 8 rows it
+    // names back to back (the K lanes of a ray: one contiguous row each), form the 8 exponentials --
+    // all independent -- and only then run the chain along the ray.  (One record, one row, one step
+    // at a time the kernel was a chain of two dependent loads per sample: 1.12 ms at 1024 x 1024,
+    // depth 9, K = 32, and no faster with the float quotient.)
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    for (int kb = 0; kb < maxn; kb += kRecBlock) {
+        uint32_t idx[kRecBlock];
+        float dt[kRecBlock], ex[kRecBlock];
+        const int n_here = min(nrec - kb, kRecBlock);            // records of this ray in the block (<= 0: none)
+        const int64_t blk = rec_block_u(L, tabreg, t >> 6, kb >> 3);
+        if (n_here > 0) {
+            const v4u* line = reinterpret_cast<const v4u*>(L.rec + rec_index_in(blk, t, kb));   // the ray's line of this block
+#pragma unroll
+            for (int j = 0; j < kRecBlock / 2; ++j) {
+                const v4u w = __builtin_nontemporal_load(line + j);
+                idx[2 * j] = w.x; dt[2 * j] = __uint_as_float(w.y);
+                idx[2 * j + 1] = w.z; dt[2 * j + 1] = __uint_as_float(w.w);
+            }
+        }
+        float x[kRecBlock];
+#pragma unroll
+        for (int j = 0; j < kRecBlock; ++j) {
+            x[j] = 0.f;
+            if (j < n_here) x[j] = tr.features[(int64_t)(int32_t)idx[j] * K + c];
+        }
+#pragma unroll
+        for (int j = 0; j < kRecBlock; ++j) {
+            ex[j] = 1.f;
+            if (j < n_here) ex[j] = pexpf(c == K - 1 ? -dt[j] * ds * x[j] : -x[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < kRecBlock; ++j) {
+            const float att = __shfl(ex[j], sig_lane, 64);       // every lane takes part
+            if (j < n_here && !stopped) {
+                const float weight = light * (1.f - att);
+                if constexpr (FAST) acc += weight * __builtin_amdgcn_rcpf(1.f + ex[j]);
+                else acc = (float)((double)acc + (double)weight / (1.0 + (double)ex[j]));
+                light *= att;
+                if constexpr (STOP) {
+                    if (light <= opt.stop_thresh) stopped = true;
+                }
+            }
+        }
+    }
+    if (!inb) return;
+    const bool over = (a.x & kRecOverflow) != 0u && !stopped;    // state for render_fwd_kernel<..., RESUME>
+    float v;
+    if (c < K - 1) {
+        if (stopped) v = acc * (float)(1.0 / (1.0 - (double)light));
+        else if (over) v = acc;
+        else v = acc + light * opt.background_brightness;
+    } else {
+        v = over ? light : 1.f - light;
+        if (stopped) a.x &= ~kRecOverflow;
+        a.z = __float_as_uint(light);
+        aux[q] = a;
+    }
+    out[q * K + c] = v;
+}
+
+// The tail launch for those rows: rays whose list overflowed (1.3 % at 1024 x 1024, depth 9,
+// S = 96 -- but as render_fwd_kernel<RGBA, 31, ..., RESUME> they cost 0.25 ms, a lane shading 31
+// channels per sample) continue with the same lane layout as shade_chan_kernel: the K lanes of a
+// ray march it together (the same steps in every lane: redundant, but a march is latency, not
+// work) and each shades its own channel.  State in and out as for the RESUME launch.
+template <int K, bool N2, bool FAST>
+__global__ void __launch_bounds__(256)
+tail_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, uint4* __restrict__ aux, float* __restrict__ out) {
+    // One workgroup (four wavefronts) per 64-ray tile; with lists that hold every sample -- the
+    // usual case since they are pooled -- the launch is one look at the tile's 64 aux entries.
+    constexpr int RPW = 64 / K;
+    __shared__ int any_over;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x + rays.tile0;
+    if (wave == 0) {
+        const int64_t q0 = ray_of_thread(rays, tile * 64 + lane);
+        const bool ov = q0 < rays.Q && (aux[q0].x & kRecOverflow) != 0u;
+        const bool a0 = __any(ov);
+        if (lane == 0) any_over = a0 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!any_over) return;
+    const int c = lane & (K - 1);
+    const int sig_lane = lane | (K - 1);
+    for (int grp = wave; grp < 64 / RPW; grp += 4) {          // RPW rays per wavefront and turn
+        const int64_t t0 = tile * 64 + grp * RPW + (lane / K);
+        const int64_t q = ray_of_thread(rays, t0);
+        uint4 a = make_uint4(0u, 0u, 0u, 0u);
+        if (q < rays.Q) a = aux[q];
+        bool alive = (a.x & kRecOverflow) != 0u;
+        if (!__any(alive)) continue;
+        Ray r;
+        float light = 1.f, acc = 0.f, t = 0.f, tmax = -1.f;
+        bool stopped = false;
+        if (alive) {
+            setup_ray(tr, rays, opt, q, r);
+            t = __uint_as_float(a.y);
+            tmax = r.tmax;
+            light = out[q * K + (K - 1)];
+            if (c < K - 1) acc = out[q * K + c];
+        }
+        while (__any(alive && t < tmax)) {
+            const bool go = alive && t < tmax;
+            float x = 0.f, dt = 0.f;
+            bool valid = false;
+            if (go) {
+                Sample s;
+                march_step<N2>(tr, r, opt.step_size, t, s);
+                dt = s.delta_t;
+                valid = s.valid;
+                if (valid) x = tr.features[(int64_t)s.idx * K + c];
+                t = march_advance(t, s.delta_t);
+            }
+            const float sigma = __shfl(x, sig_lane, 64);
+            const bool active = go && valid && sigma > opt.sigma_thresh;
+            float ex = 1.f;
+            if (active) ex = pexpf(c == K - 1 ? -dt * r.delta_scale * x : -x);
+            const float att = __shfl(ex, sig_lane, 64);
+            if (active) {
+                const float weight = light * (1.f - att);
+                if constexpr (FAST) acc += weight * __builtin_amdgcn_rcpf(1.f + ex);
+                else acc = (float)((double)acc + (double)weight / (1.0 + (double)ex));
+                light *= att;
+                if (light <= opt.stop_thresh) { stopped = true; alive = false; }
+            }
+        }
+        if ((a.x & kRecOverflow) == 0u) continue;
+        float v;
+        if (c < K - 1) {
+            v = stopped ? acc * (float)(1.0 / (1.0 - (double)light)) : acc + light * opt.background_brightness;
+        } else {
+            v = 1.f - light;
+            aux[q].z = __float_as_uint(light);
+        }
+        out[q * K + c] = v;
+    }
+}
+
+}  // namespace svoxt

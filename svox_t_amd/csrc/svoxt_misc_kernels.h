@@ -1,0 +1,481 @@
+// svoxt_misc_kernels.h -- the kernels around the render path: opacity forward / backward from lists,
+// depth, the roofline counters, point query and its unique-leaf compaction, row compaction, and the
+// acceleration-grid build.  See the file header of svoxt_kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "svoxt_device.h"
+#include "svoxt_lists.h"
+
+#pragma clang fp contract(off)
+
+namespace svoxt {
+
+// ---------------------------------------------------------------------------
+// Opacity (rt_kernel.cu:500-560, :1110-1126) and depth (:782-834, :866-882)
+// ---------------------------------------------------------------------------
+
+// REC (thresholds 0): also records each ray's samples with sigma > 0 as (feature row,
+// delta_t) in rec[k][q] and aux[q] = {count | overflow << 31, t of the first unrecorded
+// sample, final transmittance, -} for svoxt_opacity_render_bwd_replay.
+template <bool N2, bool REC = false>
+__global__ void __launch_bounds__(kBlock)
+opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
+                   RecLists L = RecLists{}, uint4* __restrict__ aux = nullptr) {
+    __shared__ uint2 rstage[REC ? kRecBlock * kBlock : 1];
+    __shared__ int32_t ltab[REC ? kMaxRecBlocks : 1];
+    if constexpr (REC) rec_tab_init(ltab);
+    const int S = L.S;
+    int64_t cur_block = 0;
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, tid);
+    if (q >= rays.Q) return;
+    Ray r;
+    if (!setup_ray(tr, rays, opt, q, r)) {
+        out[q] = 0.f;
+        if constexpr (REC) aux[q] = make_uint4(0u, 0u, __float_as_uint(1.f), 0u);
+        return;
+    }
+    const int K = tr.K;
+    float light = 1.f, t = r.tmin;
+    int nrec = 0;
+    bool over = false;
+    float t_resume = 0.f;
+    while (t < r.tmax) {
+        Sample s;
+        march_step<N2>(tr, r, opt.step_size, t, s);
+        if (s.valid) {
+            const float sigma = tr.features[(int64_t)s.idx * K + (K - 1)];
+            if (sigma > opt.sigma_thresh) {
+                if constexpr (REC) {
+                    bool room = nrec < S;
+                    if (room && (nrec & 7) == 0) {
+                        cur_block = rec_block_begin(L, ltab, tid >> 6, nrec >> 3);
+                        room = cur_block >= 0;
+                    }
+                    if (room) {
+                        rec_stage_put(rstage, (int)threadIdx.x, L.rec, cur_block, nrec, (uint32_t)s.idx, s.delta_t);
+                        ++nrec;
+                    } else if (!over) {
+                        over = true;
+                        t_resume = t;
+                    }
+                }
+                light *= pexpf(-s.delta_t * r.delta_scale * sigma);
+                if constexpr (!REC) {
+                    if (light <= opt.stop_thresh) break;
+                }
+            }
+        }
+        t = march_advance(t, s.delta_t);
+    }
+    out[q] = 1.f - light;
+    if constexpr (REC) {
+        rec_stage_finish(rstage, (int)threadIdx.x, L.rec, cur_block, nrec);
+        aux[q] = make_uint4((uint32_t)nrec | (over ? kRecOverflow : 0u), __float_as_uint(t_resume),
+                            __float_as_uint(light), 0u);
+    }
+}
+
+// opacity_render_backward from recorded lists (C = 0 of trace_ray_backward,
+// rt_kernel.cu:331-496, 1593-1616): the only gradient is the sigma entry
+//     delta_t * delta_scale * grad_output * T_ray            (:486-490 with no colour terms)
+// with T_ray the final transmittance as the reference's backward computes it
+// (exponent associated as in :397).  One walk: rec[k][q] <- (row, (delta_t * delta_scale) *
+// grad_output) and aux[q].w <- T_ray; opacity_merge_kernel multiplies by T_ray and adds
+// up per tile.  Rays whose list overflowed march their tail here (twice: T_ray must be
+// complete before their tail samples can be sent) with per-lane atomics.
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+opacity_walk_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
+                    float* __restrict__ grad, int gstride, RecLists L, uint4* __restrict__ aux) {
+    uint2* __restrict__ rec = L.rec;
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t q = ray_of_thread(rays, tid);
+    if (q >= rays.Q) return;
+    const uint4 a = aux[q];
+    const int nrec = (int)(a.x & ~kRecOverflow);
+    const bool over = (a.x & kRecOverflow) != 0u;
+    if (nrec == 0 && !over) return;
+    Ray r;
+    if (!setup_ray(tr, rays, opt, q, r)) return;
+    const int K = tr.K;
+    const float g = grad_out[q];
+    float light = 1.f;
+    for (int k = 0; k < nrec; ++k) {
+        uint2* slot = rec + rec_index(L, tid, k);
+        const uint2 e = rec_get(slot);
+        const float delta_t = __uint_as_float(e.y);
+        const float sigma = tr.features[(int64_t)(int32_t)e.x * K + (K - 1)];
+        light *= pexpf(-delta_t * sigma * r.delta_scale);
+        rec_put(slot, e.x, delta_t * r.delta_scale * g);
+    }
+    if (over) {
+        const float t0 = __uint_as_float(a.y);
+        for (int pass = 0; pass < 2; ++pass) {
+            const float light_ray = light;                  // complete only in the second pass
+            float t = t0;
+            while (t < r.tmax) {
+                Sample s;
+                march_step<N2>(tr, r, opt.step_size, t, s);
+                if (s.valid) {
+                    const float sigma = tr.features[(int64_t)s.idx * K + (K - 1)];
+                    if (sigma > 0.f) {
+                        if (pass == 0) light *= pexpf(-s.delta_t * sigma * r.delta_scale);
+                        else atomicAdd(grad + (int64_t)s.idx * gstride + (K - 1), s.delta_t * r.delta_scale * g * light_ray);
+                    }
+                }
+                t = march_advance(t, s.delta_t);
+            }
+        }
+    }
+    aux[q].w = __float_as_uint(light);
+}
+
+// Per-tile sum of the walk's records: W wavefronts share a hash table of T feature rows
+// (atomicCAS on the key, ds_add_f32 on the one value per row: 1 LDS float atomic per
+// record is cheap, 28 were not), flushed after every pass of at most T records.
+template <int T, int W>
+__global__ void __launch_bounds__(64 * W)
+opacity_merge_kernel(RaysDev rays, RecLists L, const uint4* __restrict__ aux,
+                     float* __restrict__ grad, int gstride, int col) {
+    constexpr int NT = 64 * W;
+    constexpr int kGroup = 2, kRound = kGroup * W, RPP = T / (64 * kRound);
+    static_assert((T & (T - 1)) == 0 && RPP >= 1, "a pass of RPP rounds must fit the table");
+    __shared__ int32_t keys[T];
+    __shared__ float vals[T];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t tabreg = rec_tab_reg(L, blockIdx.x, lane);
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * 64 + lane);
+    int nrec = 0;
+    float t_ray = 0.f;
+    if (q < rays.Q) {
+        const uint4 a = aux[q];
+        nrec = (int)(a.x & ~kRecOverflow);
+        t_ray = __uint_as_float(a.w);
+    }
+    int maxn = nrec;
+    for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
+    maxn = __builtin_amdgcn_readfirstlane(maxn);
+    if (maxn == 0) return;
+    for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; vals[i] = 0.f; }
+    __syncthreads();
+    for (int k0 = 0; k0 < maxn; k0 += RPP * kRound) {
+#pragma unroll 1
+        for (int rd = 0; rd < RPP; ++rd) {
+            const int kb = k0 + rd * kRound + wave * kGroup;
+            if (kb >= maxn) break;
+            uint2 e[kGroup];
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u) {
+                e[u] = make_uint2(0u, 0u);
+                if (kb + u < nrec) e[u] = rec_get(L.rec + rec_index_in(rec_block_u(L, tabreg, blockIdx.x, (kb + u) >> 3), lane, kb + u));
+            }
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u) {
+                if (kb + u < nrec) {
+                    const int32_t idx = (int32_t)e[u].x;
+                    uint32_t h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
+                    while (true) {
+                        const int32_t old = atomicCAS(keys + h, -1, idx);
+                        if (old == -1 || old == idx) break;
+                        h = (h + 1u) & (uint32_t)(T - 1);
+                    }
+                    atomicAdd(vals + h, __uint_as_float(e[u].y) * t_ray);     // ((delta_t * ds) * g) * T_ray
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < T; i += NT) {
+            const int32_t key = keys[i];
+            if (key >= 0) {
+                atomicAdd(grad + (int64_t)key * gstride + col, vals[i]);
+                keys[i] = -1;
+                vals[i] = 0.f;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+depth_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ depth) {
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+    if (q >= rays.Q) return;
+    Ray r;
+    float d = 0.f;
+    if (setup_ray(tr, rays, opt, q, r)) {
+        const int K = tr.K;
+        float t = r.tmin;
+        while (t < r.tmax) {
+            Sample s;
+            march_step<N2>(tr, r, opt.step_size, t, s);
+            if (s.valid) {
+                const float sigma = tr.features[(int64_t)s.idx * K + (K - 1)];
+                if (sigma > opt.sigma_thresh) { d = r.delta_scale * t; break; }
+            }
+            t = march_advance(t, s.delta_t);
+        }
+    }
+    depth[q] = d;
+}
+
+// ---------------------------------------------------------------------------
+// Roofline counters
+// ---------------------------------------------------------------------------
+
+
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+count_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, unsigned long long* __restrict__ counters) {
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+    unsigned long long hit = 0, steps = 0, levels = 0, valid = 0, active = 0;
+    Ray r;
+    if (q < rays.Q && setup_ray(tr, rays, opt, q, r)) {
+        hit = 1;
+        const int K = tr.K;
+        float light = 1.f, t = r.tmin;
+        while (t < r.tmax) {
+            Sample s;
+            march_step<N2>(tr, r, opt.step_size, t, s);
+            ++steps;
+            levels += s.leaf.levels;
+            if (s.valid) {
+                ++valid;
+                const float sigma = tr.features[(int64_t)s.idx * K + (K - 1)];
+                if (sigma > opt.sigma_thresh) {
+                    ++active;
+                    light *= pexpf(-s.delta_t * r.delta_scale * sigma);
+                    if (light <= opt.stop_thresh) break;
+                }
+            }
+            t = march_advance(t, s.delta_t);
+        }
+    }
+    hit = wave_sum(hit); steps = wave_sum(steps); levels = wave_sum(levels);
+    valid = wave_sum(valid); active = wave_sum(active);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(counters + 0, hit);
+        atomicAdd(counters + 1, steps);
+        atomicAdd(counters + 2, levels);
+        atomicAdd(counters + 3, valid);
+        atomicAdd(counters + 4, active);
+    }
+}
+
+// What one forward march touches (svoxt_count_touched; for the roofline's compulsory bytes):
+// row_mask[idx] = 1 for every valid leaf's feature row (the forward reads it), row_mask[M + idx] = 1
+// if a sample there is composited (the backward reads the row again); tree_mask: grid cells and (child, data)
+// pairs with the acceleration grid, child and data words without (march_step<..., MARK>);
+// longest[0] = the most leaf crossings any ray makes.  The march is the real one.
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+count_touched_kernel(TreeDev tr, RaysDev rays, Opts opt, uint8_t* __restrict__ row_mask,
+                     uint8_t* __restrict__ tree_mask, uint32_t n_slots, unsigned long long* __restrict__ longest) {
+    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+    unsigned long long steps = 0;
+    Ray r;
+    if (q < rays.Q && setup_ray(tr, rays, opt, q, r)) {
+        const int K = tr.K;
+        float light = 1.f, t = r.tmin;
+        while (t < r.tmax) {
+            Sample s;
+            march_step<N2, -1, true>(tr, r, opt.step_size, t, s, tree_mask, n_slots);
+            ++steps;
+            if (s.valid) {
+                const float sigma = tr.features[(int64_t)s.idx * K + (K - 1)];
+                row_mask[s.idx] = 1;                      // (every writer stores the same value: no race to lose)
+                if (sigma > opt.sigma_thresh) {
+                    row_mask[tr.M + s.idx] = 1;
+                    light *= pexpf(-s.delta_t * r.delta_scale * sigma);
+                    if (light <= opt.stop_thresh) break;
+                }
+            }
+            t = march_advance(t, s.delta_t);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) steps = max(steps, (unsigned long long)__shfl_down(steps, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(longest, steps);
+}
+
+// ---------------------------------------------------------------------------
+// Point query (svox_kernel.cu:45-94)
+// ---------------------------------------------------------------------------
+
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+query_fwd_kernel(TreeDev tr, const float* __restrict__ points, int64_t Q,
+                 float* __restrict__ values, int64_t* __restrict__ node_ids,
+                 int64_t* __restrict__ data_ids, uint8_t* __restrict__ hit_mask) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= Q) return;
+    const float* p = points + 3 * q;
+    const float px = tr.offset[0] + tr.scaling[0] * p[0];
+    const float py = tr.offset[1] + tr.scaling[1] * p[1];
+    const float pz = tr.offset[2] + tr.scaling[2] * p[2];
+    Leaf lf;
+    locate<N2>(tr, px, py, pz, lf);
+    node_ids[q] = (int64_t)lf.slot;
+    if (hit_mask != nullptr) hit_mask[lf.slot] = 1;
+    const int32_t idx = tr.data[lf.slot];
+    const int K = tr.K;
+    float* v = values + q * K;
+    if (idx >= 0 && (int64_t)idx < tr.M) {
+        data_ids[q] = idx;
+        const float* row = tr.features + (int64_t)idx * K;
+        for (int i = 0; i < K; ++i) v[i] = row[i];
+    } else {
+        data_ids[q] = -1;
+        for (int i = 0; i < K; ++i) v[i] = 0.f;
+    }
+}
+
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+query_bwd_kernel(TreeDev tr, const float* __restrict__ points, int64_t Q,
+                 const float* __restrict__ grad_out, float* __restrict__ grad) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= Q) return;
+    const float* p = points + 3 * q;
+    const float px = tr.offset[0] + tr.scaling[0] * p[0];
+    const float py = tr.offset[1] + tr.scaling[1] * p[1];
+    const float pz = tr.offset[2] + tr.scaling[2] * p[2];
+    Leaf lf;
+    locate<N2>(tr, px, py, pz, lf);
+    const int32_t idx = tr.data[lf.slot];
+    if (idx < 0 || (int64_t)idx >= tr.M) return;
+    const int K = tr.K;
+    for (int i = 0; i < K; ++i) atomicAdd(grad + (int64_t)idx * K + i, grad_out[q * K + i]);
+}
+
+// ---------------------------------------------------------------------------
+// Unique-leaf list of a point query: compaction of the hit mask into
+// leaf_node[U, 4] = (node, u, v, w), sorted by packed leaf id.  The reference
+// numbers the hits with a float atomic counter (svox_kernel.cu:260-269: order
+// undefined, exact only below 2^24 leaves); here a three-step integer prefix
+// sum gives a deterministic order: per-segment counts, scan of the counts,
+// ranked scatter.
+// ---------------------------------------------------------------------------
+
+constexpr int kSeg = 1024;     // mask entries per workgroup (4 per thread)
+
+__global__ void __launch_bounds__(kBlock)
+leaves_count_kernel(const uint8_t* __restrict__ mask, int64_t n, int32_t* __restrict__ seg_count) {
+    __shared__ int32_t wsum[kBlock / 64];
+    const int64_t base = (int64_t)blockIdx.x * kSeg;
+    int c = 0;
+    for (int i = threadIdx.x; i < kSeg; i += kBlock) c += (base + i < n && mask[base + i]) ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t tot = 0;
+        for (int w = 0; w < kBlock / 64; ++w) tot += wsum[w];
+        seg_count[blockIdx.x] = tot;
+    }
+}
+
+// exclusive scan of seg_count[0..nseg) in place; total -> *count (one workgroup)
+__global__ void __launch_bounds__(kBlock)
+leaves_scan_kernel(int32_t* __restrict__ seg_count, int nseg, int64_t* __restrict__ count) {
+    __shared__ int32_t part[kBlock];
+    const int per = (nseg + kBlock - 1) / kBlock;
+    const int lo = threadIdx.x * per, hi = min(lo + per, nseg);
+    int32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += seg_count[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t run = 0;
+        for (int i = 0; i < kBlock; ++i) { const int32_t v = part[i]; part[i] = run; run += v; }
+        *count = run;
+    }
+    __syncthreads();
+    int32_t run = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { const int32_t v = seg_count[i]; seg_count[i] = run; run += v; }
+}
+
+__global__ void __launch_bounds__(kBlock)
+leaves_scatter_kernel(const uint8_t* __restrict__ mask, int64_t n, int N, const int32_t* __restrict__ seg_offset,
+                      int64_t* __restrict__ leaf_node) {
+    __shared__ int32_t wbase[kBlock / 64];
+    const int64_t base = (int64_t)blockIdx.x * kSeg;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t running = seg_offset[blockIdx.x];
+    // 4 rounds of 256 consecutive entries keep the output in increasing slot order
+    for (int rd = 0; rd < kSeg / kBlock; ++rd) {
+        const int64_t i = base + rd * kBlock + threadIdx.x;
+        const bool hit = i < n && mask[i] != 0;
+        const unsigned long long b = __ballot(hit);
+        if (lane == 0) wbase[wave] = __popcll(b);
+        __syncthreads();
+        int32_t before = 0, total = 0;
+        for (int w = 0; w < kBlock / 64; ++w) { if (w < wave) before += wbase[w]; total += wbase[w]; }
+        if (hit) {
+            const int64_t dst = running + before + __popcll(b & ((1ull << lane) - 1ull));
+            int64_t tmp = i;
+            const int64_t w3 = tmp % N; tmp /= N;
+            const int64_t v3 = tmp % N; tmp /= N;
+            const int64_t u3 = tmp % N; tmp /= N;
+            leaf_node[4 * dst + 0] = tmp;
+            leaf_node[4 * dst + 1] = u3;
+            leaf_node[4 * dst + 2] = v3;
+            leaf_node[4 * dst + 3] = w3;
+        }
+        running += total;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// [M, stride] -> dense [M, K] (the backward accumulates into 64-byte-aligned rows)
+// ---------------------------------------------------------------------------
+
+// streaming copy: non-temporal both ways, the data is not re-read by these kernels
+template <typename V>
+__global__ void __launch_bounds__(kBlock)
+compact_rows_kernel(const V* __restrict__ src, int64_t n, int Kv, int stride_v, V* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / Kv;
+        const int c = (int)(i - r * Kv);
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + r * stride_v + c), dst + i);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Acceleration grid build (N == 2): one thread per cell, see locate_accel()
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(kBlock)
+accel_build_kernel(TreeDev tr, int G, uint2* __restrict__ cells) {
+    const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= (1u << (3 * G))) return;
+    const uint32_t mask = (1u << G) - 1u;
+    const uint32_t cz = c & mask, cy = (c >> G) & mask, cx = c >> (2 * G);
+    int32_t node = 0;
+    for (int k = 1; k <= G; ++k) {
+        const int sh = G - k;
+        const uint32_t c3 = (((cx >> sh) & 1u) << 2) | (((cy >> sh) & 1u) << 1) | ((cz >> sh) & 1u);
+        const uint32_t slot = ((uint32_t)node << 3) + c3;
+        const int32_t skip = tr.child[slot];
+        if (skip == 0) {
+            cells[c] = make_uint2((uint32_t)tr.data[slot], kAccelLeaf | (uint32_t)k);
+            return;
+        }
+        node += skip;
+    }
+    cells[c] = make_uint2((uint32_t)node, 0u);
+}
+
+// ... and the (child, data) pairs the descent below the grid reads
+__global__ void __launch_bounds__(kBlock)
+accel_nodes_kernel(const int32_t* __restrict__ child, const int32_t* __restrict__ data, int64_t n,
+                   uint2* __restrict__ nodes) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) nodes[i] = make_uint2((uint32_t)child[i], (uint32_t)data[i]);
+}
+
+}  // namespace svoxt
