@@ -283,13 +283,24 @@ render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __re
 // STOP: apply the early-termination rule (T <= stop_thresh ends the ray, rt_kernel.cu:313-319)
 // while marching, with the transmittance formed exactly as the shade kernel forms it.  Off when
 // the lists are for a backward, which wants every sample with sigma > 0 (:382,456).
-// One bit per feature row: sigma > thresh (svoxt_sigma_mask_build).  A wavefront's 64 rows are one 8-byte word.
+// One bit per feature row: sigma > thresh (svoxt_sigma_mask_build).  A wavefront takes four groups of 64
+// rows -- four independent loads per lane in flight, one 8-byte word per group -- 1024 rows per workgroup.
 __global__ void __launch_bounds__(256)
 sigma_mask_kernel(const float* __restrict__ features, int64_t M, int K, float thresh, unsigned long long* __restrict__ mask) {
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool on = row < M && features[row * K + (K - 1)] > thresh;
-    const unsigned long long b = __ballot(on);
-    if ((threadIdx.x & 63) == 0 && (row >> 6) < (M + 63) / 64) mask[row >> 6] = b;
+    const int lane = threadIdx.x & 63;
+    const int64_t word0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;      // first of this wavefront's four words
+    const int64_t words = (M + 63) / 64;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t row = (word0 + j) * 64 + lane;
+        v[j] = row < M ? features[row * K + (K - 1)] : thresh;       // (thresh > thresh is false: no bit)
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long b = __ballot(v[j] > thresh);
+        if (lane == j && word0 + j < words) mask[word0 + j] = b;
+    }
 }
 
 // MASK (no stop rule): whether a row's sigma exceeds sigma_thresh comes from one bit per feature row

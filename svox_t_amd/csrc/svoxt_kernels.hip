@@ -847,7 +847,7 @@ int svoxt_sigma_mask_build(const svoxt_tree* tree, float sigma_thresh, void* mas
     if (tree->M == 0) return SVOXT_OK;
     if (mask == nullptr || ((uintptr_t)mask & 7u) != 0) return fail(SVOXT_ERR_INVALID, "%s: mask is NULL or not 8-byte aligned", fn);
     const int64_t words = (tree->M + 63) / 64;
-    hipLaunchKernelGGL(svoxt::sigma_mask_kernel, dim3((unsigned)((words + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(svoxt::sigma_mask_kernel, dim3((unsigned)((words + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
                        tree->features, tree->M, tree->K, sigma_thresh, reinterpret_cast<unsigned long long*>(mask));
     return check_launch(fn);
 }
