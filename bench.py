@@ -288,8 +288,8 @@ def main():
                 "row_compaction": (4 * M * stride + 4 * M * K) if stride != K else 0,
             }
             if "grad_wide_kernel" in (route_bwd or "") or "ONEPASS" in (route_bwd or ""):
-                # sweep 1 -> sweep 2: the second pass's total_color, 4 bytes per sample, written and read
-                bwd_parts["sweep_handover"] = 8 * A
+                # sweep 1 -> sweep 2: (attenuation,) second-pass total_color per sample, written and read
+                bwd_parts["sweep_handover"] = (16 if "grad_wide_kernel" in route_bwd else 8) * A
             if atomic_requests is None or not atomic_requests:
                 bwd_parts["atomic_requests_note"] = "one row per sample (not counted on the device for this route; " \
                     "grad_wide_kernel merges rows per tile and window of 16 list positions: exp/reuse_probe.py)"

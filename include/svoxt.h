@@ -234,7 +234,11 @@ typedef struct svoxt_sample_lists {
                               backward, told so by terms_state = 2 or 3 (what svoxt_fwd_fills_terms returned:
                               the layout the forward wrote), then gathers no feature row and forms no
                               exponential in either of its sweeps.  terms_state = 0: scratch only -- the
-                              backward's first sweep fills it for the second.  Same bits every way. */
+                              backward's first sweep fills it for the second.  Same bits every way.
+                              RGBA rows of 8 / 16 / 32 floats (C = 7 / 15 / 31): scratch between the two sweeps of
+                              their exact backwards, 8 bytes per record slot for the per-tile kernel (attenuation,
+                              second-pass total_color), 4 for the per-ray one; NULL or smaller: the per-ray list
+                              replay that forms every sigmoid twice. */
     int64_t terms_bytes;
     /* Pooled lists (optional, ABI v12).  blocktab NULL: dense -- rec holds max_samples slots for every
      * ray, as described above.  blocktab given: device int32 [ceil(Q / 64) * max_samples / 8]; entry

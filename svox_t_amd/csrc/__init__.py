@@ -862,8 +862,9 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
                 (BWD_GATHER == 2 or (BWD_GATHER == 1 and coherent))
             if wide and fo is None and BWD_TERMS and not gather:
                 # one sigmoid pass instead of two: the first sweep leaves a float per list slot for the second
-                if lists.terms is None or lists.terms.numel() < lists.pool_blocks * 512:
-                    lists.terms = torch.empty((lists.pool_blocks * 512,), dtype=torch.float32, device=dev)
+                need = lists.pool_blocks * 512 * (2 if wide_tile else 1)       # (attenuation, total_color) / total_color alone
+                if lists.terms is None or lists.terms.numel() < need:
+                    lists.terms = torch.empty((need,), dtype=torch.float32, device=dev)
                 lists.terms_state = 0
             if gather and not fused:
                 # with view rotations a second plane holds each sample's rotated direction

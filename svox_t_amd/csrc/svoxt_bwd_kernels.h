@@ -1157,10 +1157,10 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 //            records are compacted; lane = RECORD forms the C sigmoids of its row ONCE -- every
 //            lane busy, the row as K / 4 loads, upstream gradients from LDS -- and from them both
 //            total_colors the reference forms (float sigmoids :424, double quotients :470);
-//            wavefront 0 then runs along the rays (weight, transmittance, accum).  The second
-//            pass's total_color goes to L.terms, one float per record (position-major).
-//   sweep 2  (:439-494 + the colour entries :419-425) per window: lane = ray forms the attenuation
-//            again (sigma gather) and enters the record's feature row in a hash table; wavefront
+//            wavefront 0 then runs along the rays (weight, transmittance, accum).  The attenuation
+//            and the second pass's total_color go to L.terms, 8 bytes per record (position-major).
+//   sweep 2  (:439-494 + the colour entries :419-425) per window: lane = ray takes the attenuation
+//            from the hand-over and enters the record's feature row in a hash table; wavefront
 //            0 runs along the rays (accum -= weight * total_color; sigma entries); counting sort
 //            by feature row; then lane = COLUMN: a group of K lanes takes one distinct row, forms
 //            the sigmoid of its column once per (tile, window, row), adds up the row's records
@@ -1188,7 +1188,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
     __shared__ float gl[64 * KG];
     __shared__ float dsl[64];
     __shared__ int32_t s_nb, s_ns;
-    float* __restrict__ tot2 = reinterpret_cast<float*>(L.terms);
+    float2* __restrict__ tot2 = reinterpret_cast<float2*>(L.terms);      // (attenuation, second-pass total_color) per record
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int32_t tabreg = rec_tab_reg(L, blockIdx.x, lane);
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * 64 + lane);
@@ -1305,7 +1305,8 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
             const int k = k0 + rd * W + wave;
             if (k < nrec) {
                 const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
-                tot2[terms_index_pm(blk, lane, k)] = r_sg[(rd * W + wave) * 64 + lane];
+                const int sl = (rd * W + wave) * 64 + lane;
+                tot2[terms_index_pm(blk, lane, k)] = make_float2(r_w[sl], r_sg[sl]);
             }
         }
         if (wave == 0) {
@@ -1348,40 +1349,35 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
     for (int k0 = 0; k0 < maxn; k0 += RPP * W) {
         {   // the window's two rounds together: records and hand-over first, then the sigma gathers, then the table
             uint2 e[RPP];
-            float t2[RPP], sigma[RPP];
+            float2 h[RPP];
             bool have[RPP];
 #pragma unroll
             for (int rd = 0; rd < RPP; ++rd) {
                 const int k = k0 + rd * W + wave;
                 have[rd] = k < nrec;
                 e[rd] = make_uint2(0u, 0u);
-                t2[rd] = 0.f;
+                h[rd] = make_float2(0.f, 0.f);
                 if (have[rd]) {
                     const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
                     e[rd] = rec_get(L.rec + rec_index_in(blk, lane, k));
-                    t2[rd] = tot2[terms_index_pm(blk, lane, k)];
+                    h[rd] = tot2[terms_index_pm(blk, lane, k)];
                 }
-            }
-#pragma unroll
-            for (int rd = 0; rd < RPP; ++rd) {
-                sigma[rd] = 0.f;
-                if (have[rd]) sigma[rd] = tr.features[(int64_t)(int32_t)e[rd].x * K + (K - 1)];
             }
 #pragma unroll
             for (int rd = 0; rd < RPP; ++rd) {
                 if (have[rd]) {
                     const int32_t idx = (int32_t)e[rd].x;
-                    uint32_t h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
+                    uint32_t h32 = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
                     while (true) {
-                        const int32_t old = atomicCAS(keys + h, -1, idx);
+                        const int32_t old = atomicCAS(keys + h32, -1, idx);
                         if (old == -1 || old == idx) break;
-                        h = (h + 1u) & (uint32_t)(T - 1);
+                        h32 = (h32 + 1u) & (uint32_t)(T - 1);
                     }
-                    atomicAdd(cnt + h, 1);
+                    atomicAdd(cnt + h32, 1);
                     const int slot = (rd * W + wave) * 64 + lane;
-                    r_sl[slot] = (h << 6) | (uint32_t)lane;
-                    r_w[slot] = pexpf<true>(-__uint_as_float(e[rd].y) * sigma[rd] * ds);
-                    r_sg[slot] = t2[rd];
+                    r_sl[slot] = (h32 << 6) | (uint32_t)lane;
+                    r_w[slot] = h[rd].x;              // the attenuation sweep 1 formed: no sigma gather here
+                    r_sg[slot] = h[rd].y;
                     r_dt[slot] = __uint_as_float(e[rd].y);
                 }
             }

@@ -181,7 +181,7 @@ inline RecLists lists_dev(const svoxt_sample_lists* l, int64_t Q, int term_bytes
     L.pool_next = reinterpret_cast<int32_t*>(l->pool_next);
     L.pool_blocks = l->blocktab != nullptr ? l->pool_blocks : rec_rays(Q) / 64 * (l->max_samples / kRecBlock);
     L.S = l->max_samples;
-    // term_bytes (16; 4 for the one-sigmoid-pass backward of wide rows) per record slot, 16-byte aligned, or not at all
+    // term_bytes (16; 8 / 4 for the backwards of wide rows) per record slot, 16-byte aligned, or not at all
     const bool have_terms = l->terms != nullptr && ((uintptr_t)l->terms & 15u) == 0 &&
                             l->terms_bytes >= L.pool_blocks * (int64_t)(64 * kRecBlock) * term_bytes;
     L.terms = have_terms ? reinterpret_cast<float4*>(l->terms) : nullptr;
@@ -637,8 +637,11 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
         const int64_t S = workspace != nullptr ? rec_capacity(workspace_bytes, rays->Q) : 0;
         const RecLists wl = dense_lists(S > 0 ? workspace : nullptr, S, rays->Q);
         if (lists != nullptr) {
-            const bool wide = opt->format == SVOXT_FORMAT_RGBA && C > 3;     // one float per slot (render_bwd_kernel<ONEPASS>)
-            const RecLists ll = lists_dev(lists, rays->Q, wide ? 4 : 16);
+            // hand-over per list slot: 16 bytes for 3-channel payloads; RGBA rows of 8 / 16 / 32 floats: 8 for the
+            // per-tile kernel (grad_wide_kernel), 4 for the per-ray one (render_bwd_kernel<ONEPASS>)
+            const bool wide = opt->format == SVOXT_FORMAT_RGBA && C > 3;
+            const RecLists ll = lists_dev(lists, rays->Q, wide ? 8 : 16);
+            const RecLists l1 = wide ? lists_dev(lists, rays->Q, 4) : ll;
             const uint4* laux = reinterpret_cast<const uint4*>(lists->aux);
             // coef_bytes < 0 (and no coef): the per-tile route if it can run fused, which needs no buffer
             const bool have_coef = lists->coef != nullptr &&
@@ -648,8 +651,8 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
                 done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, ll, laux,
                                          fwd_out, have_coef ? reinterpret_cast<float4*>(lists->coef) : nullptr, false, st,
                                          (lists->terms_state == 2 || lists->terms_state == 3) ? lists->terms_state : 1);
-            if (!done) done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, gs, ll, laux, fwd_out, st)
-                      : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, gs, ll, laux, fwd_out, st);
+            if (!done) done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, gs, l1, laux, fwd_out, st)
+                      : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, gs, l1, laux, fwd_out, st);
             if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no specialised kernel for this payload", fn);
         } else {
             done = n2 ? launch_bwd_special<true, false>(tr, rd, od, C, grad_out, grad_features, gs, wl, nullptr, nullptr, st)
