@@ -687,3 +687,32 @@ def test_ray_order_is_a_permutation_and_changes_no_result(gpu, fmt, K):
     # images are walked in tiles already: the ordering entry point refuses them
     with pytest.raises(RuntimeError):
         _C.ray_order(tree._spec(tree.features), _rays_spec_from_rays(rays, image_shape=(96, 96)), opt)
+
+
+@pytest.mark.parametrize("M,K", [(1, 4), (63, 8), (64, 28), (1000, 32), (70001, 28)])
+def test_sigma_mask_build_bits(gpu, M, K):
+    """svoxt_sigma_mask_build: bit (row & 31) of 32-bit word (row >> 5) = features[row, K-1] > thresh, for
+    row counts that are not multiples of the 1024 rows a workgroup covers; bits past M are clear; NaN
+    sigmas and a NaN threshold give no bit (the comparison the march makes is `sigma > thresh`)."""
+    import ctypes
+    rng = np.random.default_rng(M)
+    f = rng.standard_normal((M, K)).astype(np.float32)
+    if M > 10:
+        f[3, -1] = np.nan
+        f[5, -1] = np.inf
+        f[7, -1] = 0.25                      # equal to the threshold: not greater
+    feats = torch.from_numpy(f).to(gpu)
+    ct = _C._CTree(features=feats.data_ptr(), M=M, K=K, N=2, data=feats.data_ptr(), child=feats.data_ptr(), n_internal=1,
+                   offset=feats.data_ptr(), scaling=feats.data_ptr())
+    nbytes = _C._lib.svoxt_sigma_mask_bytes(M)
+    assert nbytes == (M + 63) // 64 * 8
+    for thresh in (0.0, 0.25, float("nan")):
+        mask = torch.full((nbytes // 8,), -1, dtype=torch.int64, device=gpu)
+        _C._call("svoxt_sigma_mask_build", ctypes.byref(ct), ctypes.c_float(thresh), mask.data_ptr(), None)
+        torch.cuda.synchronize()
+        words = mask.cpu().numpy().view(np.uint32)
+        bits = ((words[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(-1).astype(bool)
+        with np.errstate(invalid="ignore"):
+            want = f[:, -1] > np.float32(thresh)
+        np.testing.assert_array_equal(bits[:M], want)
+        assert not bits[M:].any()
