@@ -338,17 +338,18 @@ def _accel_for(tree: TreeSpec, ct: _CTree):
     ent = _ACCEL_CACHE.get(key)
     if ent is not None:
         cref, cv, dref, dv, n_int, eg, cells = ent
-        if cref() is tree.child and cv == tree.child._version and dref() is tree.data \
-                and dv == tree.data._version and n_int == ct.n_internal and eg == g:
+        if cref() is tree.child and cv == (tree.child._version, tree.child.data_ptr()) and dref() is tree.data \
+                and dv == (tree.data._version, tree.data.data_ptr()) and n_int == ct.n_internal and eg == g:
             return cells, g
     dev = tree.child.device
     with torch.cuda.device(dev):
         nbytes = _lib.svoxt_accel_bytes(g, ct.n_internal)       # grid cells + (child, data) pairs
         cells = torch.empty((nbytes // 8, 2), dtype=torch.int32, device=dev)
         _call("svoxt_accel_build", ctypes.byref(ct), g, _ptr(cells), _stream(dev))
+    # (versions AND data pointers: `tensor.data = other` swaps the storage without touching the version counter)
     _ACCEL_CACHE[key] = (weakref.ref(tree.child, lambda _r, _k=key: _ACCEL_CACHE.pop(_k, None)),
-                         tree.child._version, weakref.ref(tree.data), tree.data._version,
-                         ct.n_internal, g, cells)
+                         (tree.child._version, tree.child.data_ptr()), weakref.ref(tree.data),
+                         (tree.data._version, tree.data.data_ptr()), ct.n_internal, g, cells)
     return cells, g
 
 
@@ -384,7 +385,7 @@ def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool) ->
     mask = None
     if keep:
         ent = _SIGMA_CACHE.get(key)
-        if ent is not None and ent[0]() is f and ent[1] == f._version and ent[2] == thresh:
+        if ent is not None and ent[0]() is f and ent[1] == (f._version, f.data_ptr()) and ent[2] == thresh:
             mask = ent[3]
     if mask is None:
         dev = f.device
@@ -392,7 +393,9 @@ def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool) ->
             mask = torch.empty((_lib.svoxt_sigma_mask_bytes(ct.M) // 8,), dtype=torch.int64, device=dev)
             _call("svoxt_sigma_mask_build", ctypes.byref(ct), ctypes.c_float(thresh), _ptr(mask), _stream(dev))
         if keep:
-            _SIGMA_CACHE[key] = (weakref.ref(f, lambda _r, _k=key: _SIGMA_CACHE.pop(_k, None)), f._version, thresh, mask)
+            # (the data pointer too: `param.data = other` swaps the storage without touching the version counter)
+            _SIGMA_CACHE[key] = (weakref.ref(f, lambda _r, _k=key: _SIGMA_CACHE.pop(_k, None)),
+                                 (f._version, f.data_ptr()), thresh, mask)
     ct.sigma_mask = mask.data_ptr()
     ct.sigma_mask_thresh = thresh
     ct._keepalive_mask = mask

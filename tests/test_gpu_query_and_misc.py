@@ -540,6 +540,17 @@ def test_acceleration_grid_never_goes_stale(gpu):
         got = r(tree.features, rays).cpu().numpy()
     ot = O.Tree(c.features.numpy(), tree.data[:n].cpu().numpy(), tree.child[:n].cpu().numpy())
     np.testing.assert_array_equal(got, O.volume_render(ot, *c.rays_np(), opt))
+    # `tensor.data = other` swaps the storage WITHOUT bumping the version counter: the cache is keyed on the
+    # data pointer as well
+    with torch.no_grad():
+        other = tree.data.clone()
+        other[other == 7] = 11
+        v0 = tree.data._version
+        tree.data.data = other
+        assert tree.data._version == v0
+        got = r(tree.features, rays).cpu().numpy()
+    ot = O.Tree(c.features.numpy(), tree.data[:n].cpu().numpy(), tree.child[:n].cpu().numpy())
+    np.testing.assert_array_equal(got, O.volume_render(ot, *c.rays_np(), opt))
 
 
 @pytest.mark.parametrize("fmt,K,depth,mode", [

@@ -440,3 +440,10 @@ def test_sigma_bitmask_changes_nothing(name, gpu, monkeypatch):
     want2 = O.volume_render(O.Tree(f2, ot.data, ot.child, offset=ot.offset, scaling=ot.scaling), *c.rays_np(), c.oracle_opts())
     np.testing.assert_array_equal(got.cpu().numpy(), want2)
     assert not np.array_equal(want2, want)
+    # ... nor a storage swap, which leaves the version counter alone
+    with torch.no_grad():
+        v0 = tree.features._version
+        tree.features.data = torch.from_numpy(ot.features.copy()).to(gpu)        # back to the original values
+        assert tree.features._version == v0
+        got = r(tree.features, rays, image_shape=shape)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
