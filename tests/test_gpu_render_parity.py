@@ -447,3 +447,35 @@ def test_sigma_bitmask_changes_nothing(name, gpu, monkeypatch):
         assert tree.features._version == v0
         got = r(tree.features, rays, image_shape=shape)
     np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("name", ["d5_sh9", "d5_rgba8", "d5_rgba4"])
+@pytest.mark.parametrize("pool", ["dense", "dry", "tiny"])
+def test_sample_list_pool_runs_dry_or_is_dense(name, pool, gpu, monkeypatch):
+    """Sample lists are blocks of 8 positions x 64 rays handed out from a pool sized by what earlier
+    forwards used.  A pool that is too small -- here 32 blocks (one per sub-pool: most tiles get none) or
+    64 -- only means that rays stop recording early, exactly as at the per-ray cap: the tail launches take
+    over, the forward stays bit-identical and the backward within tolerance.  Dense lists
+    (SVOXT_LIST_POOL=0: every ray owns its slots) give the same."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd import synth
+    if pool == "dense":
+        monkeypatch.setattr(_C, "LIST_POOL", False)
+    else:
+        monkeypatch.setattr(_C, "_pool_blocks_for", lambda tiles, S: 32 if pool == "dry" else 64)
+    c = Case(**CASES[name])
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    shape = (CASES[name]["height"], CASES[name]["width"])
+    want = O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts())
+    g = synth.grad_output(c.Q, want.shape[1])
+    gw, _, tight = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.numpy(), want_abs="both")
+    for image in (True, False):
+        tree.features.grad = None
+        out = r(tree.features, c.rays_gpu(gpu), image_shape=shape if image else None)
+        np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
+        out.backward(g.to(gpu))
+        assert_grads_close(tree.features.grad.cpu().numpy(), gw, tight, what=f"{pool}, image={image}")
+    # scratch lists of a forward nobody differentiates (the two-kernel forward where it is the default)
+    with torch.no_grad():
+        np.testing.assert_array_equal(r(tree.features, c.rays_gpu(gpu), image_shape=shape).cpu().numpy(), want)
