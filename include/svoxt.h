@@ -381,7 +381,8 @@ int     svoxt_accel_build(const svoxt_tree* tree, int32_t log2_res, void* cells,
  * marching kernels put 64 consecutive rays on one wavefront; a batch in arbitrary order
  * (rays drawn at random from many cameras) then diverges at every step.  svoxt_ray_order
  * writes to perm [Q] (device, int32) the permutation that sorts the batch by the Morton
- * code of the point where each ray enters the tree's cube (rays that miss it last): gather
+ * code (7 bits per axis) of the point where each ray enters the tree's cube (rays that miss it last;
+ * the order of the rays of one cell is not fixed from run to run): gather
  * origins / dirs / vdirs with it, render the sorted batch through any entry point above and
  * scatter the output rows back -- results are per ray and do not depend on the order.
  * workspace: device, svoxt_ray_order_workspace_bytes(Q) bytes (-1: Q out of range or no
@@ -390,6 +391,13 @@ int     svoxt_accel_build(const svoxt_tree* tree, int32_t log2_res, void* cells,
 int64_t svoxt_ray_order_workspace_bytes(int64_t Q);
 int     svoxt_ray_order(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
                         int32_t* perm, void* workspace, int64_t workspace_bytes, void* stream);
+/* The gathers and the scatter that go with it: origins / dirs / vdirs [Q, 3] of the sorted batch
+ * (row i = row perm[i] of the caller's) in one launch, and rows of `cols` floats either way --
+ * scatter = 0: dst[i, :] = src[perm[i], :]; scatter = 1: dst[perm[i], :] = src[i, :]. */
+int     svoxt_gather_rays(const svoxt_rays* rays, const int32_t* perm, float* origins, float* dirs, float* vdirs,
+                          void* stream);
+int     svoxt_permute_rows(const float* src, const int32_t* perm, float* dst, int64_t n, int32_t cols,
+                           int32_t scatter, void* stream);
 
 /* ---- Octree construction from a point cloud -------------
  *

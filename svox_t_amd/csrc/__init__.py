@@ -131,6 +131,8 @@ EXPORTS = {
     "svoxt_set_bwd_counters": (ctypes.c_int, [_vp]),
     "svoxt_ray_order_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "svoxt_ray_order": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, ctypes.c_int64, _vp]),
+    "svoxt_gather_rays": (ctypes.c_int, [_P(_CRays), _vp, _vp, _vp, _vp, _vp]),
+    "svoxt_permute_rows": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _vp]),
     "svoxt_accel_bytes": (ctypes.c_int64, [_i32, ctypes.c_int64]),
     "svoxt_accel_build": (ctypes.c_int, [_P(_CTree), _i32, _vp, _vp]),
     "svoxt_build_workspace_bytes": (ctypes.c_int64, [_i32]),
@@ -597,6 +599,11 @@ def ray_order(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tenso
     """Permutation (int64 [Q], for torch indexing) that sorts a ray batch by the Morton code of
     each ray's entry point into the tree's cube (include/svoxt.h, svoxt_ray_order): 64
     consecutive rays of the sorted batch cross the same leaves.  Not in the reference."""
+    return _ray_order32(tree, rays, opt).long()
+
+
+def _ray_order32(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
+    """... as the library writes it (int32), for svoxt_gather_rays / svoxt_permute_rows."""
     ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
     with torch.cuda.device(dev):
@@ -607,7 +614,20 @@ def ray_order(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tenso
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
         _call("svoxt_ray_order", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co), _ptr(perm), _ptr(ws),
               nbytes, _stream(dev))
-    return perm.long()
+    return perm
+
+
+def _permute_rows(src: torch.Tensor, perm32: torch.Tensor, scatter: bool) -> torch.Tensor:
+    """dst[i] = src[perm[i]] (scatter False) or dst[perm[i]] = src[i] over rows of a float32 [Q, cols] tensor
+    (the library's kernel: torch's index kernels take 0.136 ms for 640 000 16-byte rows on this target)."""
+    if src.dtype != torch.float32 or src.dim() != 2 or not src.is_contiguous():
+        src = src.contiguous().float()
+    dev = src.device
+    with torch.cuda.device(dev):
+        dst = torch.empty_like(src)
+        _call("svoxt_permute_rows", _ptr(src), _ptr(perm32), _ptr(dst), src.shape[0], src.shape[1], 1 if scatter else 0,
+              _stream(dev))
+    return dst
 
 
 # ---------------------------------------------------------------------------
@@ -662,11 +682,13 @@ def _in_coherent_order(tree, rays, opt):
     (perm: sorted position -> position in the caller's batch), else as it is."""
     if not _wants_sort(rays):
         return rays, None
-    perm = ray_order(tree, rays, opt)
+    perm = _ray_order32(tree, rays, opt)
     s = RaysSpec()
-    s.origins = rays.origins.index_select(0, perm)
-    s.dirs = rays.dirs.index_select(0, perm)
-    s.vdirs = rays.vdirs.index_select(0, perm)
+    cr = _pack_rays(rays)
+    dev = rays.origins.device
+    with torch.cuda.device(dev):
+        s.origins, s.dirs, s.vdirs = (torch.empty((cr.Q, 3), dtype=torch.float32, device=dev) for _ in range(3))
+        _call("svoxt_gather_rays", ctypes.byref(cr), _ptr(perm), _ptr(s.origins), _ptr(s.dirs), _ptr(s.vdirs), _stream(dev))
     s.sort = False
     s.coherent = True           # neighbouring rays revisit the same leaves: the per-tile backward pays
     return s, perm
@@ -675,9 +697,7 @@ def _in_coherent_order(tree, rays, opt):
 def _to_caller_order(out_sorted, perm):
     if perm is None:
         return out_sorted
-    out = torch.empty_like(out_sorted)
-    out[perm] = out_sorted
-    return out
+    return _permute_rows(out_sorted, perm, scatter=True)
 
 
 def _need_grad(tree, rays):
@@ -814,7 +834,7 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
         p = _take_plan(tree, rays, opt)
         if p is not None:
             _check_input(grad_output, "grad_output")
-            g = grad_output if p.perm is None else grad_output.index_select(0, p.perm)
+            g = grad_output if p.perm is None else _permute_rows(grad_output, p.perm, scatter=False)
             fo = p.out if (p.lists is not None and p.out._version == p.over) else None
             if fo is not None and fo.dim() == 3:
                 fo = fo.view(-1, fo.shape[2])
@@ -971,7 +991,7 @@ def opacity_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
         p = _take_plan(tree, rays, opt)
         if p is not None:
             _check_input(grad_output, "grad_output")
-            g = grad_output if p.perm is None else grad_output.index_select(0, p.perm)
+            g = grad_output if p.perm is None else _permute_rows(grad_output, p.perm, scatter=False)
             return _opacity_render_backward(tree, p.rays, opt, g, p.lists)
     return _opacity_render_backward(tree, rays, opt, grad_output, lists)
 

@@ -13,17 +13,20 @@
 // backward); rays drawn from 8 cameras: 1.70 -> 1.35 ms.
 //
 // No counterpart in the reference (which marches rays in the order given).
-// The sort itself is rocPRIM's radix sort (the vendor primitive; keys + permutation).
+// The sort is a counting sort on the 22-bit cell key: count (a returning atomic per ray gives its rank in
+// the cell), exclusive scan of the 4 M counters (rocPRIM, the vendor primitive), scatter -- 4 launches and
+// ~0.04 ms for 640 000 rays where a radix sort of (key, id) pairs takes 21 launches and 0.14 ms.
 
 #include <cstring>
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "svoxt_host.h"
 
 namespace svoxt {
 
 constexpr int kOrderBlock = 256;
+constexpr int kOrderBits = 21;          // Morton bits of the key
 
 __device__ __forceinline__ uint32_t spread10(uint32_t x) {      // 10 bits -> every third bit
     x &= 0x3ffu;
@@ -34,23 +37,90 @@ __device__ __forceinline__ uint32_t spread10(uint32_t x) {      // 10 bits -> ev
     return x;
 }
 
+// key of ray q and its rank among the rays of the same cell.  Neighbouring rays share cells (and all
+// rays that miss the cube share the last one), so a wavefront first groups its lanes by key and sends ONE
+// returning atomic per distinct key (64 colliding atomics per wavefront: 0.35 ms for 640 000 rays).  Which wavefront reaches a cell first is not fixed from run to run -- results are per ray and do
+// not depend on the order within a cell.
 __global__ void __launch_bounds__(kOrderBlock)
-ray_key_kernel(TreeDev tr, RaysDev rays, Opts opt, uint32_t* __restrict__ keys, int32_t* __restrict__ ids) {
+ray_key_kernel(TreeDev tr, RaysDev rays, Opts opt, uint32_t* __restrict__ keys, uint32_t* __restrict__ ranks,
+               uint32_t* __restrict__ counts) {
     const int64_t q = (int64_t)blockIdx.x * kOrderBlock + threadIdx.x;
-    if (q >= rays.Q) return;
+    const bool in = q < rays.Q;
     Ray r;
-    uint32_t key = 0xffffffffu;                      // misses go last (their wavefronts end at once)
-    if (setup_ray(tr, rays, opt, q, r)) {
+    uint32_t key = 1u << kOrderBits;                 // misses go last (their wavefronts end at once)
+    if (in && setup_ray(tr, rays, opt, q, r)) {
         const float t = r.tmin;                      // >= 0: the origin itself when it lies inside
         const float px = fminf(fmaxf(r.ox + t * r.dx, 0.f), kClampHi);
         const float py = fminf(fmaxf(r.oy + t * r.dy, 0.f), kClampHi);
         const float pz = fminf(fmaxf(r.oz + t * r.dz, 0.f), kClampHi);
-        key = (spread10((uint32_t)(px * 1024.f)) << 2) | (spread10((uint32_t)(py * 1024.f)) << 1) |
-              spread10((uint32_t)(pz * 1024.f));
+        // 7 bits per axis: cells of 1/128 of the cube -- a 64-ray group of the sorted batch spans a handful of
+        // neighbouring cells; finer keys would order rays WITHIN what a wavefront holds anyway
+        key = (spread10((uint32_t)(px * 128.f)) << 2) | (spread10((uint32_t)(py * 128.f)) << 1) |
+              spread10((uint32_t)(pz * 128.f));
     }
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    // group the lanes by key first (no memory operation in the loop), then all group leaders send their
+    // atomics in ONE instruction -- one round trip per wavefront instead of one per distinct key
+    int my_leader = lane;
+    uint32_t my_rank = 0, my_count = 0;
+    unsigned long long todo = __ballot(in);
+    while (todo != 0ull) {                           // (wavefront-uniform: one turn per distinct key)
+        const int leader = (int)__builtin_ctzll(todo);
+        const uint32_t k = (uint32_t)__shfl((int)key, leader, 64);
+        const bool mine = in && key == k;
+        const unsigned long long m = __ballot(mine);
+        if (mine) {
+            my_leader = leader;
+            my_rank = (uint32_t)__popcll(m & lane_lt);
+            my_count = (uint32_t)__popcll(m);
+        }
+        todo &= ~m;
+    }
+    uint32_t base = 0;
+    if (in && lane == my_leader) base = atomicAdd(counts + key, my_count);
+    base = (uint32_t)__shfl((int)base, my_leader, 64);
+    const uint32_t rank = base + my_rank;
+    if (!in) return;
     keys[q] = key;
-    ids[q] = (int32_t)q;
+    ranks[q] = rank;
 }
+
+__global__ void __launch_bounds__(kOrderBlock)
+ray_place_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ranks,
+                 const uint32_t* __restrict__ starts, int64_t Q, int32_t* __restrict__ perm) {
+    const int64_t q = (int64_t)blockIdx.x * kOrderBlock + threadIdx.x;
+    if (q < Q) perm[starts[keys[q]] + ranks[q]] = (int32_t)q;
+}
+
+// dst[i, :] = src[perm[i], :] (GATHER) or dst[perm[i], :] = src[i, :]: rows of `cols` floats, one thread per float
+template <bool GATHER>
+__global__ void __launch_bounds__(kOrderBlock)
+permute_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ perm, float* __restrict__ dst,
+                    int64_t n, int cols) {
+    const int64_t i = (int64_t)blockIdx.x * kOrderBlock + threadIdx.x;
+    if (i >= n * cols) return;
+    const int64_t row = i / cols;
+    const int c = (int)(i - row * cols);
+    const int64_t other = perm[row];
+    if constexpr (GATHER) dst[i] = src[other * cols + c];
+    else dst[other * cols + c] = src[i];
+}
+
+// the three ray arrays in one launch: thread i < 3n takes float i of the sorted origins, dirs and vdirs
+__global__ void __launch_bounds__(kOrderBlock)
+gather_rays_kernel(RaysDev rays, const int32_t* __restrict__ perm, float* __restrict__ o, float* __restrict__ d,
+                   float* __restrict__ v) {
+    const int64_t i = (int64_t)blockIdx.x * kOrderBlock + threadIdx.x;
+    if (i >= rays.Q * 3) return;
+    const int64_t row = i / 3;
+    const int64_t from = (int64_t)perm[row] * 3 + (i - row * 3);
+    o[i] = rays.origins[from];
+    d[i] = rays.dirs[from];
+    v[i] = rays.vdirs[from];
+}
+
+constexpr size_t kOrderCells = ((size_t)1 << kOrderBits) + 1;    // one counter per cell, the last one for rays that miss the cube
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -63,11 +133,11 @@ extern "C" {
 int64_t svoxt_ray_order_workspace_bytes(int64_t Q) {
     if (Q < 0 || Q > 0x7fffffff) return -1;
     size_t temp = 0;
-    uint32_t* k = nullptr;
-    int32_t* v = nullptr;
-    if (Q > 0 && rocprim::radix_sort_pairs(nullptr, temp, k, k, v, v, (size_t)Q, 0, 32, (hipStream_t)0) != hipSuccess)
+    uint32_t* c = nullptr;
+    if (rocprim::exclusive_scan(nullptr, temp, c, c, 0u, kOrderCells, rocprim::plus<uint32_t>(), (hipStream_t)0) != hipSuccess)
         return -1;
-    return (int64_t)(3 * align256(sizeof(uint32_t) * (size_t)Q) + align256(temp));
+    // keys, ranks (per ray); counts, starts (per cell); the scan's scratch
+    return (int64_t)(2 * align256(sizeof(uint32_t) * (size_t)Q) + 2 * align256(sizeof(uint32_t) * kOrderCells) + align256(temp));
 }
 
 int svoxt_ray_order(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
@@ -81,20 +151,50 @@ int svoxt_ray_order(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_
     const int64_t need = svoxt_ray_order_workspace_bytes(rays->Q);
     if (need < 0 || workspace_bytes < need) return set_error(SVOXT_ERR_INVALID, "%s: workspace too small", fn);
     hipStream_t st = (hipStream_t)stream;
-    const size_t n = (size_t)rays->Q, plane = align256(sizeof(uint32_t) * n);
+    const size_t n = (size_t)rays->Q, plane = align256(sizeof(uint32_t) * n), cells = align256(sizeof(uint32_t) * kOrderCells);
     char* w = static_cast<char*>(workspace);
-    uint32_t* keys_in = reinterpret_cast<uint32_t*>(w);
-    uint32_t* keys_out = reinterpret_cast<uint32_t*>(w + plane);
-    int32_t* ids = reinterpret_cast<int32_t*>(w + 2 * plane);
-    void* temp = w + 3 * plane;
-    size_t temp_bytes = (size_t)workspace_bytes - 3 * plane;
+    uint32_t* keys = reinterpret_cast<uint32_t*>(w);
+    uint32_t* ranks = reinterpret_cast<uint32_t*>(w + plane);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(w + 2 * plane);
+    uint32_t* starts = reinterpret_cast<uint32_t*>(w + 2 * plane + cells);
+    void* temp = w + 2 * plane + 2 * cells;
+    size_t temp_bytes = (size_t)workspace_bytes - 2 * plane - 2 * cells;
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(uint32_t) * kOrderCells, st);
+    if (e != hipSuccess) return set_error(SVOXT_ERR_HIP, "%s: hipMemsetAsync: %s", fn, hipGetErrorString(e));
     TreeDev tr = to_dev(tree);
-    hipLaunchKernelGGL(ray_key_kernel, dim3((unsigned)((n + kOrderBlock - 1) / kOrderBlock)), dim3(kOrderBlock), 0, st,
-                       tr, to_dev(rays), to_dev(opt), keys_in, ids);
+    const unsigned nb = (unsigned)((n + kOrderBlock - 1) / kOrderBlock);
+    hipLaunchKernelGGL(ray_key_kernel, dim3(nb), dim3(kOrderBlock), 0, st, tr, to_dev(rays), to_dev(opt), keys, ranks, counts);
     if ((rc = check_launch(fn))) return rc;
-    const hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, ids, perm, n, 0, 32, st);
-    if (e != hipSuccess) return set_error(SVOXT_ERR_HIP, "%s: radix sort: %s", fn, hipGetErrorString(e));
-    return SVOXT_OK;
+    e = rocprim::exclusive_scan(temp, temp_bytes, counts, starts, 0u, kOrderCells, rocprim::plus<uint32_t>(), st);
+    if (e != hipSuccess) return set_error(SVOXT_ERR_HIP, "%s: scan: %s", fn, hipGetErrorString(e));
+    hipLaunchKernelGGL(ray_place_kernel, dim3(nb), dim3(kOrderBlock), 0, st, keys, ranks, starts, (int64_t)n, perm);
+    return check_launch(fn);
+}
+
+int svoxt_gather_rays(const svoxt_rays* rays, const int32_t* perm, float* origins, float* dirs, float* vdirs, void* stream) {
+    const char* fn = "svoxt_gather_rays";
+    int rc;
+    if ((rc = check_rays(rays, fn))) return rc;
+    if (rays->Q == 0) return SVOXT_OK;
+    if (rays->c2w != nullptr) return set_error(SVOXT_ERR_INVALID, "%s: camera mode has no ray arrays", fn);
+    if (perm == nullptr || origins == nullptr || dirs == nullptr || vdirs == nullptr)
+        return set_error(SVOXT_ERR_INVALID, "%s: NULL argument", fn);
+    const int64_t n = rays->Q * 3;
+    hipLaunchKernelGGL(gather_rays_kernel, dim3((unsigned)((n + kOrderBlock - 1) / kOrderBlock)), dim3(kOrderBlock), 0,
+                       (hipStream_t)stream, to_dev(rays), perm, origins, dirs, vdirs);
+    return check_launch(fn);
+}
+
+int svoxt_permute_rows(const float* src, const int32_t* perm, float* dst, int64_t n, int32_t cols, int32_t scatter, void* stream) {
+    const char* fn = "svoxt_permute_rows";
+    if (n < 0 || cols < 1) return set_error(SVOXT_ERR_INVALID, "%s: bad extents", fn);
+    if (n == 0) return SVOXT_OK;
+    if (src == nullptr || perm == nullptr || dst == nullptr) return set_error(SVOXT_ERR_INVALID, "%s: NULL argument", fn);
+    const int64_t tot = n * cols;
+    const unsigned nb = (unsigned)((tot + kOrderBlock - 1) / kOrderBlock);
+    if (scatter) hipLaunchKernelGGL((permute_rows_kernel<false>), dim3(nb), dim3(kOrderBlock), 0, (hipStream_t)stream, src, perm, dst, n, (int)cols);
+    else hipLaunchKernelGGL((permute_rows_kernel<true>), dim3(nb), dim3(kOrderBlock), 0, (hipStream_t)stream, src, perm, dst, n, (int)cols);
+    return check_launch(fn);
 }
 
 }  // extern "C"
