@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 14
+#define SVOXT_ABI_VERSION 15
 
 enum {
     SVOXT_OK = 0,
@@ -119,6 +119,13 @@ typedef struct svoxt_rays {
                                     before the warp, :1203); origins / dirs / vdirs are ignored, Q must be
                                     image_width * image_height, outputs are the [H, W, C+1] image. */
     float        fx, fy;         /* focal lengths in pixels (camera mode) */
+    const int32_t* order;        /* optional (ABI v15, no counterpart in the reference): device int32 [Q], a permutation
+                                    of 0 .. Q-1 (svoxt_ray_order's): launch thread i works on ray order[i], so
+                                    that the 64 rays of a wavefront are the ones the permutation puts next to
+                                    each other -- nothing is gathered or scattered, every ray's inputs and results
+                                    stay at the ray's own index.  Sample lists recorded with an order must be
+                                    replayed with the same one.  NULL: thread i takes ray i (or the image tiles
+                                    above); not allowed together with the image hint or camera mode. */
 } svoxt_rays;
 
 /* RenderOptions (data_spec.hpp:129-145), same fields in the same order. */

@@ -43,7 +43,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -67,7 +67,8 @@ class _CRays(ctypes.Structure):          # struct svoxt_rays
     _fields_ = [("origins", ctypes.c_void_p), ("dirs", ctypes.c_void_p),
                 ("vdirs", ctypes.c_void_p), ("Q", ctypes.c_int64),
                 ("image_width", ctypes.c_int32), ("image_height", ctypes.c_int32),
-                ("c2w", ctypes.c_void_p), ("fx", ctypes.c_float), ("fy", ctypes.c_float)]
+                ("c2w", ctypes.c_void_p), ("fx", ctypes.c_float), ("fy", ctypes.c_float),
+                ("order", ctypes.c_void_p)]
 
 
 class _CMotion(ctypes.Structure):        # struct svoxt_motion
@@ -173,6 +174,9 @@ class RaysSpec:
         # None = decide by size, SORT_RAYS below) / the batch already is in such an order
         self.sort = None
         self.coherent = False
+        # optional (not in the reference): int32 [Q] permutation (svoxt_ray_order's); launch thread i then works
+        # on ray order[i] -- the batch is walked in that order, nothing is gathered or scattered
+        self.order = None
 
 
 class TreeSpec:
@@ -441,7 +445,13 @@ def _pack_rays(rays) -> _CRays:
     c.origins, c.dirs, c.vdirs = _ptr(rays.origins), _ptr(rays.dirs), _ptr(rays.vdirs)
     c.Q = Q
     w, h = int(getattr(rays, "image_width", 0) or 0), int(getattr(rays, "image_height", 0) or 0)
-    if w * h == Q:
+    order = getattr(rays, "order", None)
+    if order is not None:
+        _check_input(order, "order")
+        if order.dtype != torch.int32 or order.dim() != 1 or order.shape[0] != Q:
+            raise RuntimeError("order must be int32 [Q]")
+        c.order = _ptr(order)
+    elif w * h == Q:
         c.image_width, c.image_height = w, h
     return c
 
@@ -678,20 +688,17 @@ def _wants_sort(rays) -> bool:
 
 
 def _in_coherent_order(tree, rays, opt):
-    """(rays spec to render, perm): the batch gathered into svoxt_ray_order's order when that pays
-    (perm: sorted position -> position in the caller's batch), else as it is."""
+    """(rays spec to render, perm): the batch with svoxt_ray_order's permutation attached when that pays
+    (RaysSpec.order: the kernels walk the batch in that order, every ray's data stays where it is, so
+    perm -- what a caller would have to undo -- is None), else as it is."""
     if not _wants_sort(rays):
         return rays, None
-    perm = _ray_order32(tree, rays, opt)
     s = RaysSpec()
-    cr = _pack_rays(rays)
-    dev = rays.origins.device
-    with torch.cuda.device(dev):
-        s.origins, s.dirs, s.vdirs = (torch.empty((cr.Q, 3), dtype=torch.float32, device=dev) for _ in range(3))
-        _call("svoxt_gather_rays", ctypes.byref(cr), _ptr(perm), _ptr(s.origins), _ptr(s.dirs), _ptr(s.vdirs), _stream(dev))
+    s.origins, s.dirs, s.vdirs = rays.origins, rays.dirs, rays.vdirs
+    s.order = _ray_order32(tree, rays, opt)      # the kernels read it: no gather of the rays, no scatter of the pixels
     s.sort = False
     s.coherent = True           # neighbouring rays revisit the same leaves: the per-tile backward pays
-    return s, perm
+    return s, None
 
 
 def _to_caller_order(out_sorted, perm):

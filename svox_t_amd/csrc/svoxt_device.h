@@ -58,16 +58,19 @@ struct RaysDev {
     const float* __restrict__ c2w;   // camera-to-world, rows of 4 floats, 3 rows used
     float fx, fy;
     int width, height;
+    const int32_t* __restrict__ order;   // != null: launch thread i works on ray order[i] (svoxt_rays.order)
 };
 
 // Which ray a thread works on.  By default thread i takes ray i (a wavefront =
 // 64 consecutive rays).  When the caller states that the batch is a row-major
-// image, a wavefront takes an 8x8 pixel tile instead: neighbouring rays then
+// image, a wavefront takes an 8x8 pixel tile instead (or, given a permutation, the rays it
+// puts next to each other: svoxt_rays.order): neighbouring rays then
 // traverse the same leaves in both image directions (fewer divergent
 // iterations, better cache reuse, more gradient rows merged before the
 // atomics).  Only the assignment of rays to lanes changes; every ray's result
 // is the same and is written at the ray's own index.
 __device__ __forceinline__ int64_t ray_of_thread(const RaysDev& rays, int64_t tid) {
+    if (rays.order != nullptr) return tid < rays.Q ? (int64_t)rays.order[tid] : rays.Q;
     if (rays.tiles_per_row <= 0) return tid;
     const int64_t tile = tid >> 6;
     const int within = (int)(tid & 63);

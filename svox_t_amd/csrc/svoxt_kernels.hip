@@ -103,11 +103,14 @@ int check_rays(const svoxt_rays* r, const char* fn) {
         if (r->image_width < 1 || r->image_height < 1 || (int64_t)r->image_width * r->image_height != r->Q)
             return fail(SVOXT_ERR_INVALID, "%s: camera mode needs Q == image_width * image_height", fn);
         if (!(r->fx != 0.f) || !(r->fy != 0.f)) return fail(SVOXT_ERR_INVALID, "%s: camera focal lengths must be non-zero", fn);
+        if (r->order != nullptr) return fail(SVOXT_ERR_INVALID, "%s: rays.order does not go with camera mode", fn);
     } else if (r->Q > 0 && (r->origins == nullptr || r->dirs == nullptr || r->vdirs == nullptr)) {
         return fail(SVOXT_ERR_INVALID, "%s: rays.origins / dirs / vdirs is NULL", fn);
     }
     if (r->Q >= (int64_t)kBlock * 2147483647LL) return fail(SVOXT_ERR_INVALID, "%s: too many rays", fn);
     if (r->image_width < 0 || r->image_height < 0) return fail(SVOXT_ERR_INVALID, "%s: negative image extent", fn);
+    if (r->order != nullptr && r->image_width > 0)
+        return fail(SVOXT_ERR_INVALID, "%s: rays.order and the image hint are two answers to the same question: give one", fn);
     return SVOXT_OK;
 }
 
@@ -154,6 +157,7 @@ RaysDev to_dev(const svoxt_rays* r) {
     d.tiles_per_row = tiled ? r->image_width / 8 : 0;
     d.tile0 = 0;
     d.c2w = r->c2w; d.fx = r->fx; d.fy = r->fy;
+    d.order = r->order;
     d.width = r->image_width; d.height = r->image_height;
     return d;
 }

@@ -328,7 +328,9 @@ def test_plain_calls_hand_the_forwards_lists_to_the_backward(name, gpu, monkeypa
         out = _ReferenceShapedFunction.apply(f, _C, spec, rs, opt)
         np.testing.assert_array_equal(out.detach().cpu().numpy(), want_out)
         plan = rs._svoxt_plan
-        assert plan is not None and plan.lists is not None and (plan.perm is not None) == (sort is None)
+        # (the coherent order travels as RaysSpec.order: the kernels read it, nothing is gathered or scattered)
+        assert plan is not None and plan.lists is not None and plan.perm is None
+        assert (getattr(plan.rays, "order", None) is not None) == (sort is None)
         out.backward(g, retain_graph=True)
         assert rs._svoxt_plan is None                        # taken
         assert_grads_close(f.grad.cpu().numpy(), want, absum)
