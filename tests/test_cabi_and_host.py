@@ -101,6 +101,18 @@ def test_validation_codes_without_touching_the_gpu():
     # Q == 0 is a valid no-op (empty ray batch)
     o = _C._COptions(format=0, basis_dim=-1)
     assert lib.svoxt_volume_render_fwd(ctypes.byref(t), ctypes.byref(r), ctypes.byref(o), None, None) == 0
+    # a ray order (svoxt_rays.order) and the image hint are two answers to the same question; camera mode has neither
+    r = _C._CRays(Q=64, origins=p, dirs=p, vdirs=p, image_width=8, image_height=8, order=p)
+    assert lib.svoxt_volume_render_fwd(ctypes.byref(t), ctypes.byref(r), ctypes.byref(o), None, None) == 1
+    assert b"rays.order" in lib.svoxt_last_error()
+    r = _C._CRays(Q=64, image_width=8, image_height=8, c2w=p, fx=1.0, fy=1.0, order=p)
+    assert lib.svoxt_render_depth(ctypes.byref(t), ctypes.byref(r), ctypes.byref(o), None, None) == 1
+    assert b"camera mode" in lib.svoxt_last_error()
+    # the helpers that go with svoxt_ray_order
+    assert lib.svoxt_permute_rows(None, None, None, 4, 3, 0, None) == 1
+    assert lib.svoxt_permute_rows(None, None, None, 0, 3, 0, None) == 0          # nothing to move
+    assert lib.svoxt_gather_rays(ctypes.byref(r), None, None, None, None, None) == 1
+    assert lib.svoxt_sigma_mask_bytes(65) == 16 and lib.svoxt_sigma_mask_bytes(-1) == -1
 
 
 def test_operator_layer_rejects_cpu_and_noncontiguous_tensors():
