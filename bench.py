@@ -260,6 +260,29 @@ def main():
                           "the sample lists by itself" if oroute == "plain" else
                           "VolumeRenderer.forward(..., image_shape=(H, W))")}
 
+    # round 1's headline arithmetic, for the record (same process, after the timed region): the backward
+    # that takes accum from the forward's output instead of adding it up like the reference's first pass
+    single_march = None
+    if world == 1 and not args.no_plain and not args.forward_only and _C.BWD_EXACT:
+        _C.BWD_EXACT = False
+        try:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / args.steps
+        finally:
+            _C.BWD_EXACT = True
+        single_march = {"setting": "SVOXT_BWD_EXACT=0", "value": round(Q / dt / 1e6, 3), "unit": "Mrays/s",
+                        "ms_per_step": round(dt * 1e3, 4),
+                        "what": "the single-march backward round 1's headline (BENCH_r01: 1038.5) was measured with: within "
+                                "1e-5 of the summed magnitudes, but 36 % of the sigma-column entries differ from the "
+                                "reference's by more than 1e-5 of their own value (tests/test_gpu_query_and_misc.py); "
+                                "`value` above is the exact backward"}
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * Q / (elapsed / args.steps) / 1e6
@@ -375,6 +398,8 @@ def main():
         }
         if other is not None:
             res["other_route"] = other
+        if single_march is not None:
+            res["tolerance_mode"] = single_march
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(st, feats, o, d, v, fmt, K, gout.cpu(), args.forward_only)
         print(json.dumps(res), flush=True)
