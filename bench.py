@@ -289,7 +289,7 @@ def main():
         ref_fwd, ref_bwd = reference_equivalent_bytes(cnt, Q, M, K, C)
         A = cnt[4]
         stride = K if (K <= 8 or K % 16 == 0) else (K + 15) // 16 * 16
-        tree_bytes = 8 * (touched.get("grid_cells", 0) + touched.get("node_pairs", 0)) + \
+        tree_bytes = 4 * touched.get("grid_cells", 0) + 8 * touched.get("node_pairs", 0) + \
             4 * (touched.get("child_words", 0) + touched.get("data_words", 0))
         recording = not args.forward_only
         fwd_parts = {

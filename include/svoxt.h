@@ -374,13 +374,14 @@ int svoxt_set_bwd_counters(int64_t* counters);
 /* Acceleration grid (no counterpart in the reference).  A 2^g x 2^g x 2^g table
  * that caches, per cell, where the root->leaf descent of common.cuh:63-100
  * stands after g levels (the leaf and its data word if it ended earlier), so a
- * march step costs one 8-byte load plus the levels below g instead of a
+ * march step costs one 4-byte load plus the levels below g instead of a
  * dependent load per level.  Behind the cells the buffer holds one (child word,
  * data word) pair per tree slot, so that the levels below g cost one 8-byte load
  * each and the leaf's data word none.  svoxt_accel_bytes returns the buffer size
- * for a resolution and a tree (8 bytes per cell + 64 bytes per internal node), -1
- * if log2_res is outside [1, 8]; svoxt_accel_build fills `cells` from
- * tree->child / tree->data. */
+ * for a resolution and a tree (4 bytes per cell + 64 bytes per internal node), -1
+ * if log2_res is outside [1, 8]; svoxt_accel_build fills `cells` (8-byte aligned) from
+ * tree->child / tree->data; trees with 2^27 - 1 feature rows or internal nodes and more
+ * are refused (SVOXT_ERR_UNSUPPORTED: a cell has 27 index bits) -- render them without a grid. */
 int64_t svoxt_accel_bytes(int32_t log2_res, int64_t n_internal);
 int     svoxt_accel_build(const svoxt_tree* tree, int32_t log2_res, void* cells, void* stream);
 

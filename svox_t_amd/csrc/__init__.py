@@ -325,12 +325,12 @@ def _accel_log2_for(n_internal: int, N: int, feature_bytes: int = 0) -> int:
     # the smallest grid with at least as many cells as the tree has leaf slots
     # (D=8 shell tree: 128^3 cells = 16 MiB against 7.6 MiB of topology) ...
     g = max(4, min(7, -(-slots.bit_length() // 3)))
-    # ... and one level finer (256^3 = 128 MiB at most) while cells, node pairs and the feature table
+    # ... and one level finer (256^3 = 64 MiB of 4-byte cells at most) while cells, node pairs and the feature table
     # still fit the 256 MiB Infinity Cache together: every leaf crossing of a depth-8 tree is then ONE
     # dependent load instead of two (r02, 800x800 on the depth-8 tree: forward 0.246 -> 0.226 ms;
     # with a backward behind it no change, 972 Mrays/s either way).  Past the cache the finer grid
     # loses (depth 9, 578 MB of features: 805 -> 794 Mrays/s forward).
-    finer = 8 * (1 << (3 * (g + 1))) + 64 * n_internal
+    finer = 4 * (1 << (3 * (g + 1))) + 64 * n_internal
     if g + 1 <= 8 and feature_bytes > 0 and finer + feature_bytes <= 224 * (1 << 20):
         g += 1
     return g
@@ -338,7 +338,7 @@ def _accel_log2_for(n_internal: int, N: int, feature_bytes: int = 0) -> int:
 
 def _accel_for(tree: TreeSpec, ct: _CTree):
     g = _accel_log2_for(ct.n_internal, ct.N, tree.features.numel() * tree.features.element_size())
-    if g == 0 or ct.N != 2:
+    if g == 0 or ct.N != 2 or max(ct.M, ct.n_internal) >= (1 << 27) - 1:       # (4-byte cells: 27 index bits)
         return None, 0
     key = id(tree.child)
     ent = _ACCEL_CACHE.get(key)

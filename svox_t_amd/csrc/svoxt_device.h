@@ -42,7 +42,7 @@ struct TreeDev {
     // optional acceleration grid (N == 2 only): 2^G cells per axis, one uint2 per
     // cell, see locate_accel().  Derived data: a cache of what a root descent
     // of `child` / `data` would find, never a different answer.
-    const uint2* __restrict__ accel;
+    const uint32_t* __restrict__ accel;
     int accel_g;
 };
 
@@ -282,15 +282,18 @@ __device__ __forceinline__ void locate(const TreeDev& tr, float px, float py, fl
 }
 
 // Acceleration grid.  Cell (cx,cy,cz) of the 2^G grid caches the state of the
-// root descent after (at most) G levels for any point inside the cell:
-//   .y bit 31 set : the descent ended in a leaf at depth (.y & 0xff) <= G whose
-//                   data word (feature row index) is .x
-//   .y bit 31 clear: the descent is at internal node .x after G levels
-// The 2^(3G) cells are followed by one (child word, data word) pair per tree slot.
+// root descent after (at most) G levels for any point inside the cell, in 4 bytes:
+//   bit 31 set  : the descent ended in a leaf at depth (bits 27-30) <= G whose data word
+//                 (feature row index) is bits 0-26 -- all ones: an empty leaf (a data word that
+//                 is no row of the feature table; the kernels see an index >= M)
+//   bit 31 clear: the descent is at internal node (bits 0-26) after G levels
+// (trees with 2^27 - 1 rows or internal nodes and more get no grid).  The 2^(3G) cells are
+// followed by one (child word, data word) pair per tree slot.
 // Built by accel_build_kernel / accel_nodes_kernel from child/data; the march then needs
-// one 8-byte load instead of up to G dependent 4-byte loads per step, plus one 8-byte load
+// one 4-byte load instead of up to G dependent 4-byte loads per step, plus one 8-byte load
 // per level below the grid (none for the data word).
 constexpr uint32_t kAccelLeaf = 0x80000000u;
+constexpr uint32_t kAccelIdx = 0x07ffffffu;      // row / node bits; as a row: empty
 
 // MARK: mark[cell] = 1 for the grid cell read, mark[n_cells + slot] = 1 for every (child, data) pair read
 template <bool MARK = false>
@@ -306,18 +309,19 @@ __device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float 
     const int G = tr.accel_g;
     const int gs = kFixBits - G;
     const uint32_t ci = ((((ux >> gs) << G) + (uy >> gs)) << G) + (uz >> gs);
-    const uint2 cell = tr.accel[ci];
+    const uint32_t cell = tr.accel[ci];
     if constexpr (MARK) mark[ci] = 1;
     int k;
     uint32_t slot = 0xffffffffu;
-    if (cell.y & kAccelLeaf) {
-        k = (int)(cell.y & 0xffu);
-        idx = (int32_t)cell.x;
+    if (cell & kAccelLeaf) {
+        k = (int)((cell >> 27) & 15u);
+        const uint32_t row = cell & kAccelIdx;
+        idx = row == kAccelIdx ? 0x7fffffff : (int32_t)row;
     } else {
         // below the grid: (child word, data word) pairs, so that reaching a leaf costs no
         // further dependent load for its data word
-        const uint2* __restrict__ nodes = tr.accel + ((size_t)1 << (3 * G));
-        int32_t node = (int32_t)cell.x;
+        const uint2* __restrict__ nodes = reinterpret_cast<const uint2*>(tr.accel + ((size_t)1 << (3 * G)));
+        int32_t node = (int32_t)cell;
         int32_t skip;
         uint2 cd;
         k = G + 1;

@@ -143,7 +143,7 @@ TreeDev to_dev(const svoxt_tree* t) {
     d.xform = t->xform;   // consulted by the generic render kernels only
     d.xform_dim = t->xform_dim == 4 ? 4 : 3;
     const bool use_accel = t->accel != nullptr && t->N == 2;
-    d.accel = use_accel ? reinterpret_cast<const uint2*>(t->accel) : nullptr;
+    d.accel = use_accel ? reinterpret_cast<const uint32_t*>(t->accel) : nullptr;
     d.accel_g = use_accel ? t->accel_log2 : 0;
     return d;
 }
@@ -1125,7 +1125,7 @@ int svoxt_compact_rows(const float* src, int64_t M, int32_t K, int32_t stride, f
 
 int64_t svoxt_accel_bytes(int32_t log2_res, int64_t n_internal) {
     if (log2_res < 1 || log2_res > 8 || n_internal < 0) return -1;
-    return ((int64_t)sizeof(uint2) << (3 * log2_res)) + (int64_t)sizeof(uint2) * 8 * n_internal;
+    return ((int64_t)sizeof(uint32_t) << (3 * log2_res)) + (int64_t)sizeof(uint2) * 8 * n_internal;
 }
 
 int svoxt_accel_build(const svoxt_tree* tree, int32_t log2_res, void* cells, void* stream) {
@@ -1134,16 +1134,19 @@ int svoxt_accel_build(const svoxt_tree* tree, int32_t log2_res, void* cells, voi
     if ((rc = check_tree(tree, fn))) return rc;
     if (tree->N != 2) return fail(SVOXT_ERR_UNSUPPORTED, "%s: the acceleration grid exists for N == 2 only", fn);
     if (log2_res < 1 || log2_res > 8) return fail(SVOXT_ERR_INVALID, "%s: log2_res must be in [1, 8]", fn);
-    if (cells == nullptr) return fail(SVOXT_ERR_INVALID, "%s: cells is NULL", fn);
+    if (cells == nullptr || ((uintptr_t)cells & 7u) != 0) return fail(SVOXT_ERR_INVALID, "%s: cells is NULL or not 8-byte aligned", fn);
+    if (tree->M >= (int64_t)kAccelIdx || tree->n_internal >= (int64_t)kAccelIdx)
+        return fail(SVOXT_ERR_UNSUPPORTED, "%s: the 4-byte cells hold row and node indices below 2^27 - 1", fn);
     TreeDev tr = to_dev(tree);
     tr.accel = nullptr;
     const unsigned n = 1u << (3 * log2_res);
     hipLaunchKernelGGL(accel_build_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0,
-                       (hipStream_t)stream, tr, (int)log2_res, reinterpret_cast<uint2*>(cells));
+                       (hipStream_t)stream, tr, (int)log2_res, reinterpret_cast<uint32_t*>(cells));
     const int64_t slots = tree->n_internal * 8;
     if (slots > 0)
         hipLaunchKernelGGL(accel_nodes_kernel, dim3((unsigned)((slots + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                           (hipStream_t)stream, tr.child, tr.data, slots, reinterpret_cast<uint2*>(cells) + n);
+                           (hipStream_t)stream, tr.child, tr.data, slots,
+                           reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(cells) + n));
     return check_launch(fn);
 }
 

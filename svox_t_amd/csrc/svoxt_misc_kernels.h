@@ -450,7 +450,7 @@ compact_rows_kernel(const V* __restrict__ src, int64_t n, int Kv, int stride_v, 
 // ---------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(kBlock)
-accel_build_kernel(TreeDev tr, int G, uint2* __restrict__ cells) {
+accel_build_kernel(TreeDev tr, int G, uint32_t* __restrict__ cells) {
     const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
     if (c >= (1u << (3 * G))) return;
     const uint32_t mask = (1u << G) - 1u;
@@ -462,12 +462,13 @@ accel_build_kernel(TreeDev tr, int G, uint2* __restrict__ cells) {
         const uint32_t slot = ((uint32_t)node << 3) + c3;
         const int32_t skip = tr.child[slot];
         if (skip == 0) {
-            cells[c] = make_uint2((uint32_t)tr.data[slot], kAccelLeaf | (uint32_t)k);
+            const uint32_t row = (uint32_t)tr.data[slot];
+            cells[c] = kAccelLeaf | ((uint32_t)k << 27) | ((int64_t)row < tr.M ? row : kAccelIdx);
             return;
         }
         node += skip;
     }
-    cells[c] = make_uint2((uint32_t)node, 0u);
+    cells[c] = (uint32_t)node;
 }
 
 // ... and the (child, data) pairs the descent below the grid reads
