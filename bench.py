@@ -239,6 +239,7 @@ def main():
         elapsed = float(t.item())
 
     route_fwd, route_bwd = _C.LAST_ROUTE["forward"], (None if args.forward_only else _C.LAST_ROUTE["backward"])
+    forward_terms = bool(_C.LAST_ROUTE.get("forward_terms"))       # (of the timed route: the runs below take others)
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     bwd_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
 
@@ -297,7 +298,7 @@ def main():
             "feature_rows_read": 4 * K * touched["rows_valid"], "tree_words_read": tree_bytes,
             "records_written": 8 * A if recording else 0, "aux_written": 16 * Q if recording else 0,
             # (att, e0, e1, e2) per sample, left by the recording forward for the exact backward
-            "backward_terms_written": 16 * A if (recording and _C.LAST_ROUTE.get("forward_terms")) else 0,
+            "backward_terms_written": 16 * A if (recording and forward_terms) else 0,
         }
         bwd_parts = None
         if not args.forward_only:
@@ -305,8 +306,8 @@ def main():
                 "grad_memset": 4 * M * stride, "upstream_gradient_read": 4 * (C + 1) * Q, "aux_read": 16 * Q,
                 "rays": 36 * cnt[0], "records_read": 8 * A,
                 # with the forward's hand-over the backward reads 16 B per sample instead of the feature rows
-                "feature_rows_read": 0 if _C.LAST_ROUTE.get("forward_terms") else 4 * K * touched["rows_composited"],
-                "terms_read": 16 * A if _C.LAST_ROUTE.get("forward_terms") else 0,
+                "feature_rows_read": 0 if forward_terms else 4 * K * touched["rows_composited"],
+                "terms_read": 16 * A if forward_terms else 0,
                 "atomic_requests_64B": 64 * atomic_requests if atomic_requests else 4 * K * A,
                 "row_compaction": (4 * M * stride + 4 * M * K) if stride != K else 0,
             }
