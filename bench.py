@@ -2,7 +2,7 @@
 """Headline benchmark: Mrays/s of volume_render forward + backward on synthetic
 800x800 renders of the depth-8 SH9 shell tree (BASELINE.json configs[2]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ...] [--forward-only] [--route plain]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ...] [--forward-only] [--route plain|camera]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
@@ -10,9 +10,11 @@ A "step" is one pass of the hot path over one ray batch: VolumeRenderer.forward 
 followed by backward() of a fixed upstream gradient, i.e. volume_render + volume_render_backward
 through the autograd.Function surface.  Inputs (tree topology, feature table, rays, upstream
 gradient) are resident in HBM before the timed region.  With N > 1 every rank holds a replica of
-the tree and renders its own camera (weak scaling: per-GPU work fixed); the gradient all-reduce of
-a step runs on a side stream, in row chunks, under the next step's forward, and the pixels are
-gathered while the backward runs (svox_t_amd/parallel.py).
+the tree and renders its own camera (weak scaling: per-GPU work fixed); the pixels are gathered while the
+backward runs, and the gradient is all-reduced (row chunks on a side stream, svox_t_amd/parallel.py) and
+WAITED FOR before the next step starts -- the arrangement of a trainer that updates the features after every
+batch (svox_t/renderer.py:60-77 under an optimizer); the gradient-accumulation arrangement, in which the
+all-reduce hides under the next step, is timed afterwards and reported beside it.
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  `roofline` prices the bytes
 THIS implementation cannot avoid moving to and from memory for the dominant kernel group (what
@@ -55,10 +57,32 @@ WORKLOADS = {
 }
 
 
+ROUND = "r03"        # which round's committed profiles the line quotes (profiles/<ROUND>_*)
+PREWARM_STEPS = 30   # untimed, before the --warmup steps: printed in the line
+
+
+def kernel_stats_ms(workload, forward_only):
+    """{kernel name prefix: mean ms per launch} from this round's committed `rocprofv3 --kernel-trace --stats`
+    summary of the same command (profiles/<ROUND>_<workload>[_fwd]_kernel_stats.csv), or {}."""
+    import csv
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_{workload}{'_fwd' if forward_only else ''}_kernel_stats.csv")
+    out = {}
+    try:
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                name = r["Name"].replace("void ", "").replace("svoxt::", "")
+                key = name.split("(")[0]
+                if int(r["Calls"]) >= 10:                  # (the one-off counting launches are not the step's)
+                    out[key] = round(float(r["AverageNs"]) * 1e-6, 5)
+    except Exception:
+        return {}
+    return out
+
+
 def pmc_traffic(workload, forward_only, group):
     """(bytes per launch group, note) from this round's committed rocprofv3 --pmc passes of the same
     command (scripts/pmc_passes.sh -> scripts/pmc_summary.py), or (None, reason)."""
-    name = f"r02_{workload}{'_fwd' if forward_only else ''}_pmc.json"
+    name = f"{ROUND}_{workload}{'_fwd' if forward_only else ''}_pmc.json"
     path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as f:
@@ -92,9 +116,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="d8_sh9_800", choices=list(WORKLOADS))
-    ap.add_argument("--route", default="hinted", choices=["hinted", "plain"],
+    ap.add_argument("--route", default="hinted", choices=["hinted", "plain", "camera"],
                     help="hinted: VolumeRenderer.forward(..., image_shape=(H, W)); plain: exactly the two calls the "
-                         "reference's own autograd function makes on the operator module (no hint, no extra argument)")
+                         "reference's own autograd function makes on the operator module (no hint, no extra argument); "
+                         "camera: VolumeRenderer.render_persp (rays generated in the kernels, no ray tensors in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plain", action="store_true", help="skip the extra plain-route measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for dry runs")
@@ -158,11 +183,20 @@ def main():
         def backward(ctx, grad_out):
             return _C.volume_render_backward(ctx.tree, ctx.rays, ctx.opt, grad_out.contiguous()), None, None, None
 
+    if args.forward_only:
+        # inference: the caller declares the feature table static, so what the operator layer derives from its
+        # content (the sigma bitmask) is built once and cached; a training step rebuilds it in every forward
+        tree.static_features = True
+    c2w = torch.from_numpy(pose).float().to(dev)
+    fx = 1111.111 * W / 800.0
+
     def render(route):
         if route == "plain":
             rs = _C.RaysSpec()
             rs.origins, rs.dirs, rs.vdirs = rays.origins, rays.dirs, rays.viewdirs
             return _ReferenceShaped.apply(features, tree._spec(features), rs, opt)
+        if route == "camera":
+            return renderer.render_persp(features, c2w, width=W, height=H, fx=fx).view(Q, -1)
         return renderer(features, rays, image_shape=(H, W))
 
     # ---- one-off device-side counts (before the timed region) -------------------------------
@@ -183,7 +217,7 @@ def main():
     gathered = torch.empty((world * Q, C + 1), dtype=torch.float32, device=dev) if dist is not None else None
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
 
-    def step(i=None, route=args.route):
+    def step(i=None, route=args.route, accumulate=False):
         e = ev[i] if i is not None else None
         features.grad = None              # (a gradient still travelling is held by the reducer)
         if e: e[0].record()
@@ -202,72 +236,97 @@ def main():
         if e: e[2].record()
         if dist is not None:
             if not args.forward_only:
-                # gradient accumulation over batches: the previous batch's reduced gradient is complete
-                # here; this batch's travels (side stream, row chunks) under the next batch's work
-                reducer.start(features.grad)
+                reducer.start(features.grad)           # row chunks on a side stream
+                if not accumulate:
+                    # every-step update: the reduced gradient is needed before the features may change,
+                    # i.e. before the next forward -- the all-reduce is exposed (this is the timed arrangement)
+                    reducer.wait()
+                # accumulate: the previous batch's reduced gradient is complete here; this batch's travels
+                # under the next batch's forward and backward (gradient accumulation over batches / cameras)
             if gather is not None:
                 gather.wait()
         return out
 
+    def timed(n, **kw):
+        """Mean seconds per step of n steps, bracketed by barrier + synchronize, max over ranks."""
+        if reducer is not None:
+            reducer.wait()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(i if kw.get("events") else None, **{k: v for k, v in kw.items() if k != "events"})
+        if reducer is not None:
+            reducer.wait()                    # the last gradient is reduced inside the timed region
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     # Setup, not measurement: the first process on a fresh box has been seen to run its first
     # dozens of steps far below steady state (allocator growth, code-object loads, clocks).
-    # Bring the device there before the W warm-up steps the contract asks for.
-    for _ in range(30):
+    # Bring the device there before the W warm-up steps the contract asks for (PREWARM_STEPS is
+    # printed in the line as `prewarm`).
+    for _ in range(PREWARM_STEPS):
         step()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    if reducer is not None:
-        reducer.wait()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    if reducer is not None:
-        reducer.wait()                    # the last gradient is reduced inside the timed region
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(args.steps, events=True)
 
     route_fwd, route_bwd = _C.LAST_ROUTE["forward"], (None if args.forward_only else _C.LAST_ROUTE["backward"])
     forward_terms = bool(_C.LAST_ROUTE.get("forward_terms"))       # (of the timed route: the runs below take others)
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     bwd_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
 
-    # the other route, for the record (same process, after the timed region)
-    other = None
-    if world == 1 and not args.no_plain:
-        oroute = "plain" if args.route == "hinted" else "hinted"
+    # N > 1: the gradient-accumulation arrangement (one gradient in flight under the next step) beside the
+    # timed every-step-update one, same process, same number of steps
+    accumulation = None
+    if dist is not None and not args.forward_only:
         for _ in range(3):
-            step(route=oroute)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step(route=oroute)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t1) / args.steps
-        other = {"route": oroute, "value": round(Q / dt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(dt * 1e3, 4),
-                 "what": ("the two calls the reference's own autograd function makes (svox_t/renderer.py:60-77) on "
-                          "svox_t_amd.csrc: no image hint; the operator layer orders the rays, records and replays "
-                          "the sample lists by itself" if oroute == "plain" else
-                          "VolumeRenderer.forward(..., image_shape=(H, W))")}
+            step(accumulate=True)
+        el = timed(args.steps, accumulate=True)
+        accumulation = {"value": round(world * Q / (el / args.steps) / 1e6, 3), "unit": "Mrays/s",
+                        "ms_per_step": round(el * 1e3 / args.steps, 4),
+                        "what": "gradient accumulation over batches: step i's all-reduce travels (side stream, row chunks) "
+                                "under step i+1's forward and backward; only the last one is exposed"}
 
-    # round 1's headline arithmetic, for the record (same process, after the timed region): the backward
-    # that takes accum from the forward's output instead of adding it up like the reference's first pass
-    single_march = None
-    if world == 1 and not args.no_plain and not args.forward_only and _C.BWD_EXACT:
-        _C.BWD_EXACT = False
-        try:
+    # the other routes, for the record (same process, after the timed region)
+    WHAT = {"plain": "the two calls the reference's own autograd function makes (svox_t/renderer.py:60-77) on "
+                     "svox_t_amd.csrc: no image hint; the operator layer orders the rays, records and replays "
+                     "the sample lists by itself",
+            "hinted": "VolumeRenderer.forward(..., image_shape=(H, W))",
+            "camera": "VolumeRenderer.render_persp (svox_t/renderer.py:310-366 -> volume_render_image, rt_kernel.cu:1153-1238): "
+                      "the kernels generate the pinhole rays themselves, no ray tensors are read"}
+    other = []
+    if world == 1 and not args.no_plain:
+        for oroute in ("hinted", "plain", "camera"):
+            if oroute == args.route:
+                continue
             for _ in range(3):
+                step(route=oroute)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step(route=oroute)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / args.steps
+            other.append({"route": oroute, "value": round(Q / dt / 1e6, 3), "unit": "Mrays/s",
+                          "ms_per_step": round(dt * 1e3, 4), "what": WHAT[oroute]})
+
+    def timed_with(attr, value, n_warm=3):
+        old = getattr(_C, attr)
+        setattr(_C, attr, value)
+        try:
+            for _ in range(n_warm):
                 step()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -275,14 +334,35 @@ def main():
                 step()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / args.steps
+            routes = (_C.LAST_ROUTE["forward"], None if args.forward_only else _C.LAST_ROUTE["backward"])
         finally:
-            _C.BWD_EXACT = True
-        single_march = {"setting": "SVOXT_BWD_EXACT=0", "value": round(Q / dt / 1e6, 3), "unit": "Mrays/s",
-                        "ms_per_step": round(dt * 1e3, 4),
-                        "what": "the single-march backward round 1's headline (BENCH_r01: 1038.5) was measured with: within "
-                                "1e-5 of the summed magnitudes, but 36 % of the sigma-column entries differ from the "
-                                "reference's by more than 1e-5 of their own value (tests/test_gpu_query_and_misc.py); "
-                                "`value` above is the exact backward"}
+            setattr(_C, attr, old)
+        return dt, routes
+
+    # the opt-in tolerance modes, for the record (same process, after the timed region; `value` above is the exact mode)
+    tolerance = None
+    wide = fmt == "RGBA" and K in (8, 16, 32)
+    if world == 1 and not args.no_plain and wide and not _C.NATIVE_MATH:
+        # rows of 8 / 16 / 32 floats: bit-exact stepping, shading with v_exp_f32 / v_rcp_f32 (forward and backward)
+        dt, routes = timed_with("NATIVE_MATH", True)
+        tolerance = {"setting": "SVOXT_NATIVE_MATH=1", "value": round(Q / dt / 1e6, 3), "unit": "Mrays/s",
+                     "ms_per_step": round(dt * 1e3, 4), "kernels": {"forward": routes[0], "backward": routes[1]},
+                     "what": "the lists are the exact march's; exponentials and the quotients w / (1 + e) of the shade "
+                             "kernels and of both sweeps of the per-tile backward with the hardware's v_exp_f32 / v_rcp_f32 "
+                             "instead of the bit-exact expf replica and a double-precision divide: outputs within 1e-5 "
+                             "relative (+1e-6), gradients within 1e-5 of the tight scale, tested at this size "
+                             "(tests/test_gpu_query_and_misc.py::test_config4_native_math_tolerance_mode_full_size)"}
+    elif world == 1 and not args.no_plain and not args.forward_only and _C.BWD_EXACT:
+        # round 1's headline arithmetic: the backward that takes accum from the forward's output instead of
+        # adding it up like the reference's first pass
+        dt, _ = timed_with("BWD_EXACT", False)
+        tolerance = {"setting": "SVOXT_BWD_EXACT=0", "value": round(Q / dt / 1e6, 3), "unit": "Mrays/s",
+                     "ms_per_step": round(dt * 1e3, 4),
+                     "what": "the single-march backward round 1's headline (BENCH_r01: 1038.5) was measured with: within "
+                             "1e-5 of the summed magnitudes, but 36 % of the sigma-column entries differ from the "
+                             "reference's by more than 1e-5 of their own value (tests/test_gpu_query_and_misc.py); "
+                             "`value` above is the exact backward"}
+    single_march = tolerance
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -315,8 +395,7 @@ def main():
                 # sweep 1 -> sweep 2: (attenuation,) second-pass total_color per sample, written and read
                 bwd_parts["sweep_handover"] = (16 if "grad_wide_kernel" in route_bwd else 8) * A
             if atomic_requests is None or not atomic_requests:
-                bwd_parts["atomic_requests_note"] = "one row per sample (not counted on the device for this route; " \
-                    "grad_wide_kernel merges rows per tile and window of 16 list positions: exp/reuse_probe.py)"
+                bwd_parts["atomic_requests_note"] = "one row per sample (this route has no counting instance)"
         fwd_bytes = sum(fwd_parts.values())
         bwd_bytes = sum(v for v in bwd_parts.values() if not isinstance(v, str)) if bwd_parts else 0
         if args.forward_only or fwd_ms >= bwd_ms:
@@ -327,17 +406,27 @@ def main():
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic, traffic_note = pmc_traffic(args.workload, args.forward_only, dom) if world == 1 else \
             (None, "PMC profiles exist for N=1 only")
-        chain = "march" if "march_rec" in (route_fwd or "") else "march+shade"
+        # Like with like: the chain floor of the STEPPING against the march kernel's own time (from the committed
+        # kernel statistics of this command) when the forward is march + shade; the floor of stepping + shading
+        # in one chain against the whole forward when it is one kernel.
+        two_kernel = "march_rec" in (route_fwd or "")
+        chain = "march" if two_kernel else "march+shade"
+        kstats = kernel_stats_ms(args.workload, args.forward_only) if world == 1 else {}
+        march_ms = next((v for k, v in kstats.items() if k.startswith("march_rec_kernel")), None)
+        shade_ms = next((v for k, v in kstats.items() if k.startswith("shade_")), None)
         limits = {"forward": {
             "bound": "dependent chain of the longest ray (tree words -> step -> next tree words), not bytes",
             "longest_ray_crossings": touched["longest_ray_crossings"],
             "us_per_crossing_unloaded": US_PER_CROSSING_UNLOADED[chain],
             "floor_ms": round(touched["longest_ray_crossings"] * US_PER_CROSSING_UNLOADED[chain] * 1e-3, 4),
-            "measured_ms": round(fwd_ms, 4)}}
-        if "shade_chan" in (route_fwd or ""):
-            limits["forward"]["note"] = ("two kernels: the march is bound by this chain; shade_chan_kernel by the vector ALUs "
-                                         "(one exponential and one double-precision divide per channel and sample) and, when the "
-                                         "feature table exceeds the 256 MiB Infinity Cache, by HBM (see roofline.traffic)")
+            "floor_of": "march_rec_kernel alone" if two_kernel else "render_fwd_kernel (stepping and shading in one chain)",
+            "measured_ms": march_ms if two_kernel else round(fwd_ms, 4),
+            "measured_of": (f"march_rec_kernel, profiles/{ROUND}_{args.workload}{'_fwd' if args.forward_only else ''}_kernel_stats.csv"
+                            + ("" if march_ms is not None else " (not committed yet)")) if two_kernel
+                           else "the whole forward (HIP events of this run)",
+            "forward_ms_whole": round(fwd_ms, 4)}}
+        if two_kernel and shade_ms is not None:
+            limits["forward"]["shade_kernel_ms"] = shade_ms
         if atomic_requests:
             limits["backward"] = {
                 "bound": "rate at which the memory side takes 64-byte float-atomic requests (exp/atomic_bench.hip: 22 G/s)",
@@ -352,6 +441,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm": PREWARM_STEPS,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -368,8 +458,11 @@ def main():
                 "backward_arithmetic": None if args.forward_only else
                 ("exact (every contribution the reference's formula)" if _C.BWD_EXACT else "single march (SVOXT_BWD_EXACT=0)"),
                 "partitioning": "replicated tree, one camera (ray batch) per GPU"
-                                + ("; all-gather of pixels under the backward, all-reduce of grad in row chunks on a "
-                                   "side stream under the next step's forward" if world > 1 else ""),
+                                + ("; all-gather of pixels under the backward; all-reduce of grad in row chunks on a "
+                                   "side stream, waited for before the next step (every-step update); "
+                                   "`accumulation_arrangement` has the overlapped form" if world > 1 else ""),
+                "features": "declared static (inference: the sigma bitmask is built once)" if args.forward_only
+                            else "updated every step (nothing derived from them is cached between steps)",
             },
             "kernel_ms": {"forward": round(fwd_ms, 4), "backward": round(bwd_ms, 4)},
             "kernels": {"forward": route_fwd, "backward": route_bwd},
@@ -397,10 +490,15 @@ def main():
             },
             "limits": limits,
         }
-        if other is not None:
-            res["other_route"] = other
+        if other:
+            res["other_routes"] = other
         if single_march is not None:
             res["tolerance_mode"] = single_march
+        if accumulation is not None:
+            res["accumulation_arrangement"] = accumulation
+        if world > 1:
+            res["multi_gpu_note"] = ("kernel_ms is the compute stream's forward / backward per step; ms_per_step - kernel "
+                                     "time = exposed collectives + host; unmeasured on hardware by the builder (no 8-GPU node)")
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(st, feats, o, d, v, fmt, K, gout.cpu(), args.forward_only)
         print(json.dumps(res), flush=True)

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 15
+#define SVOXT_ABI_VERSION 16
 
 enum {
     SVOXT_OK = 0,
@@ -158,15 +158,16 @@ int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
  * bytes (S >= 8, 96 is a good value) the forward can run as two kernels -- one that only
  * steps the rays through the tree and lists each ray's samples (up to S; longer rays finish in a
  * tail launch), one that shades the lists: per 64-ray tile with eight wavefronts sharing the
- * work (3-channel payloads; chosen with SVOXT_FWD_SPLIT=1), or with the channels of a row on
+ * work (3-channel payloads; only on request: svoxt_volume_render_fwd_scratch with SVOXT_LISTS_FWD_TWO_KERNELS), or with the channels of a row on
  * the lanes of a wavefront (RGBA-style rows of 8 / 16 / 32 floats: the default for them) --
  * instead of one kernel as long as its longest ray.  Other payloads,
  * tree->weight_accum, a NULL or too small workspace: exactly svoxt_volume_render_fwd.  Contents of the workspace on return are unspecified.
  * (Reference: volume_render, rt_kernel.cu:1362-1379; trace_ray :222-328.) */
-/* flags: 0, or SVOXT_FWD_FAST_SIGMOID -- an opt-in tolerance mode for RGBA-style rows of 8 / 16 / 32
- * floats: the per-channel quotient w / (1 + exp(-x)), double precision in the reference
- * (rt_kernel.cu:300-305), is taken in float with the hardware reciprocal.  Each term then lies
- * within 2e-7 of the reference's, outputs within 1e-5 relative (tests); no longer bit for bit. */
+/* flags: 0, or an OR of the SVOXT_LISTS_* values below (how the scratch lists are filled); among them
+ * SVOXT_FWD_FAST_SIGMOID (= SVOXT_LISTS_NATIVE_MATH) -- an opt-in tolerance mode for
+ * RGBA-style rows of 8 / 16 / 32 floats: bit-exact stepping, but expf and the per-channel quotient
+ * w / (1 + exp(-x)) -- double precision in the reference (rt_kernel.cu:280, 300-305) -- are taken with the
+ * hardware's v_exp_f32 / v_rcp_f32.  Outputs within 1e-5 relative (tests at full size); no longer bit for bit. */
 #define SVOXT_FWD_FAST_SIGMOID 1
 int64_t svoxt_fwd_workspace_bytes(int64_t Q, int32_t max_samples);
 int svoxt_volume_render_fwd_ws(const svoxt_tree* tree, const svoxt_rays* rays,
@@ -207,8 +208,11 @@ int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
 
 /* Sample lists (no counterpart in the reference).  When a forward will be
  * followed by a backward, the forward can record which samples each ray
- * composited -- rec[k][q] = (feature row, step length) for k < max_samples, and
- * aux[q] = (count, overflow flag, resume point) -- and the backward then replays
+ * composited -- 8-byte records (feature row, step length), the k-th record of the ray
+ * handled by launch thread t at rec[block(t / 64, k / 8)][t % 64][k % 8] (a lane's 8
+ * consecutive records are one 64-byte line; `block` is the identity for dense lists and
+ * goes through blocktab for pooled ones, below), and aux[q] = (count, overflow flag,
+ * resume point, final transmittance) -- and the backward then replays
  * those samples instead of traversing the tree again (twice, in the reference:
  * rt_kernel.cu:365-494).  Rays with more than max_samples composited samples
  * march the remainder, so the result does not depend on max_samples.  Needs
@@ -216,6 +220,24 @@ int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
  * one of the specialised payloads (svoxt_can_record returns 1; with tree->xform
  * set: SH payloads on N = 2 trees); the lists are valid for the tree, features'
  * sign of sigma, rays and options they were recorded with. */
+/* svoxt_sample_lists.flags (ABI v16): how the kernels that write and read these lists work.
+ *   SVOXT_LISTS_NATIVE_MATH      opt-in TOLERANCE mode for RGBA-style rows of 8 / 16 / 32 floats (= the `flags`
+ *                                value SVOXT_FWD_FAST_SIGMOID of the scratch forwards): the stepping -- which
+ *                                leaves a ray crosses, the step lengths, the lists -- stays bit-exact, the SHADING
+ *                                arithmetic uses the hardware's exponential (v_exp_f32 on x * log2 e) and
+ *                                reciprocal (v_rcp_f32) where the reference has expf and a double-precision
+ *                                quotient (rt_kernel.cu:280, 300-305, 397, 408-425, 461-476): the channel-lane
+ *                                shade / tail kernels of the forward and both sweeps of the per-tile backward.
+ *                                Outputs within 1e-5 relative (+1e-6 absolute), gradients within 1e-5 of the
+ *                                tight scale (tests at full size); not bit for bit.  A backward must be given the
+ *                                flags its forward recorded with.  Ignored by every other payload / kernel.
+ *   SVOXT_LISTS_FWD_ONE_KERNEL   the forward that fills these lists runs as one kernel / as march + shade
+ *   SVOXT_LISTS_FWD_TWO_KERNELS  kernels where both exist (neither: the library's default for the payload:
+ *                                two kernels for rows of 8 / 16 / 32 floats and for 3-channel forwards that
+ *                                also fill `terms`).  Result-neutral. */
+#define SVOXT_LISTS_NATIVE_MATH 1
+#define SVOXT_LISTS_FWD_ONE_KERNEL 2
+#define SVOXT_LISTS_FWD_TWO_KERNELS 4
 typedef struct svoxt_sample_lists {
     void*   rec;           /* device, 64-byte aligned, max_samples * ceil(Q / 64) * 64 * 8 bytes: record k of the
                               ray handled by launch thread t lives at rec[t / 64][k / 8][t % 64][k % 8] (8 bytes
@@ -262,12 +284,13 @@ typedef struct svoxt_sample_lists {
     int64_t pool_blocks;
     void*   pool_next;
     int32_t terms_state;   /* see terms */
+    int32_t flags;         /* 0 or an OR of SVOXT_LISTS_* (above) */
 } svoxt_sample_lists;
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt);
-/* What svoxt_volume_render_fwd_record does with lists that carry `terms` for this tree / options: 0 = nothing,
- * 2 / 3 = fills them (in the layout of that number: pass it back as terms_state to the backward) */
-int svoxt_fwd_fills_terms(const svoxt_tree* tree, const svoxt_options* opt);
+/* What svoxt_volume_render_fwd_record does with lists that carry `terms` for this tree / options / lists.flags:
+ * 0 = nothing, 2 / 3 = fills them (in the layout of that number: pass it back as terms_state to the backward) */
+int svoxt_fwd_fills_terms(const svoxt_tree* tree, const svoxt_options* opt, int32_t list_flags);
 
 /* The sigma bitmask of svoxt_tree.sigma_mask (no counterpart in the reference): bytes for M rows, and the
  * build -- bit (row & 31) of 32-bit word (row >> 5) = features[row * K + K - 1] > sigma_thresh.  One read of a
@@ -366,9 +389,10 @@ int svoxt_count_touched(const svoxt_tree* tree, const svoxt_rays* rays, const sv
                         uint8_t* row_mask, uint8_t* tree_mask, int64_t* longest, void* stream);
 
 /* Instrumentation: counters [2] (device int64, caller-zeroed) or NULL.  While set, the one-kernel
- * per-tile backward (grad_fused_kernel) adds to counters[0] the number of 64-byte atomic requests it
- * sends to the gradient table and to counters[1] the number of (tile, pass, feature row) groups they
- * belong to.  Process-wide; meant for bench.py. */
+ * per-tile backwards (grad_fused_kernel; grad_wide_kernel for rows of 8 / 16 / 32 floats) add to
+ * counters[0] the number of 64-byte atomic requests they send to the gradient table and to counters[1]
+ * the number of (tile, window of 16 list positions, feature row) groups they belong to.  Process-wide;
+ * meant for bench.py. */
 int svoxt_set_bwd_counters(int64_t* counters);
 
 /* Acceleration grid (no counterpart in the reference).  A 2^g x 2^g x 2^g table

@@ -4,6 +4,7 @@
 # (scripts/pmc_passes.sh: one rocprofv3 --pmc run per counter group, no trace domains).
 #   scripts/profile_round.sh <outdir under gpurun_out>      then copy what is to be judged into profiles/
 set -u
+ROUND=r03      # = bench.py's ROUND
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-prof}
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -17,7 +18,7 @@ stats() {   # name, args...
   ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${name}_trace -- \
       python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-plain "$@" > /dev/null 2>&1 < /dev/null ) || echo "stats $name failed"
   local f=$(find $OUT/${name}_trace -name "*kernel_stats.csv" | sort | tail -1)
-  [ -n "$f" ] && cp "$f" $OUT/${name}_kernel_stats.csv
+  [ -n "$f" ] && cp "$f" $OUT/${name}_kernel_stats.csv && cp "$f" profiles/${ROUND}_${name}_kernel_stats.csv   # (the bench lines read it for limits.forward)
   rm -rf $OUT/${name}_trace
   echo "stats $name done"
 }
@@ -25,7 +26,7 @@ pmc() {     # name, args...
   local name=$1; shift
   bash scripts/pmc_passes.sh $name bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-plain "$@" > $OUT/${name}_pmc.log 2>&1 < /dev/null
   python3 scripts/pmc_summary.py $name $OUT/${name}_pmc.json > $OUT/${name}_pmc_summary.txt 2>&1
-  cp $OUT/${name}_pmc.json profiles/r02_${name}_pmc.json      # (on the box's copy: the bench lines below read it for roofline.traffic)
+  cp $OUT/${name}_pmc.json profiles/${ROUND}_${name}_pmc.json      # (on the box's copy: the bench lines below read it for roofline.traffic)
   echo "pmc $name done"
 }
 # headline (configs[2]) forward+backward, its forward alone, and the two opt-outs
@@ -42,7 +43,9 @@ bench d9_rgba32_1024 --workload d9_rgba32_1024
 pmc   d9_rgba32_1024_fwd --workload d9_rgba32_1024 --forward-only
 stats d9_rgba32_1024_fwd --workload d9_rgba32_1024 --forward-only
 bench d9_rgba32_1024_fwd --workload d9_rgba32_1024 --forward-only
-SVOXT_FAST_SIGMOID=1 bench d9_rgba32_1024_fwd_fastsigmoid --workload d9_rgba32_1024 --forward-only
+SVOXT_NATIVE_MATH=1 bench d9_rgba32_1024_fwd_native --workload d9_rgba32_1024 --forward-only --no-plain
+SVOXT_NATIVE_MATH=1 stats d9_rgba32_1024_native --workload d9_rgba32_1024
+SVOXT_NATIVE_MATH=1 pmc   d9_rgba32_1024_native --workload d9_rgba32_1024
 # configs[0]: the reference's own CPU-runnable case
 bench d5_rgba_64_fwd --workload d5_rgba_64 --forward-only
 ls $OUT

@@ -16,6 +16,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_NAME = "libsvoxt_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
+# what the compiler says each kernel needs (registers, scratch, LDS, occupancy), written by every build:
+# tests/test_cabi_and_host.py holds it to "no kernel with a dynamic stack or more than a few spilled
+# registers" (a private array that ends up in scratch memory is a round trip per access -- DESIGN.md
+# step 13 -- and the one place an out-of-range private index could fault)
+RESOURCES_PATH = os.path.join(CSRC, "libsvoxt_hip.resources.txt")
 SOURCES = ["svoxt_kernels.hip", "svoxt_build.hip", "svoxt_motion.hip", "svoxt_order.hip"]
 HEADERS = ["svoxt_device.h", "svoxt_host.h", "svoxt_lists.h", "svoxt_fwd_kernels.h", "svoxt_bwd_kernels.h",
            "svoxt_misc_kernels.h", os.path.join("..", "..", "include", "svoxt.h")]
@@ -44,13 +49,41 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH + ".tmp"] + \
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-o", LIB_PATH + ".tmp"] + \
         [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    res = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)
+    remarks, other = [], []
+    for line in res.stderr.splitlines():
+        (remarks if "-Rpass-analysis=kernel-resource-usage" in line else other).append(line)
+    # the remarks come with source excerpts ("  123 | code", "      | ^"): keep warnings and errors only
+    noise = [ln for ln in other if not (ln.lstrip()[:1].isdigit() or ln.lstrip().startswith("|"))]
+    if res.returncode != 0 or any("warning:" in ln or "error:" in ln for ln in noise):
+        print("\n".join(noise), file=sys.stderr)
+    if res.returncode != 0:
+        raise subprocess.CalledProcessError(res.returncode, cmd)
+    with open(RESOURCES_PATH + ".tmp", "w") as f:
+        f.write("\n".join(ln.split("remark: ", 1)[-1].replace(" [-Rpass-analysis=kernel-resource-usage]", "")
+                          for ln in remarks) + "\n")
+    os.replace(RESOURCES_PATH + ".tmp", RESOURCES_PATH)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
+
+
+def kernel_resources(path: str = RESOURCES_PATH) -> dict:
+    """{mangled kernel name: {"VGPRs": n, "ScratchSize [bytes/lane]": n, "Dynamic Stack": "False", ...}}
+    from the remarks of the last build."""
+    out, cur = {}, None
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith("Function Name:"):
+                cur = out.setdefault(line.split(":", 1)[1].strip(), {})
+            elif cur is not None and ":" in line:
+                k, v = line.rsplit(":", 1)
+                cur[k.strip()] = v.strip()
+    return out
 
 
 if __name__ == "__main__":

@@ -43,7 +43,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -93,7 +93,11 @@ class _CLists(ctypes.Structure):         # struct svoxt_sample_lists
                 ("coef", ctypes.c_void_p), ("coef_bytes", ctypes.c_int64),
                 ("terms", ctypes.c_void_p), ("terms_bytes", ctypes.c_int64),
                 ("blocktab", ctypes.c_void_p), ("pool_blocks", ctypes.c_int64), ("pool_next", ctypes.c_void_p),
-                ("terms_state", ctypes.c_int32)]
+                ("terms_state", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+# svoxt_sample_lists.flags (include/svoxt.h)
+LISTS_NATIVE_MATH, LISTS_FWD_ONE_KERNEL, LISTS_FWD_TWO_KERNELS = 1, 2, 4
 
 
 _P = ctypes.POINTER
@@ -111,7 +115,7 @@ EXPORTS = {
     "svoxt_volume_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _vp, _i64, _vp]),
     "svoxt_bwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
     "svoxt_can_record": (ctypes.c_int, [_P(_CTree), _P(_COptions)]),
-    "svoxt_fwd_fills_terms": (ctypes.c_int, [_P(_CTree), _P(_COptions)]),
+    "svoxt_fwd_fills_terms": (ctypes.c_int, [_P(_CTree), _P(_COptions), _i32]),
     "svoxt_sigma_mask_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "svoxt_sigma_mask_build": (ctypes.c_int, [_P(_CTree), ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "svoxt_compact_rows": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
@@ -158,6 +162,62 @@ if _lib.svoxt_abi_version() != ABI_VERSION:
 
 
 # ---------------------------------------------------------------------------
+# Switches.  Every SVOXT_* environment variable this package knows is read HERE, once, at import (the
+# library itself reads none); the module attributes below are what the code consults, so a test or a
+# caller changes behaviour by assigning to them.  README.md has the table (default, result-neutral or not).
+# ---------------------------------------------------------------------------
+def _env_flag(name: str, default: str) -> bool:
+    return os.environ.get(name, default) not in ("", "0")
+
+
+# acceleration-grid resolution: None = chosen from the tree size, 0 = no grid, g = 2^g cells per axis (<= 8)
+ACCEL_LOG2 = (lambda v: None if v is None else max(0, min(8, int(v))))(os.environ.get("SVOXT_ACCEL_LOG2"))
+# SVOXT_SIGMA_MASK=0: the two-kernel forward's march gathers sigma instead of reading a bit per feature row
+SIGMA_MASK = _env_flag("SVOXT_SIGMA_MASK", "1")
+# Samples kept per ray for the backward (8 bytes each; rays with more composited samples march the
+# remainder, so this only trades memory for speed).  0 = never record: the backward traverses the tree itself.
+BWD_LIST_SAMPLES = int(os.environ.get("SVOXT_BWD_LIST", "96"))
+# The same for a forward nobody differentiates: scratch lists for the two-kernel forward
+# (0 = always the one-kernel forward, svoxt_volume_render_fwd).
+FWD_LIST_SAMPLES = int(os.environ.get("SVOXT_FWD_LIST", "96"))
+# SVOXT_LIST_POOL=0: dense sample lists (every ray owns `cap` slots) instead of 4 KB blocks from a pool
+LIST_POOL = _env_flag("SVOXT_LIST_POOL", "1")
+# SVOXT_AUTO_PLAN=0: plain volume_render / volume_render_backward calls hand nothing from forward to backward
+AUTO_PLAN = _env_flag("SVOXT_AUTO_PLAN", "1")
+# SVOXT_SORT_RAYS: "auto" (batches that are not images are rendered in svoxt_ray_order's order from
+# SORT_RAYS_MIN rays on), "0" never, "1" always; RaysSpec.sort per call
+SORT_RAYS = os.environ.get("SVOXT_SORT_RAYS", "auto")
+SORT_RAYS_MIN = 16384
+# SVOXT_FWD_SPLIT: "" = the library's default per payload, "0" / "1" = the forward as one kernel / as march +
+# shade kernels wherever both exist (handed to the library as svoxt_sample_lists.flags)
+FWD_SPLIT = os.environ.get("SVOXT_FWD_SPLIT", "")
+# SVOXT_BWD_GATHER: 0 = always the per-ray backward, 1 (default) = the per-tile one (grad_fused_kernel /
+# grad_wide_kernel) for batches declared as images or rendered in svoxt_ray_order's order, 2 = whenever the payload allows
+BWD_GATHER = int(os.environ.get("SVOXT_BWD_GATHER", "1") or 0)
+# --- the two TOLERANCE modes (not result-neutral; both off by default)
+# SVOXT_BWD_EXACT=0: the single-march backward -- accum = sum_c g_c * out_c from the forward's output, one
+# sweep over the lists instead of two: equal up to the rounding of that sum, which moves 36 % of the
+# sigma-column entries by more than 1e-5 of their own value (tests/test_gpu_query_and_misc.py)
+BWD_EXACT = _env_flag("SVOXT_BWD_EXACT", "1")
+# SVOXT_NATIVE_MATH=1: RGBA-style rows of 8 / 16 / 32 floats are SHADED with the hardware's exponential and
+# reciprocal (forward and per-tile backward; include/svoxt.h SVOXT_LISTS_NATIVE_MATH); the stepping stays
+# bit-exact.  Outputs within 1e-5 relative, gradients within 1e-5 of the tight scale (tested at full size).
+NATIVE_MATH = _env_flag("SVOXT_NATIVE_MATH", "0")
+# --- not environment switches: routes the tests exercise by assignment
+BWD_TERMS = True     # False: no hand-over between the sweeps of the exact backwards (every row gathered twice)
+BWD_FUSED = True     # False: list walk and per-tile merge of an image's backward as two kernels (the form view rotations take)
+
+
+def _list_flags(native: bool = False) -> int:
+    f = LISTS_NATIVE_MATH if native else 0
+    if FWD_SPLIT == "0":
+        f |= LISTS_FWD_ONE_KERNEL
+    elif FWD_SPLIT not in ("", "0"):
+        f |= LISTS_FWD_TWO_KERNELS
+    return f
+
+
+# ---------------------------------------------------------------------------
 # Spec classes (svox.cpp:74-117): default-constructed, read/write attributes.
 # ---------------------------------------------------------------------------
 
@@ -194,6 +254,11 @@ class TreeSpec:
         self.joint_index = None
         self.n_internal = 0
         self.transformation_matrices = None
+        # optional (not in the reference): the caller's promise that `features` is not written behind
+        # torch's back (through `.data`, a raw pointer, a storage swap) while this tree is rendered, so that
+        # data derived from its CONTENT (the sigma bitmask) may be cached across forwards on the tensor's
+        # version counter.  False: such data is rebuilt by every forward.  N3Tree.static_features sets it.
+        self.static_features = False
 
 
 class CameraSpec:
@@ -309,16 +374,16 @@ def _pack_tree(tree: TreeSpec) -> _CTree:
 # device address can never alias a stale grid) and is valid only while the torch
 # version counters of child and data are unchanged (every in-place torch op
 # bumps them, as N3Tree.refine / construct_tree do) and `data` is the same
-# tensor object.  SVOXT_ACCEL_LOG2=0 disables the grid, =g forces a resolution;
-# default: chosen from the tree size.
+# tensor object.  A writer that bypasses the version counter (`child.data[...] = v`, a kernel of its own)
+# must call invalidate_caches(); N3Tree.refine / construct_tree / parallel.broadcast_tree do.
+# ACCEL_LOG2 (SVOXT_ACCEL_LOG2) = 0 disables the grid, = g forces a resolution; default: chosen from the tree size.
 # ---------------------------------------------------------------------------
 _ACCEL_CACHE: dict = {}     # id(child tensor) -> (weakref to it, ...); entries are dropped when the tensor dies
 
 
 def _accel_log2_for(n_internal: int, N: int, feature_bytes: int = 0) -> int:
-    env = os.environ.get("SVOXT_ACCEL_LOG2")
-    if env is not None:
-        return max(0, min(8, int(env)))
+    if ACCEL_LOG2 is not None:
+        return ACCEL_LOG2
     if N != 2 or n_internal < 64:
         return 0
     slots = n_internal * 8
@@ -372,23 +437,26 @@ def _pack_tree_accel(tree: TreeSpec) -> _CTree:
 
 # ---------------------------------------------------------------------------
 # Sigma bitmask (include/svoxt.h, svoxt_sigma_mask_build): one bit per feature row, for the march of
-# the two-kernel forward.  Derived from the CONTENT of `features`: cached like the acceleration grid
-# (tensor object + torch version counter) for forwards nobody differentiates; a forward that records
-# for a backward belongs to a training step whose features have just changed, so it builds the mask
-# afresh every time (inside whatever the caller times) instead of pretending the cache would hit.
-# SVOXT_SIGMA_MASK=0: never.  Default: whenever the forward about to run is the two-kernel one and its
-# march can use it (r02: depth 9 / 578 MB of features, forward 1.29 -> 1.05 ms; depth 8 / 66 MB, where the
-# gather still hits the Infinity Cache, forward+backward 955 -> 972 Mrays/s with the rebuild inside the step).
-SIGMA_MASK = os.environ.get("SVOXT_SIGMA_MASK", "auto")
+# the two-kernel forward.  Derived from the CONTENT of `features`, which torch's version counter does not
+# vouch for: `param.data.add_(...)` and `tree.features.data[key] = v` -- the reference's own idiom --
+# leave it unchanged.  The mask is therefore built afresh by EVERY forward that uses it
+# (M / 8 bytes written, one line of the table read per row: 0.012 ms at depth 8, 0.10 ms for the 578 MB
+# table of depth 9), inside whatever the caller times -- unless the caller has declared the table static
+# (TreeSpec.static_features, set by N3Tree.static_features = True: an inference server's frozen tree):
+# then it is cached on the tensor object, its version counter and its data pointer like the
+# acceleration grid.  SIGMA_MASK (SVOXT_SIGMA_MASK=0) False: never.  (r02: depth 9 / 578 MB of features,
+# forward 1.29 -> 1.05 ms; depth 8 / 66 MB, where the gather still hits the Infinity Cache,
+# forward+backward 955 -> 972 Mrays/s with the rebuild inside the step.)
 _SIGMA_CACHE: dict = {}
 
 
 def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool) -> None:
     f = tree.features
-    if SIGMA_MASK == "0" or ct.M == 0:
+    if not SIGMA_MASK or ct.M == 0:
         return
     key = id(f)
     mask = None
+    keep = keep and bool(getattr(tree, "static_features", False))
     if keep:
         ent = _SIGMA_CACHE.get(key)
         if ent is not None and ent[0]() is f and ent[1] == (f._version, f.data_ptr()) and ent[2] == thresh:
@@ -399,12 +467,29 @@ def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool) ->
             mask = torch.empty((_lib.svoxt_sigma_mask_bytes(ct.M) // 8,), dtype=torch.int64, device=dev)
             _call("svoxt_sigma_mask_build", ctypes.byref(ct), ctypes.c_float(thresh), _ptr(mask), _stream(dev))
         if keep:
-            # (the data pointer too: `param.data = other` swaps the storage without touching the version counter)
             _SIGMA_CACHE[key] = (weakref.ref(f, lambda _r, _k=key: _SIGMA_CACHE.pop(_k, None)),
                                  (f._version, f.data_ptr()), thresh, mask)
     ct.sigma_mask = mask.data_ptr()
     ct.sigma_mask_thresh = thresh
     ct._keepalive_mask = mask
+
+
+def invalidate_caches(*tensors) -> None:
+    """Drop what this module derived from the CONTENT of the given tensors (child / data: the acceleration
+    grid; features: a cached sigma bitmask) and bump their torch version counters.  For writers that bypass
+    the counters: `t.data[...] = v`, raw-pointer kernels, collectives into `.data`.  No arguments: everything."""
+    if not tensors:
+        _ACCEL_CACHE.clear()
+        _SIGMA_CACHE.clear()
+        return
+    ids = {id(t) for t in tensors if isinstance(t, torch.Tensor)}
+    for k in [k for k, ent in _ACCEL_CACHE.items() if k in ids or id(ent[2]()) in ids]:
+        _ACCEL_CACHE.pop(k, None)
+    for k in ids:
+        _SIGMA_CACHE.pop(k, None)
+    for t in tensors:
+        if isinstance(t, torch.Tensor):
+            torch.autograd.graph.increment_version(t)
 
 
 def _pack_camera(cam: "CameraSpec") -> _CRays:
@@ -486,26 +571,13 @@ def get_out_data_dim(opt: RenderOptions, K: int) -> int:
 # Hot-path operators
 # ---------------------------------------------------------------------------
 
-# Samples kept per ray for the backward (8 bytes each; rays with more composited
-# samples march the remainder, so this only trades memory for speed).
-# 0 = never record: the backward then traverses the tree itself.
-BWD_LIST_SAMPLES = int(os.environ.get("SVOXT_BWD_LIST", "96"))
-# The same for a forward nobody differentiates: scratch lists for the two-kernel forward
-# (0 = always the one-kernel forward, svoxt_volume_render_fwd).
-FWD_LIST_SAMPLES = int(os.environ.get("SVOXT_FWD_LIST", "96"))
-# SVOXT_FAST_SIGMOID=1: opt into the tolerance mode of forwards nobody differentiates (include/svoxt.h,
-# SVOXT_FWD_FAST_SIGMOID: float quotient for RGBA-style rows of 8 / 16 / 32 floats, outputs within 1e-5)
-FAST_SIGMOID = os.environ.get("SVOXT_FAST_SIGMOID", "0") not in ("", "0")
-
-
 # Pooled lists (include/svoxt.h, svoxt_sample_lists.blocktab): the records live in 4 KB blocks handed
 # out per (tile, 8 list positions) from a pool, so memory follows the samples that exist instead of
 # cap x rays (800x800, depth-8 SH9: 47 MB of records in a 491 MB dense buffer).  How large a pool a
 # batch needs is learned from the forward before it: its block counter is copied to pinned host
 # memory without waiting, and the next lists of the same shape are sized 1.25x what was used (twice
 # the pool if it ran dry -- a ray that finds no block stops recording and marches the rest, so a pool
-# that is too small costs time, never correctness).  SVOXT_LIST_POOL=0: dense lists.
-LIST_POOL = os.environ.get("SVOXT_LIST_POOL", "1") not in ("", "0")
+# that is too small costs time, never correctness).  LIST_POOL (SVOXT_LIST_POOL=0) False: dense lists.
 _POOL_HINT: dict = {}       # (tiles, S) -> [blocks to allocate, pending (event, pinned counter, capacity) or None, forwards seen]
 
 
@@ -558,6 +630,7 @@ class SampleLists:
         self.consumed = False   # which rewrites `rec`: the lists then serve no second backward
         self.terms = None       # (att, e0, e1, e2) per record slot for the exact one-kernel backward
         self.terms_state = 0    # 2: filled by the forward; 0: scratch (the backward's first sweep fills it)
+        self.flags = 0          # svoxt_sample_lists.flags: how the kernels that write / read these lists work
 
     def note_usage(self):
         """After the forward that filled the lists was enqueued: remember how much of the pool it took
@@ -585,7 +658,7 @@ class SampleLists:
                        None if self.blocktab is None else self.blocktab.data_ptr(),
                        self.pool_blocks if self.pooled else 0,
                        None if self.pool_next is None else self.pool_next.data_ptr(),
-                       self.terms_state)
+                       self.terms_state, self.flags)
 
 
 def _list_cap(ct: "_CTree", base: int) -> int:
@@ -652,26 +725,46 @@ def _permute_rows(src: torch.Tensor, perm32: torch.Tensor, scatter: bool) -> tor
 # nothing (another spec object, features changed in place since, SVOXT_AUTO_PLAN=0) marches, as
 # the reference does.  The explicit forms (record=True / lists= / fwd_output=) remain.
 # ---------------------------------------------------------------------------
-AUTO_PLAN = os.environ.get("SVOXT_AUTO_PLAN", "1") not in ("", "0")
 # Batches that are not declared images are rendered in a coherent order (svoxt_ray_order,
 # include/svoxt.h: sort by the rays' entry points into the cube, three gathers, a scatter --
 # ~0.3 ms per 640 000 rays) from SORT_RAYS_MIN rays on, and their backward then takes the
 # per-tile route: 640 000 rays forward+backward, shuffled within one camera 1.47 -> 0.93 ms,
 # drawn from 8 cameras 1.48 -> 1.29 ms, row-major but not declared an image 1.29 -> 0.92 ms
-# (profiles/r01_s_ray_order_timing.txt).  SVOXT_SORT_RAYS=0 never, =1 always; RaysSpec.sort per call.
-SORT_RAYS = os.environ.get("SVOXT_SORT_RAYS", "auto")
-SORT_RAYS_MIN = 16384
+# (profiles/r01_s_ray_order_timing.txt).  SORT_RAYS (SVOXT_SORT_RAYS) "0" never, "1" always; RaysSpec.sort per call.
 
 
 class _Plan:
     """What a forward leaves on its rays / camera spec for the backward of the same call."""
-    __slots__ = ("features", "fver", "optkey", "lists", "out", "over", "perm", "rays")
+    __slots__ = ("kind", "features", "fkey", "tkey", "rkey", "optkey", "lists", "out", "over", "perm", "rays")
 
 
 def _opt_key(opt):
     return (float(opt.step_size), float(opt.background_brightness), int(opt.format), int(opt.basis_dim),
             int(opt.ndc_width), int(opt.ndc_height), float(opt.ndc_focal), int(opt.min_comp), int(opt.max_comp),
             float(opt.sigma_thresh), float(opt.stop_thresh))
+
+
+def _tkey(t):
+    """Identity of a tensor's content as far as torch can vouch for it: storage address, version, shape."""
+    if not isinstance(t, torch.Tensor) or t.numel() == 0:
+        return None
+    return (t.data_ptr(), t._version, tuple(t.shape))
+
+
+def _tree_key(tree):
+    """What the recorded lists depend on besides the features: the topology and the view rotations."""
+    return (_tkey(tree.child), _tkey(tree.data), int(tree.n_internal or 0), _tkey(tree.offset), _tkey(tree.scaling),
+            _tkey(tree.transformation_matrices))
+
+
+def _rays_key(rays):
+    """... and the rays: the reference's backward re-marches whatever the spec holds NOW (renderer.py:64-72),
+    so lists recorded for other ray values must not be replayed."""
+    if isinstance(rays, CameraSpec):
+        return ("cam", _tkey(rays.c2w), float(rays.fx), float(rays.fy), int(rays.width), int(rays.height))
+    return ("rays", _tkey(rays.origins), _tkey(rays.dirs), _tkey(rays.vdirs),
+            int(getattr(rays, "image_width", 0) or 0), int(getattr(rays, "image_height", 0) or 0),
+            _tkey(getattr(rays, "order", None)))
 
 
 def _wants_sort(rays) -> bool:
@@ -715,14 +808,20 @@ def _need_grad(tree, rays):
     return bool(tree.features.requires_grad) if ng is None else bool(ng)
 
 
-def _planned_forward(render, tree, rays, opt):
-    """render(tree, rays_spec, opt, record) -> (out, lists): the forward of a plain call."""
+def _planned_forward(kind, render, tree, rays, opt):
+    """render(tree, rays_spec, opt, record) -> (out, lists): the forward of a plain call of operator `kind`."""
     rr, perm = _in_coherent_order(tree, rays, opt)
     if _need_grad(tree, rays):
         out, lists = render(tree, rr, opt, True)
         p = _Plan()
-        p.features, p.fver, p.optkey = tree.features, tree.features._version, _opt_key(opt)
-        p.lists, p.out, p.over, p.perm, p.rays = lists, out, out._version, perm, rr
+        f = tree.features
+        p.kind, p.features, p.fkey, p.optkey = kind, f, (f._version, f.data_ptr()), _opt_key(opt)
+        p.tkey, p.rkey = _tree_key(tree), _rays_key(rays)
+        # `out` is the very tensor autograd hangs this call's node on; the node keeps the ctx, the ctx the
+        # spec, the spec this plan: a reference to `out` itself would close a cycle that only the cyclic
+        # collector breaks, and a forward nobody runs a backward for would keep its lists (tens to hundreds
+        # of MB) until then.  A detached alias has no grad_fn and shares storage and version counter.
+        p.lists, p.out, p.over, p.perm, p.rays = lists, out.detach(), out._version, perm, rr
         rays._svoxt_plan = p
     else:
         out = render(tree, rr, opt, False)
@@ -730,12 +829,17 @@ def _planned_forward(render, tree, rays, opt):
     return _to_caller_order(out, perm)
 
 
-def _take_plan(tree, rays, opt):
+def _take_plan(kind, tree, rays, opt):
+    """The plan the forward of the same operator left on this spec -- or None (the backward then marches, as
+    the reference's does) if anything the lists were recorded for may have changed since: the feature table
+    (object, version, storage), the topology, the view rotations, the rays / camera, the options."""
     p = getattr(rays, "_svoxt_plan", None)
     if p is None:
         return None
     rays._svoxt_plan = None              # the lists serve one backward; a second one marches
-    if p.features is not tree.features or p.fver != tree.features._version or p.optkey != _opt_key(opt):
+    f = tree.features
+    if p.kind != kind or p.features is not f or p.fkey != (f._version, f.data_ptr()) or p.optkey != _opt_key(opt) \
+            or p.tkey != _tree_key(tree) or p.rkey != _rays_key(rays):
         return None
     return p
 
@@ -748,7 +852,7 @@ def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bo
     lists = None when recording does not apply (non-zero thresholds, a payload
     without a specialised kernel, SVOXT_BWD_LIST=0)."""
     if not record and AUTO_PLAN:
-        return _planned_forward(lambda t, r, o, rec: _volume_render(t, r, o, rec), tree, rays, opt)
+        return _planned_forward("volume", lambda t, r, o, rec: _volume_render(t, r, o, rec), tree, rays, opt)
     return _volume_render(tree, rays, opt, record)
 
 
@@ -760,26 +864,27 @@ def _volume_render(tree, rays, opt, record):
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
     lists = None
-    env = os.environ.get("SVOXT_FWD_SPLIT", "")
     wide = co.format == FORMAT_RGBA and ct.K in (8, 16, 32)
-    split = (env not in ("", "0")) if env != "" else wide
+    split = (FWD_SPLIT != "0") if FWD_SPLIT != "" else wide
     will_record = bool(record and BWD_LIST_SAMPLES > 0 and cr.Q > 0 and
                        _lib.svoxt_can_record(ctypes.byref(ct), ctypes.byref(co)))
-    fills = _lib.svoxt_fwd_fills_terms(ctypes.byref(ct), ctypes.byref(co)) \
+    lflags = _list_flags(native=NATIVE_MATH and wide)
+    fills = _lib.svoxt_fwd_fills_terms(ctypes.byref(ct), ctypes.byref(co), lflags) \
         if (will_record and BWD_EXACT and BWD_TERMS and BWD_FUSED and BWD_GATHER) else 0
     # the march of the two-kernel forward reads a bit per row instead of gathering sigma -- where that
     # forward is what runs and the stop rule (which needs sigma itself) does not apply
-    if ((split or fills == 3) and env != "0") if will_record else (split and co.stop_thresh == 0.0):
+    if ((split or fills == 3) and FWD_SPLIT != "0") if will_record else (split and co.stop_thresh == 0.0):
         _attach_sigma_mask(tree, ct, float(co.sigma_thresh), keep=not will_record)
     LAST_ROUTE["forward_terms"] = False
     LAST_ROUTE["forward"] = (("march_rec_kernel + shade_chan_kernel (two-kernel forward, channels on lanes"
-                              + (", float quotient)" if FAST_SIGMOID and not record else ")") if wide else
+                              + (", native exp / rcp)" if NATIVE_MATH else ")") if wide else
                               "march_rec_kernel + shade_tile_kernel (two-kernel forward)") if split
                              else "render_fwd_kernel") + (", recording sample lists" if record else "")
     with torch.cuda.device(dev):
         out = torch.empty((cr.Q, get_out_data_dim(opt, ct.K)), dtype=torch.float32, device=dev)
         if will_record:
             lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
+            lists.flags = lflags
             if fills:
                 # the exact per-tile backward will want (att, e0, e1, e2) of every sample: this forward has them
                 lists.terms = torch.empty((lists.pool_blocks * 512 * 4,), dtype=torch.float32, device=dev)
@@ -789,44 +894,37 @@ def _volume_render(tree, rays, opt, record):
                   _ptr(out), ctypes.byref(cl), _stream(dev))
             lists.note_usage()
             LAST_ROUTE["forward_terms"] = lists.terms_state in (2, 3)
-            if lists.terms_state == 3 and os.environ.get("SVOXT_FWD_SPLIT", "") == "":
+            if lists.terms_state == 3 and FWD_SPLIT == "":
                 LAST_ROUTE["forward"] = "march_rec_kernel + shade_tile_kernel (two-kernel forward), recording sample lists"
         elif FWD_LIST_SAMPLES > 0 and cr.Q > 0:
             # scratch for the two-kernel forward (march, then shade per tile; the library falls
             # back to the one-kernel forward for payloads it does not cover)
             if LIST_POOL:
                 scratch = SampleLists(cr.Q, _list_cap(ct, FWD_LIST_SAMPLES), dev)
+                scratch.flags = lflags
                 cl = scratch.c_struct()
                 _call("svoxt_volume_render_fwd_scratch", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
-                      _ptr(out), ctypes.byref(cl), 1 if FAST_SIGMOID else 0, _stream(dev))
+                      _ptr(out), ctypes.byref(cl), 0, _stream(dev))
                 scratch.note_usage()
             else:
                 nbytes = _lib.svoxt_fwd_workspace_bytes(cr.Q, FWD_LIST_SAMPLES)
                 ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
                 _call("svoxt_volume_render_fwd_ws", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
-                      _ptr(out), _ptr(ws), nbytes, 1 if FAST_SIGMOID else 0, _stream(dev))
+                      _ptr(out), _ptr(ws), nbytes, lflags, _stream(dev))
         else:
             _call("svoxt_volume_render_fwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(out), _stream(dev))
     return (out, lists) if record else out
 
 
-# The backward's arithmetic.  Default (exact): `accum` and the ray's final transmittance are added
+# The backward's arithmetic.  Default (BWD_EXACT): `accum` and the ray's final transmittance are added
 # up sequentially over the ray's samples as the reference's first pass does (rt_kernel.cu:365-437),
-# every gradient contribution bit-identical to the reference's formulas.  SVOXT_BWD_EXACT=0 opts
+# every gradient contribution bit-identical to the reference's formulas.  BWD_EXACT False opts
 # into the single march: accum = sum_c g_c * out_c from the forward's output -- one sweep over the
-# lists instead of two (0.34 vs 0.43 ms on the headline workload, r02), equal up to the rounding of
-# that sum, which is enough to move 36 % of the sigma-column entries by more than 1e-5 of their own
-# value (tests/test_gpu_query_and_misc.py::test_config3_backward_relative_error_both_routes).
-BWD_EXACT = os.environ.get("SVOXT_BWD_EXACT", "1") not in ("", "0")
-# SVOXT_BWD_GATHER=0: always the one-kernel backward (every sample's row goes to memory as
-# shaped atomics); 1 (default): the two-kernel one (list walk -> factored records -> per-tile
-# merge in LDS -> one atomic row per tile and feature row, include/svoxt.h
-# svoxt_sample_lists.coef) for batches declared as images; 2: whenever the payload allows
-GATHER_ALIGNED = os.environ.get("SVOXT_GATHER_ALIGNED", "1") not in ("", "0")   # 64-byte-aligned rows for the merge kernel too
-BWD_TERMS = os.environ.get("SVOXT_BWD_TERMS", "1") not in ("", "0")   # 0: the exact one-kernel backward gathers every row twice
-BWD_FUSED = os.environ.get("SVOXT_BWD_FUSED", "1") not in ("", "0")   # 0: list walk and merge as two kernels (a coef buffer is handed over)
-BWD_GATHER = int(os.environ.get("SVOXT_BWD_GATHER", "1") or 0)     # 0 never, 1 for image batches, 2 whenever possible
+# lists instead of two (0.34 vs 0.43 ms on the headline workload, r02).
+# BWD_GATHER 0: always the per-ray backward (every sample's row goes to memory as shaped atomics); 1: the
+# per-tile one (lists -> per-tile merge in LDS -> one atomic row per tile, window and feature row) for
+# batches declared as images or in svoxt_ray_order's order; 2: whenever the payload allows.
 
 
 def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
@@ -838,7 +936,7 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
     backward its first pass (include/svoxt.h, svoxt_volume_render_bwd_replay).
     Neither given: what the forward of the same spec objects left behind (see _Plan)."""
     if lists is None and fwd_output is None and AUTO_PLAN:
-        p = _take_plan(tree, rays, opt)
+        p = _take_plan("volume", tree, rays, opt)
         if p is not None:
             _check_input(grad_output, "grad_output")
             g = grad_output if p.perm is None else _permute_rows(grad_output, p.perm, scatter=False)
@@ -868,8 +966,6 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
     coherent = tiled or bool(getattr(rays, "coherent", False))      # or sorted by svoxt_ray_order
     gather = lists is not None and K <= 32 and grad_output.shape[1] == 4 and ct.N == 2 and \
         (BWD_GATHER == 2 or (BWD_GATHER == 1 and coherent))
-    if gather and not GATHER_ALIGNED:
-        stride = K
     with torch.cuda.device(dev):
         buf = torch.empty((M, stride), dtype=torch.float32, device=dev)
         if lists is not None:
@@ -906,7 +1002,8 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
                 ("grad_fused_kernel<EXACT> (two sweeps over the lists + per-tile merge)" if fo is None else
                  "grad_fused_kernel (one sweep over the lists + per-tile merge; accum from the forward's output)") if fused else
                 "render_bwd_kernel<GATHER> + grad_merge_kernel (list walk, then per-tile merge)" if gather else
-                "grad_wide_kernel (two sweeps over the lists, sigmoids per record once + once per distinct row; per-tile merge)"
+                ("grad_wide_kernel (two sweeps over the lists, sigmoids per record once + once per distinct row; per-tile merge"
+                 + (", native exp / rcp)" if lists.flags & LISTS_NATIVE_MATH else ")"))
                 if wide_tile else
                 "render_bwd_kernel<ONEPASS> (two list walks, sigmoids formed once; one atomic row + one sigma atomic per sample)"
                 if (wide and fo is None and BWD_TERMS) else
@@ -968,7 +1065,7 @@ def opacity_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: b
     """rt_kernel.cu:1574-1591.  `record=True` (not in the reference): also return the
     sample lists opacity_render_backward can walk (None when thresholds are non-zero)."""
     if not record and AUTO_PLAN:
-        return _planned_forward(lambda t, r, o, rec: _opacity_render(t, r, o, rec), tree, rays, opt)
+        return _planned_forward("opacity", lambda t, r, o, rec: _opacity_render(t, r, o, rec), tree, rays, opt)
     return _opacity_render(tree, rays, opt, record)
 
 
@@ -995,7 +1092,7 @@ def opacity_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
     opacity_render(..., record=True) returned for the same tree / rays / options; not given:
     what the forward of the same spec objects left behind (see _Plan)."""
     if lists is None and AUTO_PLAN:
-        p = _take_plan(tree, rays, opt)
+        p = _take_plan("opacity", tree, rays, opt)
         if p is not None:
             _check_input(grad_output, "grad_output")
             g = grad_output if p.perm is None else _permute_rows(grad_output, p.perm, scatter=False)

@@ -1169,10 +1169,19 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 //            at 1024 x 1024 / depth 9, exp/reuse_probe.py).
 // Rays whose list overflowed: a tail-only launch of render_bwd_kernel<..., GATHER> in front
 // (aux.z / .w carry its pass-1 results), as for grad_fused_kernel<EXACT>.
-template <int K>
+// FAST (opt-in tolerance mode, SVOXT_LISTS_NATIVE_MATH): the sigmoids and the attenuation of both sweeps
+// with the hardware's exponential and reciprocal (nsigmoidf / nexpf: ~5 instructions where the exact
+// replica of expf plus a double-precision divide are ~45 -- r02 PMC: 783 M vector instructions, 65 %
+// VALU busy at 1024 x 1024 / depth 9), the second pass's total_color summed in float; lists, hash,
+// sort and the order of the additions unchanged.  Gradients within 1e-5 of the tight scale.
+// COUNT (instrumentation, svoxt_set_bwd_counters): counters[0] += 64-byte atomic requests sent (a row of
+// K floats that starts on a K * 4-byte boundary: two for K = 32, one for K = 16 / 8), counters[1] +=
+// (tile, window, feature row) groups.
+template <int K, bool FAST = false, bool COUNT = false>
 __global__ void __launch_bounds__(512, 6)
 grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
-                 RecLists L, const uint4* __restrict__ aux, float* __restrict__ grad, int gstride) {
+                 RecLists L, const uint4* __restrict__ aux, float* __restrict__ grad, int gstride,
+                 unsigned long long* __restrict__ counters = nullptr) {
     static_assert(K == 8 || K == 16 || K == 32, "row widths with an instance");
     constexpr int C = K - 1, W = 8, NT = 64 * W, T = 1024, R = 1024, RPP = R / (64 * W);
     constexpr int KG = K | 1;                                // odd stride: conflict-free gradient rows
@@ -1266,10 +1275,15 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (8 * gq + j < C) {                      // (the last lane's eighth column is sigma)
-                        const double sd = sigmoid_d<true>(row[j]);
                         const float gj = gr[j];
-                        a1[j] = (float)sd * gj;
-                        a2[j] = sd * (double)gj;
+                        if constexpr (FAST) {
+                            a1[j] = nsigmoidf(row[j]) * gj;
+                            a2[j] = (double)a1[j];
+                        } else {
+                            const double sd = sigmoid_d<true>(row[j]);
+                            a1[j] = (float)sd * gj;
+                            a2[j] = sd * (double)gj;
+                        }
                     } else {
                         a1[j] = 0.f; a2[j] = 0.0;
                     }
@@ -1286,15 +1300,16 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                     for (int j = 0; j < 8; ++j) {
                         if (rr * 8 + j < C) {
                             t1 += a1[j];
-                            t2 = (float)((double)t2 + a2[j]);
+                            if constexpr (!FAST) t2 = (float)((double)t2 + a2[j]);
                         }
                     }
                 }
             }
             if (on && gq == G - 1) {
-                r_w[slot] = pexpf<true>(-r_dt[slot] * row[7] * dsl[ray]);
+                const float arg = -r_dt[slot] * row[7] * dsl[ray];
+                r_w[slot] = FAST ? nexpf(arg) : pexpf<true>(arg);
                 r_t1[slot] = t1;
-                r_sg[slot] = t2;
+                r_sg[slot] = FAST ? t1 : t2;          // (FAST: one float sum serves both passes)
             }
         }
         __syncthreads();
@@ -1437,6 +1452,12 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
         __syncthreads();
         // ---- reduce: lane = column; after the scatter cnt[h] is where the records of entry h END
         const int ns = __builtin_amdgcn_readfirstlane(s_ns);
+        if constexpr (COUNT) {
+            if (threadIdx.x == 0 && ns > 0) {
+                atomicAdd(counters, (unsigned long long)ns * (K * 4 > 64 ? (K * 4) / 64 : 1));
+                atomicAdd(counters + 1, (unsigned long long)ns);
+            }
+        }
         const int col = lane & (K - 1), sub = lane / K;
         constexpr int D = 4;                                 // rows in flight per lane: a row gather is ~1 us, its use ~0.3 us
         for (int i0 = wave * SPW; i0 < ns; i0 += D * W * SPW) {
@@ -1463,7 +1484,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                 const int p = ps[u];
                 float sig = 0.f, om = 0.f;
                 if (idx >= 0 && col < C) {
-                    sig = (float)sigmoid_d<true>(xs[u]);
+                    sig = FAST ? nsigmoidf(xs[u]) : (float)sigmoid_d<true>(xs[u]);
                     om = 1.f - sig;
                 }
                 float acc = 0.f;

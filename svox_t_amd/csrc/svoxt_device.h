@@ -459,6 +459,19 @@ __device__ __forceinline__ float pexpf(float x) {
     return (x != x) ? x : y;
 }
 
+// Tolerance-grade arithmetic for the opt-in SVOXT_LISTS_NATIVE_MATH mode (shading only; never the stepping):
+// e^x as v_exp_f32(x * log2 e).  v_exp_f32 is good to 1 ulp; the rounding of the product adds up to
+// 2^-24 |x log2 e| to the exponent, i.e. a relative error of |x| * 6e-8 in the result (4e-7 at |x| = 6,
+// 5e-6 at the float range's end) -- where CUDA's expf, which the reference calls, is specified to
+// 2 ulp (rt_kernel.cu:280, 300, 304, 397, 408, 420, 461, 472, 476).  Results below 2^-126 flush to 0.
+__device__ __forceinline__ float nexpf(float x) {
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+}
+// 1 / (1 + e^-x) with the hardware reciprocal (1 ulp) where the reference divides in double
+__device__ __forceinline__ float nsigmoidf(float x) {
+    return __builtin_amdgcn_rcpf(1.f + nexpf(-x));
+}
+
 // t += delta_t (rt_kernel.cu:321), guarded: if the step is too small to move t
 // in float (step_size <= 0 on a degenerate crossing, or ~1e-8 of t) the
 // reference loops forever; here the march ends instead of hanging the GPU.

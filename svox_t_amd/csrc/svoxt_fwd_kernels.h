@@ -518,8 +518,10 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
 // keeps 31 accumulators and the 32-float row per lane: 1.1 wavefronts per SIMD on average and the
 // VALU half idle at 1024 x 1024, depth 9 -- r02 PMC -- because a wavefront shades all 31
 // channels of whichever of its 64 rays have a sample.)
-// FAST (opt-in tolerance mode): the quotient in float with the hardware reciprocal,
-// acc += w * rcp(1 + e): each term within 2e-7 of the reference's double-precision quotient.
+// FAST (opt-in tolerance mode, SVOXT_LISTS_NATIVE_MATH): the lists are the exact march's; the shading
+// takes its exponentials with v_exp_f32 (nexpf) and the quotient with the hardware reciprocal,
+// acc = fma(w, rcp(1 + e), acc) -- a dozen instructions per channel and sample where the bit-exact
+// replica of expf and the double-precision divide are about fifty (r02 PMC: this kernel 100 % VALU-bound).
 template <int K, bool STOP, bool FAST>
 __global__ void __launch_bounds__(256)
 shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
@@ -577,14 +579,17 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
 #pragma unroll
         for (int j = 0; j < kRecBlock; ++j) {
             ex[j] = 1.f;
-            if (j < n_here) ex[j] = pexpf(c == K - 1 ? -dt[j] * ds * x[j] : -x[j]);
+            if (j < n_here) {
+                const float arg = c == K - 1 ? -dt[j] * ds * x[j] : -x[j];
+                ex[j] = FAST ? nexpf(arg) : pexpf(arg);
+            }
         }
 #pragma unroll
         for (int j = 0; j < kRecBlock; ++j) {
             const float att = __shfl(ex[j], sig_lane, 64);       // every lane takes part
             if (j < n_here && !stopped) {
                 const float weight = light * (1.f - att);
-                if constexpr (FAST) acc += weight * __builtin_amdgcn_rcpf(1.f + ex[j]);
+                if constexpr (FAST) acc = __builtin_fmaf(weight, __builtin_amdgcn_rcpf(1.f + ex[j]), acc);
                 else acc = (float)((double)acc + (double)weight / (1.0 + (double)ex[j]));
                 light *= att;
                 if constexpr (STOP) {
@@ -665,11 +670,14 @@ tail_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, uint4* __restrict__ aux, fl
             const float sigma = __shfl(x, sig_lane, 64);
             const bool active = go && valid && sigma > opt.sigma_thresh;
             float ex = 1.f;
-            if (active) ex = pexpf(c == K - 1 ? -dt * r.delta_scale * x : -x);
+            if (active) {
+                const float arg = c == K - 1 ? -dt * r.delta_scale * x : -x;
+                ex = FAST ? nexpf(arg) : pexpf(arg);
+            }
             const float att = __shfl(ex, sig_lane, 64);
             if (active) {
                 const float weight = light * (1.f - att);
-                if constexpr (FAST) acc += weight * __builtin_amdgcn_rcpf(1.f + ex);
+                if constexpr (FAST) acc = __builtin_fmaf(weight, __builtin_amdgcn_rcpf(1.f + ex), acc);
                 else acc = (float)((double)acc + (double)weight / (1.0 + (double)ex));
                 light *= att;
                 if (light <= opt.stop_thresh) { stopped = true; alive = false; }

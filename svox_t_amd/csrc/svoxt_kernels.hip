@@ -298,13 +298,14 @@ bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
 // components.  Default: on for RGBA-style rows of 8 / 16 / 32 floats (shade_chan_kernel: r02,
 // 1024 x 1024 depth-9 K = 32), off for the 3-channel payloads (shade_tile_kernel:
 // 800x800 depth-8 SH9 0.156 + 0.123 ms against 0.247 ms for the one-kernel forward).
-// SVOXT_FWD_SPLIT=0 / 1 forces it off / on where a shade kernel exists.
+// list_flags: SVOXT_LISTS_FWD_ONE_KERNEL / _TWO_KERNELS force it off / on where a shade kernel exists
+// (the caller's choice, handed over with the lists: the library reads no environment).
 // with_terms: a recording forward that is to leave the backward's (att, e_c) -- the tile shade kernel
 // writes them 1 KB at a time for nothing, the one-kernel forward pays 0.06 ms for its scattered lines
 // (r02: 0.145 + 0.13 ms against 0.316 ms) -- so then the two kernels are the default for 3 channels too.
-bool fwd_split_enabled(const svoxt_tree* t, const svoxt_options* o, bool with_terms = false) {   // read per call
-    const char* e = getenv("SVOXT_FWD_SPLIT");
-    if (e != nullptr && *e != 0) return atoi(e) != 0;
+bool fwd_split_enabled(const svoxt_tree* t, const svoxt_options* o, bool with_terms, int32_t list_flags) {
+    if (list_flags & SVOXT_LISTS_FWD_ONE_KERNEL) return false;
+    if (list_flags & SVOXT_LISTS_FWD_TWO_KERNELS) return true;
     if (o->format == SVOXT_FORMAT_RGBA && (t->K == 8 || t->K == 16 || t->K == 32)) return true;
     return with_terms && t->xform == nullptr && t->weight_accum == nullptr;
 }
@@ -381,41 +382,9 @@ bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float
     return false;
 }
 
-// A side stream and a few events per device, made on first use: the march of one range of tiles
-// runs on the caller's stream while the side stream shades the range before it.  (The idea: the
-// march is bound by its dependent loads and leaves the vector ALUs half idle, the shade kernels
-// are bound by those ALUs.  See fwd_split_chunks for what it measured.)
-struct SideStream {
-    hipStream_t st = nullptr;
-    hipEvent_t ev[8] = {};
-    bool ok = false;
-};
-SideStream* side_stream() {
-    static thread_local SideStream tab[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    SideStream& s = tab[dev];
-    if (!s.ok) {
-        if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        for (auto& e : s.ev)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        s.ok = true;
-    }
-    return &s;
-}
-
-// Measured r02 and NOT the default: with 4 ranges the forward got slower, not faster (800x800
-// depth-8 SH9 0.29 -> 0.59 ms, 1024x1024 depth-9 K = 32 1.47 -> 2.0 ms): each cross-stream event
-// dependency costs more than the overlap returns.  SVOXT_FWD_CHUNKS=n (2..7) keeps the experiment
-// reachable; the default is one range on the caller's stream.
-int fwd_split_chunks(int64_t ntiles) {
-    const char* e = getenv("SVOXT_FWD_CHUNKS");
-    int n = (e != nullptr && *e != 0) ? atoi(e) : 1;
-    if (n < 1) n = 1;
-    if (n > 7) n = 7;
-    return (int64_t)n > ntiles ? (int)ntiles : n;
-}
-
+// (Measured r02 and removed in r03: the tiles cut into 2..7 ranges pipelined over two streams, so that
+// the shade of one range runs beside the march of the next -- each cross-stream event dependency cost
+// more than the overlap returned: 800x800 depth-8 SH9 0.29 -> 0.59 ms with 4 ranges.)
 template <bool N2, bool STOP>
 bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out,
                       RecLists L, uint4* aux, bool xf, bool fast, hipStream_t st,
@@ -423,43 +392,25 @@ bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
     const unsigned nb = nblocks(rays.Q);
     if (xf && !N2) return false;
     const bool acc = N2 && tr.accel != nullptr;
-    int nchunk = fwd_split_chunks(nb);
-    SideStream* ss = nchunk > 1 ? side_stream() : nullptr;
-    if (ss == nullptr) nchunk = 1;
-    bool ok = true;
-    for (int c = 0; c < nchunk && ok; ++c) {
-        const unsigned lo = (unsigned)((uint64_t)nb * c / nchunk), hi = (unsigned)((uint64_t)nb * (c + 1) / nchunk);
-        RaysDev rc = rays;
-        rc.tile0 = lo;
-        if constexpr (!STOP) {
-            if (sigma_mask != nullptr) {
-                if (acc) hipLaunchKernelGGL((march_rec_kernel<N2, false, 1, true>), dim3(hi - lo), dim3(kBlock), 0, st, tr, rc, opt, L, aux, sigma_mask);
-                else hipLaunchKernelGGL((march_rec_kernel<N2, false, 0, true>), dim3(hi - lo), dim3(kBlock), 0, st, tr, rc, opt, L, aux, sigma_mask);
-            }
-        }
-        if (STOP || sigma_mask == nullptr) {
-            if (acc) hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 1>), dim3(hi - lo), dim3(kBlock), 0, st, tr, rc, opt, L, aux, (const uint32_t*)nullptr);
-            else hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 0>), dim3(hi - lo), dim3(kBlock), 0, st, tr, rc, opt, L, aux, (const uint32_t*)nullptr);
-        }
-        if (nchunk == 1) {
-            ok = launch_shade<N2, STOP>(tr, rc, opt, out, L, aux, xf, fast, hi - lo, st);
-        } else {
-            // the side stream takes over this range once its march is done
-            if (hipEventRecord(ss->ev[c], st) != hipSuccess || hipStreamWaitEvent(ss->st, ss->ev[c], 0) != hipSuccess) return false;
-            ok = launch_shade<N2, STOP>(tr, rc, opt, out, L, aux, xf, fast, hi - lo, ss->st);
+    if constexpr (!STOP) {
+        if (sigma_mask != nullptr) {
+            if (acc) hipLaunchKernelGGL((march_rec_kernel<N2, false, 1, true>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, L, aux, sigma_mask);
+            else hipLaunchKernelGGL((march_rec_kernel<N2, false, 0, true>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, L, aux, sigma_mask);
         }
     }
-    if (nchunk > 1) {   // join: what follows on the caller's stream sees every pixel
-        if (hipEventRecord(ss->ev[7], ss->st) != hipSuccess || hipStreamWaitEvent(st, ss->ev[7], 0) != hipSuccess) return false;
+    if (STOP || sigma_mask == nullptr) {
+        if (acc) hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 1>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, L, aux, (const uint32_t*)nullptr);
+        else hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 0>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, L, aux, (const uint32_t*)nullptr);
     }
-    return ok;
+    return launch_shade<N2, STOP>(tr, rays, opt, out, L, aux, xf, fast, nb, st);
 }
 
 // two-kernel backward: SH 1/4/9 (also with view rotations) and RGBA with 3 channels
 // (K <= 32) on N = 2 trees
 bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
                        const float* grad_out, float* grad, int gstride, RecLists L, const uint4* aux,
-                       const float* fwd_out, float4* coef, bool xf, hipStream_t st, int terms_state = 0) {
+                       const float* fwd_out, float4* coef, bool xf, hipStream_t st, int terms_state = 0,
+                       bool native = false) {
     const unsigned nb = nblocks(rays.Q);
     if (C > 3) {
         // RGBA-style rows of 8 / 16 / 32 floats: the exact per-tile form only (one kernel, a float per
@@ -469,8 +420,16 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
     {                                                                                                         \
         hipLaunchKernelGGL((render_bwd_kernel<FMT_RGBA, KK - 1, 0, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
                            tr, rays, opt, grad_out, grad, gstride, L, aux, (const float*)nullptr, (float4*)nullptr); \
-        hipLaunchKernelGGL((grad_wide_kernel<KK>), dim3(nb), dim3(512), 0, st, tr, rays, opt, grad_out, L, aux, \
-                           grad, gstride);                                                                    \
+        unsigned long long* ctr = reinterpret_cast<unsigned long long*>(g_bwd_counters);                      \
+        if (ctr != nullptr)                                                                                   \
+            hipLaunchKernelGGL((grad_wide_kernel<KK, false, true>), dim3(nb), dim3(512), 0, st, tr, rays, opt, grad_out, L, aux, \
+                               grad, gstride, ctr);                                                           \
+        else if (native)                                                                                      \
+            hipLaunchKernelGGL((grad_wide_kernel<KK, true>), dim3(nb), dim3(512), 0, st, tr, rays, opt, grad_out, L, aux, \
+                               grad, gstride, (unsigned long long*)nullptr);                                  \
+        else                                                                                                  \
+            hipLaunchKernelGGL((grad_wide_kernel<KK, false>), dim3(nb), dim3(512), 0, st, tr, rays, opt, grad_out, L, aux, \
+                               grad, gstride, (unsigned long long*)nullptr);                                  \
         return true;                                                                                          \
     }
         if (C == 7 && tr.K == 8) SVOXT_WIDE(8)
@@ -654,7 +613,8 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
                 // (ll.terms: the exact one-kernel form's hand-over buffer; terms_state 2 = the forward filled it)
                 done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, ll, laux,
                                          fwd_out, have_coef ? reinterpret_cast<float4*>(lists->coef) : nullptr, false, st,
-                                         (lists->terms_state == 2 || lists->terms_state == 3) ? lists->terms_state : 1);
+                                         (lists->terms_state == 2 || lists->terms_state == 3) ? lists->terms_state : 1,
+                                         (lists->flags & SVOXT_LISTS_NATIVE_MATH) != 0);
             if (!done) done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, gs, l1, laux, fwd_out, st)
                       : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, gs, l1, laux, fwd_out, st);
             if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no specialised kernel for this payload", fn);
@@ -751,9 +711,12 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
     bool done = false;
     // two kernels (march, shade per tile) where there is room for the lists: the caller's,
     // or scratch (then the stop rule applies while marching -- those lists serve no backward)
-    const bool fast = (flags & SVOXT_FWD_FAST_SIGMOID) != 0;
+    // what the lists (the caller's, or the scratch) say about the kernels that fill them, and the scratch
+    // forwards' own `flags` argument (SVOXT_FWD_FAST_SIGMOID = SVOXT_LISTS_NATIVE_MATH)
+    const int32_t lflags = flags | (lists != nullptr ? lists->flags : 0) | (scratch != nullptr ? scratch->flags : 0);
+    const bool fast = (lflags & SVOXT_LISTS_NATIVE_MATH) != 0;
     const bool want_terms = lists != nullptr && lists->terms != nullptr && C == 3;
-    if (fwd_split_enabled(tree, opt, want_terms) && full_comp(opt) && fwd_split_payload(tree, opt, C) &&
+    if (fwd_split_enabled(tree, opt, want_terms, lflags) && full_comp(opt) && fwd_split_payload(tree, opt, C) &&
         (!uses_xform(tree, opt) || xform_special(tree, opt))) {
         const bool xf = uses_xform(tree, opt);
         // one bit per feature row, built for this feature table and this sigma_thresh (else ignored)
@@ -761,8 +724,8 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
                                     ? reinterpret_cast<const uint32_t*>(tree->sigma_mask) : nullptr;
         if (lists != nullptr) {
             uint4* aux = reinterpret_cast<uint4*>(lists->aux);
-            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, xf, false, st, smask)
-                      : launch_fwd_split<false, false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, xf, false, st, smask);
+            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, xf, fast, st, smask)
+                      : launch_fwd_split<false, false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, xf, fast, st, smask);
         } else if (scratch != nullptr && smask != nullptr && opt->stop_thresh == 0.f) {
             // With stop_thresh = 0 the stop rule ends a ray only once its transmittance is exactly 0; every
             // later sample then has weight 0 * (1 - att) = 0 and the final rescale is by 1 / (1 - 0): the
@@ -859,13 +822,13 @@ int svoxt_sigma_mask_build(const svoxt_tree* tree, float sigma_thresh, void* mas
     return check_launch(fn);
 }
 
-int svoxt_fwd_fills_terms(const svoxt_tree* tree, const svoxt_options* opt) {
+int svoxt_fwd_fills_terms(const svoxt_tree* tree, const svoxt_options* opt, int32_t list_flags) {
     if (tree == nullptr || opt == nullptr || !svoxt_can_record(tree, opt)) return 0;
     if (uses_xform(tree, opt)) return 0;
     const int C = svoxt_out_data_dim(opt, tree->K) - 1;
     if (C != 3) return 0;
     // 3: the two-kernel forward (tile shade kernel, position-major); 2: the one-kernel forward (lane-major lines)
-    return (fwd_split_enabled(tree, opt, true) && full_comp(opt) && fwd_split_payload(tree, opt, C)) ? 3 : 2;
+    return (fwd_split_enabled(tree, opt, true, list_flags) && full_comp(opt) && fwd_split_payload(tree, opt, C)) ? 3 : 2;
 }
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt) {

@@ -290,3 +290,14 @@ def broadcast_tree(tree, src: int = 0, group: Optional[dist.ProcessGroup] = None
     (buffers and the feature table).  Shapes must already agree."""
     for t in (tree.child, tree.data, tree.parent_depth, tree.invradius, tree.offset, tree.features.data):
         dist.broadcast(t, src=src, group=group)
+    # the collective wrote into `features.data` (no version bump) and maybe into child / data: what the
+    # operator layer derived from the old contents (acceleration grid, a cached sigma bitmask) is stale
+    try:
+        from svox_t_amd import csrc as _C
+    except ImportError:          # (the CPU tests of the collective logic run without the HIP library)
+        _C = None
+    if _C is not None:
+        _C.invalidate_caches(tree.child, tree.data, tree.features)
+    else:
+        for t in (tree.child, tree.data, tree.features):
+            torch.autograd.graph.increment_version(t)

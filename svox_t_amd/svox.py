@@ -359,6 +359,9 @@ class N3Tree(nn.Module):
             else torch.empty((0, 0), device=dev, dtype=torch.int32)
         spec.transformation_matrices = transformation_matrices if transformation_matrices is not None \
             else torch.empty((0, 0, 0), device=dev)
+        # (not in the reference) `tree.static_features = True`: the caller's promise that the feature table
+        # is not written behind torch's version counter, so what is derived from its content may be cached
+        spec.static_features = bool(getattr(self, "static_features", False))
         return spec
 
     def __repr__(self):

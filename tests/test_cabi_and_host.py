@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_C.EXPORTS)          # the ctypes table and the header agree
-    assert lib.svoxt_abi_version() == _C.ABI_VERSION == 15
+    assert lib.svoxt_abi_version() == _C.ABI_VERSION == 16
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -39,16 +39,45 @@ def test_struct_layouts_match_header(tmp_path):
                    'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu ", sizeof(svoxt_options), sizeof(svoxt_rays),'
                    ' sizeof(svoxt_tree), sizeof(svoxt_sample_lists), offsetof(svoxt_rays, c2w), offsetof(svoxt_rays, fy),'
                    ' offsetof(svoxt_tree, accel_log2)); printf("%zu %zu\\n", offsetof(svoxt_tree, xform_dim),'
-                   ' sizeof(svoxt_motion)); printf(" %zu %zu\\n", offsetof(svoxt_sample_lists, coef_bytes),'
-                   ' offsetof(svoxt_tree, sigma_mask_thresh)); return 0;}\n')
+                   ' sizeof(svoxt_motion)); printf(" %zu %zu %zu\\n", offsetof(svoxt_sample_lists, coef_bytes),'
+                   ' offsetof(svoxt_tree, sigma_mask_thresh), offsetof(svoxt_sample_lists, flags)); return 0;}\n')
     exe = tmp_path / "probe"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert got == [ctypes.sizeof(_C._COptions), ctypes.sizeof(_C._CRays), ctypes.sizeof(_C._CTree),
                    ctypes.sizeof(_C._CLists), _C._CRays.c2w.offset, _C._CRays.fy.offset, _C._CTree.accel_log2.offset,
                    _C._CTree.xform_dim.offset, ctypes.sizeof(_C._CMotion), _C._CLists.coef_bytes.offset,
-                   _C._CTree.sigma_mask_thresh.offset]
+                   _C._CTree.sigma_mask_thresh.offset, _C._CLists.flags.offset]
     assert got[:3] == [44, 64, 128]
+
+
+def test_no_kernel_keeps_private_arrays_in_scratch_memory():
+    """What the compiler reported for every kernel of the last build (svox_t_amd/build.py writes the
+    -Rpass-analysis=kernel-resource-usage remarks next to the library).  No kernel may have a dynamic
+    stack, and none more than a few spilled registers' worth of scratch: a per-lane array (feature
+    row, basis, accumulators) that lands in scratch memory costs a memory round trip per access
+    (forward 0.33 -> 0.28 ms when 12 bytes left it) -- and scratch is the only place
+    where an out-of-range private index could fault instead of reading another register.  The one
+    unexplained abort in this project's records (r02, gpurun_out/r2q/t5.log) was an EXPERIMENT build
+    that capped shade_tile_kernel at 64 registers: its SH16 instance, the first kernel of that test
+    run with a large spill (152 bytes per lane), is what was running."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_svoxt_build", os.path.join(ROOT, "svox_t_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    if not os.path.exists(b.RESOURCES_PATH):
+        pytest.skip("library built without resource remarks (an older build.py)")
+    res = b.kernel_resources()
+    assert len(res) > 200                         # every instance of every kernel template
+    worst = {}
+    for name, r in res.items():
+        assert r["Dynamic Stack"] == "False", name
+        sc = int(r["ScratchSize [bytes/lane]"])
+        if sc:
+            worst[name] = sc
+    # today: the exact grad_wide_kernel<16 / 32> instances spill 7 registers (24 bytes) at their 80-register budget
+    assert all(v <= 32 for v in worst.values()), worst
+    assert all("grad_wide_kernel" in k for k in worst), worst
 
 
 def test_out_data_dim():

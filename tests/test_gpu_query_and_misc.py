@@ -222,7 +222,7 @@ def test_weight_accumulation_matches_oracle(gpu, name, accel, monkeypatch):
     coarse leaves hold data; with and without early termination; N = 2 and 3."""
     import svox_t_amd.csrc as _C
     from svox_t_amd.renderer import _rays_spec_from_rays
-    monkeypatch.setenv("SVOXT_ACCEL_LOG2", "0" if accel == "plain" else "5")
+    monkeypatch.setattr(_C, "ACCEL_LOG2", 0 if accel == "plain" else 5)
     if name.startswith("random"):
         from tests.test_gpu_random_stress import random_rays, random_tree
         N = int(name[-1])
@@ -350,11 +350,34 @@ def test_config3_backward_relative_error_both_routes(cfg3, gpu, monkeypatch, cap
     assert stats["single-march"][1] <= 0.005
 
 
-def test_config4_depth9_features32_and_depth(gpu):
+class _Cfg4:
+    """BASELINE configs[3] (depth-9, 31 features + sigma, 1024 x 1024) and the oracle's results for it,
+    computed once per test module."""
+
+    def __init__(self):
+        self.case = Case(depth=9, K=32, data_format="RGBA", width=1024, height=1024)
+        self._bwd = None
+
+    def backward(self):
+        if self._bwd is None:
+            c = self.case
+            gout = synth.grad_output(c.Q, 32)
+            want, absum, tight = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), gout.numpy(),
+                                                           want_abs="both")
+            self._bwd = (gout, want, absum, tight)
+        return self._bwd
+
+
+@pytest.fixture(scope="module")
+def cfg4():
+    return _Cfg4()
+
+
+def test_config4_depth9_features32_and_depth(cfg4, gpu, monkeypatch):
     """BASELINE configs[3]: depth-9, data_dim 32 (31 features + sigma), 1024x1024:
     volume_render [Q,32] and render_depth [Q,1]; checked against the oracle on a
     deterministic subsample of the rays (the full batch is rendered)."""
-    c = Case(depth=9, K=32, data_format="RGBA", width=1024, height=1024)
+    c = cfg4.case
     assert (c.st.n_internal, c.st.n_features) == (792753, 4738568)
     tree = c.tree(gpu)
     r = svox.VolumeRenderer(tree)
@@ -370,20 +393,17 @@ def test_config4_depth9_features32_and_depth(gpu):
     np.testing.assert_array_equal(out[sel].cpu().numpy(), want)
     np.testing.assert_array_equal(depth[sel].cpu().numpy(), O.render_depth(ot, o, d, v, c.oracle_opts()))
     # the same through the one-kernel forward (the default for this payload is march + channel-lane shade)
-    import os
-    os.environ["SVOXT_FWD_SPLIT"] = "0"
-    try:
-        with torch.no_grad():
-            assert torch.equal(r(tree.features, rays), out)
-    finally:
-        del os.environ["SVOXT_FWD_SPLIT"]
-    # opt-in tolerance mode (SVOXT_FAST_SIGMOID: float quotient): 1e-5 relative, at full size
-    _C.FAST_SIGMOID = True
-    try:
-        with torch.no_grad():
-            fast = r(tree.features, rays)
-    finally:
-        _C.FAST_SIGMOID = False
+    monkeypatch.setattr(_C, "FWD_SPLIT", "0")
+    with torch.no_grad():
+        assert torch.equal(r(tree.features, rays), out)
+    assert _C.LAST_ROUTE["forward"].startswith("render_fwd_kernel")
+    monkeypatch.setattr(_C, "FWD_SPLIT", "")
+    # opt-in tolerance mode (NATIVE_MATH: bit-exact stepping, v_exp_f32 / v_rcp_f32 shading): 1e-5 relative, at full size
+    monkeypatch.setattr(_C, "NATIVE_MATH", True)
+    with torch.no_grad():
+        fast = r(tree.features, rays)
+    assert "native" in _C.LAST_ROUTE["forward"]
+    monkeypatch.setattr(_C, "NATIVE_MATH", False)
     assert not torch.equal(fast, out)
     assert_outputs_close(fast[sel].cpu().numpy(), want, rtol=1e-5, atol=1e-6)
     rel = ((fast - out).abs() / out.abs().clamp_min(1e-3)).max().item()
@@ -394,17 +414,15 @@ def test_config4_depth9_features32_and_depth(gpu):
     assert dn.max() < 1.6 + 0.9
 
 
-def test_config4_backward_full_size(gpu, monkeypatch):
+def test_config4_backward_full_size(cfg4, gpu, monkeypatch):
     """BASELINE configs[3] forward + backward at full size (1 048 576 rays, 13.4 M samples of 31
     channels): the per-tile backward for wide rows (grad_wide_kernel) and the per-ray one-sigmoid-pass
     form against the oracle's two-pass backward, every entry within 1e-5 of the TIGHT scale (accum
     priced by the reference's own sequential addends)."""
-    c = Case(depth=9, K=32, data_format="RGBA", width=1024, height=1024)
+    c = cfg4.case
     tree = c.tree(gpu)
     r = svox.VolumeRenderer(tree)
-    gout = synth.grad_output(c.Q, 32)
-    want, _, tight = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), gout.numpy(),
-                                              want_abs="both")
+    gout, want, _, tight = cfg4.backward()
     for gather, expect in ((1, "grad_wide_kernel"), (0, "render_bwd_kernel<ONEPASS>")):
         monkeypatch.setattr(_C, "BWD_GATHER", gather)
         tree.features.grad = None
@@ -413,6 +431,56 @@ def test_config4_backward_full_size(gpu, monkeypatch):
         assert _C.LAST_ROUTE["backward"].startswith(expect), _C.LAST_ROUTE
         assert_grads_close(tree.features.grad.cpu().numpy(), want, tight, what=expect)
         tree.features.grad = None
+    # the device-side count of what the per-tile kernel sends to memory (bench.py prices its roofline from
+    # it): one request per 64 bytes of a (tile, window, row) group's gradient row -- two per row of 32 floats
+    monkeypatch.setattr(_C, "BWD_GATHER", 1)
+    with _C.bwd_counters(gpu) as ctr:
+        out = r(tree.features, c.rays_gpu(gpu), image_shape=(1024, 1024))
+        out.backward(gout.to(gpu))
+        torch.cuda.synchronize()
+    requests, groups = ctr.read()
+    assert requests == 2 * groups and 1_000_000 < groups < 13_400_000, (requests, groups)
+    assert_grads_close(tree.features.grad.cpu().numpy(), want, tight, what="counting instance")
+
+
+def test_config4_native_math_tolerance_mode_full_size(cfg4, gpu, monkeypatch, capsys):
+    """The opt-in tolerance mode for wide rows (NATIVE_MATH / SVOXT_NATIVE_MATH=1) at
+    BASELINE configs[3]'s full size, forward AND backward: the stepping is the exact one -- same leaves,
+    same lists -- the shading takes its exponentials from v_exp_f32 and its quotients from v_rcp_f32
+    where the reference has expf and a double-precision divide (rt_kernel.cu:280, 300-305, 397, 408-425,
+    461-476).  Held to the north star's figure: outputs |err| <= 1e-5 |want| + 1e-6, every gradient entry
+    within 1e-5 of the tight scale; the fraction of entries off by more than 1e-5 of their OWN value is
+    reported for both modes (the exact mode's is float-atomic reordering alone)."""
+    c = cfg4.case
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    gout, want, absum, tight = cfg4.backward()
+    want_out = O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts())
+    touched = absum > 0
+    stats = {}
+    for mode, native in (("exact", False), ("native", True)):
+        monkeypatch.setattr(_C, "NATIVE_MATH", native)
+        tree.features.grad = None
+        out = r(tree.features, c.rays_gpu(gpu), image_shape=(1024, 1024))
+        out.backward(gout.to(gpu))
+        assert ("native" in _C.LAST_ROUTE["forward"]) == native and ("native" in _C.LAST_ROUTE["backward"]) == native
+        assert _C.LAST_ROUTE["backward"].startswith("grad_wide_kernel")
+        got_out = out.detach().cpu().numpy()
+        got = tree.features.grad.double().cpu().numpy()
+        if native:
+            assert_outputs_close(got_out, want_out, rtol=1e-5, atol=1e-6, what="native-math forward")
+        else:
+            np.testing.assert_array_equal(got_out, want_out)
+        assert_grads_close(got, want, tight, what=f"{mode} backward")
+        err = np.abs(got - want)
+        oerr = np.abs(got_out.astype(np.float64) - want_out)
+        stats[mode] = (float((oerr > 1e-5 * np.abs(want_out)).mean()), float((err > 1e-5 * np.abs(want))[touched].mean()),
+                       float((err / (tight + 1e-300))[touched].max()))
+    with capsys.disabled():
+        for k, (fo, fg, worst) in stats.items():
+            print(f"\n[cfg4, {k}] outputs with |err| > 1e-5 |want|: {fo:.4%}; gradient entries with |err| > 1e-5 |want|: "
+                  f"{fg:.4%}; worst |err| / tight scale {worst:.2e}")
+    assert stats["native"][2] <= 1e-5 and stats["exact"][2] <= 1e-5
 
 
 @pytest.mark.parametrize("width,height,ndc", [(64, 48, False), (50, 37, False), (64, 48, True), (33, 40, True)])

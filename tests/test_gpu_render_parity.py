@@ -55,9 +55,12 @@ def test_volume_render_backward(case, gpu):
     g = synth.grad_output(case.Q, out.shape[1])
     out.backward(g.to(gpu))
     got = feats.grad.cpu().numpy()
-    want, abs_sum = O.volume_render_backward(case.oracle_tree(), *case.rays_np(), case.oracle_opts(),
-                                             g.numpy(), want_abs=True)
-    assert_grads_close(got, want, abs_sum)
+    # the default backward is exact (every contribution the reference's formula, accum added up in the
+    # reference's order): held to the TIGHT scale -- accum priced by the reference's own sequential addends
+    want, abs_sum, tight = O.volume_render_backward(case.oracle_tree(), *case.rays_np(), case.oracle_opts(),
+                                                    g.numpy(), want_abs="both")
+    assert_grads_close(got, want, tight)
+    assert np.all(got[abs_sum == 0] == 0)
 
 
 def test_depth_and_opacity(case, gpu):
@@ -82,9 +85,9 @@ def test_opacity_backward(case, gpu):
     g = synth.grad_output(case.Q, 1, seed=3)
     out.backward(g.to(gpu))
     got = feats.grad.cpu().numpy()
-    want, abs_sum = O.volume_render_backward(case.oracle_tree(), *case.rays_np(), case.oracle_opts(),
-                                             g.numpy(), want_abs=True)
-    assert_grads_close(got, want, abs_sum)
+    want, _, tight = O.volume_render_backward(case.oracle_tree(), *case.rays_np(), case.oracle_opts(),
+                                              g.numpy(), want_abs="both")
+    assert_grads_close(got, want, tight)
     assert np.all(got[:, :-1] == 0)          # only the sigma column receives gradient
 
 
@@ -243,7 +246,7 @@ def test_two_kernel_backward_extreme_coherence(gpu, kind):
 
 @pytest.mark.parametrize("name", ["d5_rgba4", "d5_sh9", "d5_sh4_world", "d4_sh16", "d5_rgba8", "d5_rgba16", "d6_rgba32"])
 def test_two_kernel_forward_equals_one_kernel_forward(name, gpu, monkeypatch):
-    """SVOXT_FWD_SPLIT=1 (march_rec_kernel + shade_tile_kernel + tail launch, through
+    """FWD_SPLIT = "1" (SVOXT_FWD_SPLIT; march_rec_kernel + shade_tile_kernel + tail launch, through
     svoxt_volume_render_fwd_ws and svoxt_volume_render_fwd_record) against the one-kernel forward:
     outputs bit-identical with thresholds 0 and 1e-2, with lists long enough and too short (the tail
     launch finishes the rays), as an image and as a plain batch; lists recorded either way give the
@@ -259,21 +262,21 @@ def test_two_kernel_forward_equals_one_kernel_forward(name, gpu, monkeypatch):
     for rs in (_rays_spec_from_rays(rays), _rays_spec_from_rays(rays, (c.Q // W, W))):
         for fast in (False, True):
             opt = r._get_options(fast=fast)
-            monkeypatch.setenv("SVOXT_FWD_SPLIT", "0")
+            monkeypatch.setattr(_C, "FWD_SPLIT", "0")
             rs.need_grad = False                 # forwards nobody differentiates
             want = _C.volume_render(spec, rs, opt)
-            monkeypatch.setenv("SVOXT_FWD_SPLIT", "1")
+            monkeypatch.setattr(_C, "FWD_SPLIT", "1")
             for S in (96, 8):
                 monkeypatch.setattr(_C, "FWD_LIST_SAMPLES", S)
                 assert torch.equal(_C.volume_render(spec, rs, opt), want), (name, fast, S)
         opt = r._get_options()
-        monkeypatch.setenv("SVOXT_FWD_SPLIT", "0")
+        monkeypatch.setattr(_C, "FWD_SPLIT", "0")
         rs.need_grad = False
         want = _C.volume_render(spec, rs, opt)
         g = torch.randn_like(want)
         grads = {}
         for split in ("0", "1"):
-            monkeypatch.setenv("SVOXT_FWD_SPLIT", split)
+            monkeypatch.setattr(_C, "FWD_SPLIT", split)
             for S in (96, 8):
                 monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", S)
                 out, lists = _C.volume_render(spec, rs, opt, record=True)
@@ -404,8 +407,8 @@ def test_sigma_bitmask_changes_nothing(name, gpu, monkeypatch):
     import svox_t_amd.csrc as _C
     from svox_t_amd import synth
     from svox_t_amd.renderer import _rays_spec_from_rays
-    monkeypatch.setattr(_C, "SIGMA_MASK", "1")
-    monkeypatch.setenv("SVOXT_FWD_SPLIT", "1")               # the march + shade forward for every payload that has one
+    monkeypatch.setattr(_C, "SIGMA_MASK", True)
+    monkeypatch.setattr(_C, "FWD_SPLIT", "1")               # the march + shade forward for every payload that has one
     c = Case(**CASES[name])
     tree = c.tree(gpu)
     r = svox.VolumeRenderer(tree)
@@ -414,11 +417,17 @@ def test_sigma_bitmask_changes_nothing(name, gpu, monkeypatch):
     ot = c.oracle_tree()
     assert (ot.features[:, -1] <= 0).any() and (ot.features[:, -1] > 0).any()      # rows on both sides of the threshold
     want = O.volume_render(ot, *c.rays_np(), c.oracle_opts())
+    _C._SIGMA_CACHE.clear()
     with torch.no_grad():
         got = r(tree.features, rays, image_shape=shape)
     assert "march_rec_kernel" in _C.LAST_ROUTE["forward"]
     np.testing.assert_array_equal(got.cpu().numpy(), want)
-    assert len(_C._SIGMA_CACHE) >= 1
+    assert len(_C._SIGMA_CACHE) == 0             # nothing derived from the features' content is kept by default ...
+    tree.static_features = True                  # ... only for a table its owner declares static
+    with torch.no_grad():
+        got = r(tree.features, rays, image_shape=shape)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    assert len(_C._SIGMA_CACHE) == 1
     # recording forward + backward (the mask is rebuilt, not taken from the cache)
     g = synth.grad_output(c.Q, want.shape[1])
     out = r(tree.features, rays, image_shape=shape)
@@ -449,6 +458,94 @@ def test_sigma_bitmask_changes_nothing(name, gpu, monkeypatch):
         assert tree.features._version == v0
         got = r(tree.features, rays, image_shape=shape)
     np.testing.assert_array_equal(got.cpu().numpy(), want)
+    # a write through `.data` -- the reference's own idiom, and what an optimizer's `p.data.add_()` does --
+    # bumps no version counter: a tree that is NOT declared static gets a fresh mask every forward
+    tree.static_features = False
+    with torch.no_grad():
+        v0 = tree.features._version
+        tree.features.data[:, -1] *= -1.0
+        assert tree.features._version == v0
+        got = r(tree.features, rays, image_shape=shape)
+    np.testing.assert_array_equal(got.cpu().numpy(), want2)
+    # ... and for a static one, invalidate_caches() is the way to say so
+    tree.static_features = True
+    with torch.no_grad():
+        got = r(tree.features, rays, image_shape=shape)              # caches the mask of the flipped table
+        tree.features.data[:, -1] *= -1.0                            # back to the original values
+        _C.invalidate_caches(tree.features)
+        got = r(tree.features, rays, image_shape=shape)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_plan_is_not_replayed_for_other_rays_trees_or_operators(gpu):
+    """The forward of a plain call leaves its sample lists on the rays spec (svox_t_amd.csrc._Plan).  The
+    reference's backward re-marches whatever the spec objects hold when it runs (renderer.py:64-72), so a
+    plan must be dropped -- and the backward march -- when anything the lists were recorded for has changed:
+    the rays (in-place edit between forward and backward), the operator, the topology."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd import synth
+    from svox_t_amd.renderer import _rays_spec_from_rays
+    c = Case(depth=5, K=28, data_format="SH9", width=64, height=64)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    opt = r._get_options()
+    g = synth.grad_output(c.Q, 4)
+    rays = c.rays_gpu(gpu)
+    rs = _rays_spec_from_rays(rays, (64, 64))
+    rs.need_grad = True
+    spec = tree._spec(tree.features)
+    _C.volume_render(spec, rs, opt)
+    assert rs._svoxt_plan is not None and rs._svoxt_plan.lists is not None
+    # the caller moves the camera in place between forward and backward
+    shift = torch.tensor([0.02, -0.01, 0.015], device=gpu)
+    rays.origins.add_(shift)
+    got = _C.volume_render_backward(spec, rs, opt, g.to(gpu))
+    assert _C.LAST_ROUTE["backward"].startswith("render_bwd_kernel (marches")
+    o2 = c.origins.numpy() + shift.cpu().numpy()
+    want, _, tight = O.volume_render_backward(c.oracle_tree(), o2, c.dirs.numpy(), c.vdirs.numpy(), c.oracle_opts(),
+                                              g.numpy(), want_abs="both")
+    assert_grads_close(got.cpu().numpy(), want, tight, what="re-marched with the edited rays")
+    # a plan left by volume_render is not taken by opacity_render_backward (and is consumed by the attempt)
+    _C.volume_render(spec, rs, opt)
+    g1 = synth.grad_output(c.Q, 1, seed=3)
+    got = _C.opacity_render_backward(spec, rs, opt, g1.to(gpu))
+    assert rs._svoxt_plan is None
+    want1, ab1 = O.volume_render_backward(c.oracle_tree(), o2, c.dirs.numpy(), c.vdirs.numpy(), c.oracle_opts(),
+                                          g1.numpy(), want_abs=True)
+    assert_grads_close(got.cpu().numpy(), want1, ab1, what="opacity backward after a volume forward")
+    # topology edited between forward and backward (refine bumps child / data): the lists name stale rows
+    _C.volume_render(spec, rs, opt)
+    p = rs._svoxt_plan
+    torch.autograd.graph.increment_version(tree.child)
+    assert _C._take_plan("volume", spec, rs, opt) is None
+    # unchanged everything: the plan is taken
+    _C.volume_render(spec, rs, opt)
+    assert _C._take_plan("volume", spec, rs, opt) is not None
+
+
+def test_a_forward_without_a_backward_frees_its_lists_by_refcount(gpu):
+    """the plan must not close a reference cycle through the autograd node (ctx -> rays spec ->
+    plan -> out -> grad_fn -> ctx), or a forward that never gets a backward keeps its sample lists, its
+    hand-over buffer and its output on the GPU until the cyclic collector happens to run."""
+    import gc
+    import weakref
+    import svox_t_amd.csrc as _C
+    from svox_t_amd.renderer import _VolumeRenderFunction, _rays_spec_from_rays
+    c = Case(depth=5, K=28, data_format="SH9", width=64, height=64)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    gc.collect()
+    gc.disable()
+    try:
+        rs = _rays_spec_from_rays(c.rays_gpu(gpu), (64, 64))
+        rs.need_grad = True
+        out = _VolumeRenderFunction.apply(tree.features, tree._spec(tree.features), rs, r._get_options())
+        assert out.grad_fn is not None and rs._svoxt_plan is not None
+        refs = [weakref.ref(rs._svoxt_plan.lists.rec), weakref.ref(rs._svoxt_plan.lists.terms), weakref.ref(rs._svoxt_plan)]
+        del out, rs
+        assert all(w() is None for w in refs), [w() is None for w in refs]
+    finally:
+        gc.enable()
 
 
 @pytest.mark.parametrize("name", ["d5_sh9", "d5_rgba8", "d5_rgba4"])
