@@ -735,7 +735,7 @@ def _permute_rows(src: torch.Tensor, perm32: torch.Tensor, scatter: bool) -> tor
 
 class _Plan:
     """What a forward leaves on its rays / camera spec for the backward of the same call."""
-    __slots__ = ("kind", "features", "fkey", "tkey", "rkey", "optkey", "lists", "out", "over", "perm", "rays")
+    __slots__ = ("kind", "features", "fkey", "tkey", "rkey", "optkey", "lists", "out", "over", "perm", "rays", "__weakref__")
 
 
 def _opt_key(opt):
@@ -821,7 +821,8 @@ def _planned_forward(kind, render, tree, rays, opt):
         # spec, the spec this plan: a reference to `out` itself would close a cycle that only the cyclic
         # collector breaks, and a forward nobody runs a backward for would keep its lists (tens to hundreds
         # of MB) until then.  A detached alias has no grad_fn and shares storage and version counter.
-        p.lists, p.out, p.over, p.perm, p.rays = lists, out.detach(), out._version, perm, rr
+        # (rays: only a spec made here -- the caller's own would be a cycle spec -> plan -> spec)
+        p.lists, p.out, p.over, p.perm, p.rays = lists, out.detach(), out._version, perm, (None if rr is rays else rr)
         rays._svoxt_plan = p
     else:
         out = render(tree, rr, opt, False)
@@ -943,7 +944,7 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
             fo = p.out if (p.lists is not None and p.out._version == p.over) else None
             if fo is not None and fo.dim() == 3:
                 fo = fo.view(-1, fo.shape[2])
-            return _volume_render_backward(tree, p.rays, opt, g, p.lists, fo)
+            return _volume_render_backward(tree, p.rays if p.rays is not None else rays, opt, g, p.lists, fo)
     return _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output)
 
 
@@ -1096,7 +1097,7 @@ def opacity_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
         if p is not None:
             _check_input(grad_output, "grad_output")
             g = grad_output if p.perm is None else _permute_rows(grad_output, p.perm, scatter=False)
-            return _opacity_render_backward(tree, p.rays, opt, g, p.lists)
+            return _opacity_render_backward(tree, p.rays if p.rays is not None else rays, opt, g, p.lists)
     return _opacity_render_backward(tree, rays, opt, grad_output, lists)
 
 

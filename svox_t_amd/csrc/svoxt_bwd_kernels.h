@@ -1178,7 +1178,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 // K floats that starts on a K * 4-byte boundary: two for K = 32, one for K = 16 / 8), counters[1] +=
 // (tile, window, feature row) groups.
 template <int K, bool FAST = false, bool COUNT = false>
-__global__ void __launch_bounds__(512, 6)
+__global__ void __launch_bounds__(512, FAST ? 8 : 6)
 grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                  RecLists L, const uint4* __restrict__ aux, float* __restrict__ grad, int gstride,
                  unsigned long long* __restrict__ counters = nullptr) {
@@ -1189,8 +1189,9 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
     static_assert(RPP == 2, "sizes");
     __shared__ int32_t keys[T];
     __shared__ int32_t cnt[T];
-    __shared__ uint16_t order[R];                // sweep 1: the window's records, compacted; sweep 2: sorted by row
-    __shared__ uint16_t slots[T];                // sweep 2: the occupied table entries
+    __shared__ uint16_t order[R];                // sweep 1: the window's records, compacted
+    static_assert(T <= R, "slots shares order's storage");
+    uint16_t* const slots = order;               // sweep 2: the occupied table entries (order is sweep 1's alone)
     __shared__ uint32_t r_sl[R];                 // sweep 1: feature row; sweep 2: table entry << 6 | lane, ~0: no record
     __shared__ float r_w[R], r_sg[R], r_t1[R], r_dt[R];   // (sweep 2: r_t1 / r_dt hold weight / sigma entry in sorted order)
     __shared__ uint8_t s_ray[R];                 // sweep 2: the ray of the sorted record
@@ -1267,6 +1268,27 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
             const int slot = on ? (int)order[p] : 0;
             const int ray = slot & 63;
             float row[8];
+            if constexpr (FAST) {
+                // tolerance mode: no order of the additions to reproduce -- every lane sums its 8 columns,
+                // two xor-shuffles add the G partial sums (where the exact form hops G - 1 times from lane to
+                // lane with the float and the double sum), one float serves both passes' total_color
+                float part = 0.f;
+                if (on) {
+                    load_row<8>(tr.features + (int64_t)(int32_t)r_sl[slot] * K + 8 * gq, row);
+                    const float* __restrict__ gr = gl + ray * KG + 8 * gq;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (8 * gq + j < C) part = __builtin_fmaf(nsigmoidf(row[j]), gr[j], part);
+                    }
+                }
+#pragma unroll
+                for (int off = 1; off < G; off <<= 1) part += __shfl_xor(part, off, 64);
+                if (on && gq == G - 1) {
+                    r_w[slot] = nexpf(-r_dt[slot] * row[7] * dsl[ray]);
+                    r_t1[slot] = part;
+                    r_sg[slot] = part;
+                }
+            } else {
             float a1[8];
             double a2[8];
             if (on) {
@@ -1275,15 +1297,10 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (8 * gq + j < C) {                      // (the last lane's eighth column is sigma)
+                        const double sd = sigmoid_d<true>(row[j]);
                         const float gj = gr[j];
-                        if constexpr (FAST) {
-                            a1[j] = nsigmoidf(row[j]) * gj;
-                            a2[j] = (double)a1[j];
-                        } else {
-                            const double sd = sigmoid_d<true>(row[j]);
-                            a1[j] = (float)sd * gj;
-                            a2[j] = sd * (double)gj;
-                        }
+                        a1[j] = (float)sd * gj;
+                        a2[j] = sd * (double)gj;
                     } else {
                         a1[j] = 0.f; a2[j] = 0.0;
                     }
@@ -1300,16 +1317,16 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                     for (int j = 0; j < 8; ++j) {
                         if (rr * 8 + j < C) {
                             t1 += a1[j];
-                            if constexpr (!FAST) t2 = (float)((double)t2 + a2[j]);
+                            t2 = (float)((double)t2 + a2[j]);
                         }
                     }
                 }
             }
             if (on && gq == G - 1) {
-                const float arg = -r_dt[slot] * row[7] * dsl[ray];
-                r_w[slot] = FAST ? nexpf(arg) : pexpf<true>(arg);
+                r_w[slot] = pexpf<true>(-r_dt[slot] * row[7] * dsl[ray]);
                 r_t1[slot] = t1;
-                r_sg[slot] = FAST ? t1 : t2;          // (FAST: one float sum serves both passes)
+                r_sg[slot] = t2;
+            }
             }
         }
         __syncthreads();

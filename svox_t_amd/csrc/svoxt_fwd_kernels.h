@@ -555,45 +555,60 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
     // all independent -- and only then run the chain along the ray.  (One record, one row, one step
     // at a time the kernel was a chain of two dependent loads per sample: 1.12 ms at 1024 x 1024,
     // depth 9, K = 32, and no faster with the float quotient.)
+    // (r03) Branch-free: a list position past the ray's last record is made a sample that does nothing --
+    // its row index is clamped to row 0 (a load nobody waits for the value of), its exponent to 0, so that
+    // e = att = 1, weight = T (1 - 1) = 0, acc + 0 = acc and T * 1 = T, bit for bit (acc never holds -0: it
+    // starts at +0 and only receives terms >= 0) -- instead of a compare, an exec-mask save / restore and a
+    // branch around every load and every step of the chain (r02 ISA: ~15 of the FAST loop's 31 vector
+    // instructions per record).  The row address is ONE v_mad_u64_u32 (row index x row bytes + the lane's
+    // column address).
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const bool is_sig = c == K - 1;
+    const char* __restrict__ col_base = reinterpret_cast<const char*>(tr.features) + 4 * c;
+    constexpr float kNegLog2e = -1.44269504088896341f;
+    // FAST: exponent of 2 = x * sc with sc = fma(dt, mult, base): sigma lane dt * (-ds log2 e), channel lanes -log2 e
+    const float sc_mult = is_sig ? ds * kNegLog2e : 0.f, sc_base = is_sig ? 0.f : kNegLog2e;
     for (int kb = 0; kb < maxn; kb += kRecBlock) {
         uint32_t idx[kRecBlock];
         float dt[kRecBlock], ex[kRecBlock];
-        const int n_here = min(nrec - kb, kRecBlock);            // records of this ray in the block (<= 0: none)
+        const int n_here = nrec - kb;                            // records of this ray from here on (<= 0: none)
         const int64_t blk = rec_block_u(L, tabreg, t >> 6, kb >> 3);
-        if (n_here > 0) {
-            const v4u* line = reinterpret_cast<const v4u*>(L.rec + rec_index_in(blk, t, kb));   // the ray's line of this block
+        // The ray's line of this block, read whether or not the ray still has records here: kb < maxn, so
+        // some ray of this wavefront -- of the same tile -- started the block, i.e. the block exists and
+        // every lane's line of it is memory of the lists (stale bits where nothing was recorded).
+        const v4u* line = reinterpret_cast<const v4u*>(L.rec + rec_index_in(blk, t, kb));
 #pragma unroll
-            for (int j = 0; j < kRecBlock / 2; ++j) {
-                const v4u w = __builtin_nontemporal_load(line + j);
-                idx[2 * j] = w.x; dt[2 * j] = __uint_as_float(w.y);
-                idx[2 * j + 1] = w.z; dt[2 * j + 1] = __uint_as_float(w.w);
-            }
+        for (int j = 0; j < kRecBlock / 2; ++j) {
+            const v4u w = __builtin_nontemporal_load(line + j);
+            idx[2 * j] = w.x; dt[2 * j] = __uint_as_float(w.y);
+            idx[2 * j + 1] = w.z; dt[2 * j + 1] = __uint_as_float(w.w);
         }
         float x[kRecBlock];
 #pragma unroll
         for (int j = 0; j < kRecBlock; ++j) {
-            x[j] = 0.f;
-            if (j < n_here) x[j] = tr.features[(int64_t)(int32_t)idx[j] * K + c];
+            const uint32_t row = j < n_here ? idx[j] : 0u;       // (slots past the count hold stale bits)
+            x[j] = *reinterpret_cast<const float*>(col_base + (size_t)row * (size_t)(K * 4));
         }
 #pragma unroll
         for (int j = 0; j < kRecBlock; ++j) {
-            ex[j] = 1.f;
-            if (j < n_here) {
-                const float arg = c == K - 1 ? -dt[j] * ds * x[j] : -x[j];
-                ex[j] = FAST ? nexpf(arg) : pexpf(arg);
+            if constexpr (FAST) {
+                const float e2 = x[j] * __builtin_fmaf(dt[j], sc_mult, sc_base);
+                ex[j] = __builtin_amdgcn_exp2f(j < n_here ? e2 : 0.f);
+            } else {
+                const float arg = is_sig ? -dt[j] * ds * x[j] : -x[j];
+                ex[j] = pexpf(j < n_here ? arg : 0.f);
             }
         }
 #pragma unroll
         for (int j = 0; j < kRecBlock; ++j) {
             const float att = __shfl(ex[j], sig_lane, 64);       // every lane takes part
-            if (j < n_here && !stopped) {
+            if (!STOP || !stopped) {
                 const float weight = light * (1.f - att);
                 if constexpr (FAST) acc = __builtin_fmaf(weight, __builtin_amdgcn_rcpf(1.f + ex[j]), acc);
                 else acc = (float)((double)acc + (double)weight / (1.0 + (double)ex[j]));
                 light *= att;
                 if constexpr (STOP) {
-                    if (light <= opt.stop_thresh) stopped = true;
+                    if (j < n_here && light <= opt.stop_thresh) stopped = true;
                 }
             }
         }

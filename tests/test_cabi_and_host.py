@@ -75,8 +75,10 @@ def test_no_kernel_keeps_private_arrays_in_scratch_memory():
         sc = int(r["ScratchSize [bytes/lane]"])
         if sc:
             worst[name] = sc
-    # today: the exact grad_wide_kernel<16 / 32> instances spill 7 registers (24 bytes) at their 80-register budget
-    assert all(v <= 32 for v in worst.values()), worst
+    # today: grad_wide_kernel alone -- 7 registers (24 bytes) of the exact instances at their 80-register budget,
+    # 7-9 loop-invariant ones (shuffle lane indices, a pointer: written once in front of sweep 2) of the
+    # native-math instances at the 64 registers that let four workgroups share a CU
+    assert all(v <= 48 for v in worst.values()), worst
     assert all("grad_wide_kernel" in k for k in worst), worst
 
 

@@ -349,7 +349,7 @@ def test_plain_calls_hand_the_forwards_lists_to_the_backward(name, gpu, monkeypa
     out = _ReferenceShapedFunction.apply(f, _C, spec, rs, opt)
     with torch.no_grad():
         f.mul_(1.0)
-    assert _C._take_plan(spec, rs, opt) is None
+    assert _C._take_plan("volume", spec, rs, opt) is None
     # a forward nobody differentiates leaves nothing
     rs2 = _rays_spec_from_rays(rays)
     with torch.no_grad():

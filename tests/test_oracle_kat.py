@@ -203,6 +203,40 @@ def test_choice_of_expf_moves_results_only_at_ulp_level():
     np.testing.assert_allclose(out_a, out_b, rtol=0, atol=2e-6)
 
 
+def test_two_one_ulp_exponentials_are_more_than_1e5_of_the_tight_scale_apart():
+    """What "gradients within 1e-5" can mean between two implementations that do NOT share their expf
+    bits (this repo's tolerance modes against the oracle; equally the oracle against the reference's CUDA
+    expf, which is specified to 2 ulp).  The formula weight = T * (1.f - expf(-y)) (rt_kernel.cu:280-281,
+    397-398) divides att's last-place error by 1 - att ~ y, and a thin sample has y = delta * sigma *
+    delta_scale ~ 1e-3 * sigma: one ulp of att (6e-8) is 6e-5 of such a weight.  Shown here with the oracle
+    alone: its own backward with glibc's expf instead of the fixed-sequence one (both <= 1 ulp, equal for
+    most arguments) already leaves the 1e-5 x tight-scale band for some entries, and ~1 % of the entries
+    move by more than 1e-5 of their own value -- while the OUTPUTS stay within 1e-5 relative + 1e-6.
+    The native-math mode of the HIP path (v_exp_f32: 1 ulp, differing from the oracle's bits for most
+    arguments) is therefore held to: outputs rtol 1e-5 + atol 1e-6; gradients all within 1e-4 of the tight
+    scale -- the a-priori bound ulp(1) / (step_size * min sigma * delta_scale) = 6e-8 / 1e-3 -- and >= 99 %
+    within 1e-5 of it (tests/test_gpu_query_and_misc.py)."""
+    from svox_t_amd import synth
+    c = Case(depth=6, K=28, data_format="SH9", width=160, height=160)
+    ot, opt = c.oracle_tree(), c.oracle_opts()
+    g = synth.grad_output(c.Q, 4).numpy()
+    out0 = O.volume_render(ot, *c.rays_np(), opt)
+    w0, ab, tight = O.volume_render_backward(ot, *c.rays_np(), opt, g, want_abs="both")
+    try:
+        O.use_libm_exp(True)
+        out1 = O.volume_render(ot, *c.rays_np(), opt)
+        w1 = O.volume_render_backward(ot, *c.rays_np(), opt, g)
+    finally:
+        O.use_libm_exp(False)
+    touched = ab > 0
+    err = np.abs(w1 - w0)
+    ratio = (err / (tight + 1e-300))[touched]
+    assert ratio.max() > 1e-5                                 # the 1e-5 x tight band does not hold across exponentials ...
+    assert ratio.max() < 1e-4 and (ratio > 1e-5).mean() < 1e-3      # ... 1e-4 does, and nearly every entry is inside 1e-5
+    assert (err > 1e-5 * np.abs(w0))[touched].mean() > 1e-3         # elementwise "1e-5 of its own value": ~1 % miss
+    np.testing.assert_allclose(out1, out0, rtol=1e-5, atol=1e-6)    # the outputs hold the north star's figure
+
+
 def test_counters_and_algorithmic_bytes():
     c = Case(depth=5, K=4, data_format="RGBA", width=64, height=64)
     _, cnt = O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), count=True)
