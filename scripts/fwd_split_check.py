@@ -54,7 +54,7 @@ def thread_of_ray(rs, Q):
 def both(name, rs, opt, record):
     res = {}
     for split in ("0", "1"):
-        os.environ["SVOXT_FWD_SPLIT"] = split
+        _C.FWD_SPLIT = split
         _C.FWD_LIST_SAMPLES = 96 if split == "1" else 0
         rs.need_grad = False          # record=False means a forward nobody differentiates
         x = _C.volume_render(spec, rs, opt, record=record)
@@ -104,7 +104,6 @@ p = torch.randperm(W * H, device=dev)
 rp = svox.Rays(rays.origins[p].contiguous(), rays.dirs[p].contiguous(), rays.viewdirs[p].contiguous())
 both("shuffled", _rays_spec_from_rays(rp), opt, False)
 # short lists: most rays overflow and finish in the tail launch
-os.environ["SVOXT_BWD_LIST"] = "8"
 _C.BWD_LIST_SAMPLES = 8
 both("image hint, S=8", rsh, opt, True)
 _C.BWD_LIST_SAMPLES = 96

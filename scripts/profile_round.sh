@@ -2,7 +2,8 @@
 # One pass over everything profiles/rNN_* holds for the bench workloads (run on the GPU box through
 # gpurun; ~5 minutes):  per workload the bench line, rocprofv3 --kernel-trace --stats, and the PMC passes
 # (scripts/pmc_passes.sh: one rocprofv3 --pmc run per counter group, no trace domains).
-#   scripts/profile_round.sh <outdir under gpurun_out>      then copy what is to be judged into profiles/
+#   scripts/profile_round.sh <outdir under gpurun_out> [a|b|all]     then copy what is to be judged into profiles/
+#   (a: the headline config and the f-rows; b: configs[3], exact and native math)
 set -u
 ROUND=r03      # = bench.py's ROUND
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-prof}
@@ -29,23 +30,41 @@ pmc() {     # name, args...
   cp $OUT/${name}_pmc.json profiles/${ROUND}_${name}_pmc.json      # (on the box's copy: the bench lines below read it for roofline.traffic)
   echo "pmc $name done"
 }
-# headline (configs[2]) forward+backward, its forward alone, and the two opt-outs
+timing() {  # name, script, args...
+  local name=$1; shift
+  timeout -k 10 240 python3 "$@" > $OUT/${name}_timing.txt 2> $OUT/${name}_timing.err < /dev/null || echo "timing $name failed"
+  echo "timing $name done"
+}
+PART=${2:-all}
+if [ $PART = all ] || [ $PART = a ]; then
+# headline (configs[2]) forward+backward, its forward alone, the camera route (render_persp) and the two opt-outs
 pmc   d8_sh9_800
 stats d8_sh9_800
 bench d8_sh9_800
 bench d8_sh9_800_fwd --forward-only
+bench d8_sh9_800_camera --route camera --no-plain
 SVOXT_BWD_EXACT=0 bench d8_sh9_800_single_march --no-plain
 SVOXT_LIST_POOL=0 bench d8_sh9_800_dense_lists --no-plain
-# configs[3]: the one that leaves the Infinity Cache
+# configs[0]: the reference's own CPU-runnable case
+bench d5_rgba_64_fwd --workload d5_rgba_64 --forward-only
+# the rows SURVEY.md 8(f) added around the path, on this round's kernels
+timing persp scripts/persp_timing.py
+timing motion scripts/motion_timing.py
+timing xform scripts/xform_timing.py
+timing opacity scripts/opacity_timing.py
+timing build scripts/build_timing.py
+timing ray_order scripts/ray_order_timing.py
+fi
+if [ $PART = all ] || [ $PART = b ]; then
+# configs[3]: the one that leaves the Infinity Cache -- exact (the parity suite's mode) and native math (tolerance)
 pmc   d9_rgba32_1024 --workload d9_rgba32_1024
 stats d9_rgba32_1024 --workload d9_rgba32_1024
 bench d9_rgba32_1024 --workload d9_rgba32_1024
 pmc   d9_rgba32_1024_fwd --workload d9_rgba32_1024 --forward-only
 stats d9_rgba32_1024_fwd --workload d9_rgba32_1024 --forward-only
 bench d9_rgba32_1024_fwd --workload d9_rgba32_1024 --forward-only
-SVOXT_NATIVE_MATH=1 bench d9_rgba32_1024_fwd_native --workload d9_rgba32_1024 --forward-only --no-plain
 SVOXT_NATIVE_MATH=1 stats d9_rgba32_1024_native --workload d9_rgba32_1024
 SVOXT_NATIVE_MATH=1 pmc   d9_rgba32_1024_native --workload d9_rgba32_1024
-# configs[0]: the reference's own CPU-runnable case
-bench d5_rgba_64_fwd --workload d5_rgba_64 --forward-only
+SVOXT_NATIVE_MATH=1 stats d9_rgba32_1024_fwd_native --workload d9_rgba32_1024 --forward-only
+fi
 ls $OUT
