@@ -238,6 +238,9 @@ int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
 #define SVOXT_LISTS_NATIVE_MATH 1
 #define SVOXT_LISTS_FWD_ONE_KERNEL 2
 #define SVOXT_LISTS_FWD_TWO_KERNELS 4
+/*   SVOXT_LISTS_FWD_NO_OVERLAP   march and shade of the two-kernel forward as two launches even where lists.tile_state
+ *                                would let one launch carry both (below).  Result-neutral. */
+#define SVOXT_LISTS_FWD_NO_OVERLAP 8
 typedef struct svoxt_sample_lists {
     void*   rec;           /* device, 64-byte aligned, max_samples * ceil(Q / 64) * 64 * 8 bytes: record k of the
                               ray handled by launch thread t lives at rec[t / 64][k / 8][t % 64][k % 8] (8 bytes
@@ -285,6 +288,13 @@ typedef struct svoxt_sample_lists {
     void*   pool_next;
     int32_t terms_state;   /* see terms */
     int32_t flags;         /* 0 or an OR of SVOXT_LISTS_* (above) */
+    void*   tile_state;    /* optional (pooled lists only): device int32 [9 * ceil(Q / 64) + 512], scratch.  Given, the two-kernel
+                              forward of 3-channel payloads (N = 2, no view rotations, sigma bitmask at hand) runs its march
+                              and its shade as ONE launch: tiles are shaded in the order their marches finish, beside the
+                              marches still running (per-tile states, then per-XCD ready queues and their counters:
+                              fwd_roles_kernel).  Cleared by the
+                              forward together with the block table (one fill when it lies right behind pool_next's
+                              counters).  Same lists, terms and pixels bit for bit.  NULL: two launches. */
 } svoxt_sample_lists;
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt);

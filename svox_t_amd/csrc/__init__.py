@@ -93,11 +93,11 @@ class _CLists(ctypes.Structure):         # struct svoxt_sample_lists
                 ("coef", ctypes.c_void_p), ("coef_bytes", ctypes.c_int64),
                 ("terms", ctypes.c_void_p), ("terms_bytes", ctypes.c_int64),
                 ("blocktab", ctypes.c_void_p), ("pool_blocks", ctypes.c_int64), ("pool_next", ctypes.c_void_p),
-                ("terms_state", ctypes.c_int32), ("flags", ctypes.c_int32)]
+                ("terms_state", ctypes.c_int32), ("flags", ctypes.c_int32), ("tile_state", ctypes.c_void_p)]
 
 
 # svoxt_sample_lists.flags (include/svoxt.h)
-LISTS_NATIVE_MATH, LISTS_FWD_ONE_KERNEL, LISTS_FWD_TWO_KERNELS = 1, 2, 4
+LISTS_NATIVE_MATH, LISTS_FWD_ONE_KERNEL, LISTS_FWD_TWO_KERNELS, LISTS_FWD_NO_OVERLAP = 1, 2, 4, 8
 
 
 _P = ctypes.POINTER
@@ -203,6 +203,9 @@ BWD_EXACT = _env_flag("SVOXT_BWD_EXACT", "1")
 # reciprocal (forward and per-tile backward; include/svoxt.h SVOXT_LISTS_NATIVE_MATH); the stepping stays
 # bit-exact.  Outputs within 1e-5 relative, gradients within 1e-5 of the tight scale (tested at full size).
 NATIVE_MATH = _env_flag("SVOXT_NATIVE_MATH", "0")
+# SVOXT_FWD_OVERLAP=0: march and shade of the two-kernel forward as two launches instead of one grid that
+# carries both roles (include/svoxt.h, svoxt_sample_lists.tile_state); result-neutral
+FWD_OVERLAP = _env_flag("SVOXT_FWD_OVERLAP", "1")
 # --- not environment switches: routes the tests exercise by assignment
 BWD_TERMS = True     # False: no hand-over between the sweeps of the exact backwards (every row gathered twice)
 BWD_FUSED = True     # False: list walk and per-tile merge of an image's backward as two kernels (the form view rotations take)
@@ -214,6 +217,8 @@ def _list_flags(native: bool = False) -> int:
         f |= LISTS_FWD_ONE_KERNEL
     elif FWD_SPLIT not in ("", "0"):
         f |= LISTS_FWD_TWO_KERNELS
+    if not FWD_OVERLAP:
+        f |= LISTS_FWD_NO_OVERLAP
     return f
 
 
@@ -617,12 +622,13 @@ class SampleLists:
         if self.pooled:
             self.pool_blocks = (_pool_blocks_for(tiles, S) + 31) // 32 * 32      # 32 equal parts, a counter each
             nt = tiles * (S // 8)
-            both = torch.empty((nt + 32 * 16,), dtype=torch.int32, device=device)     # table, then the 32 counters
-            self.blocktab, self.pool_next = both[:nt], both[nt:]
+            # table, then the 32 counters, then the tile states, ready queues and their counters (march and shade in one launch): one fill
+            both = torch.empty((nt + 32 * 16 + 9 * tiles + 512,), dtype=torch.int32, device=device)
+            self.blocktab, self.pool_next, self.tile_state = both[:nt], both[nt:nt + 32 * 16], both[nt + 32 * 16:]
         else:
             # rec[tile][block][lane][8]: every ray owns S slots
             self.pool_blocks = tiles * (S // 8)
-            self.blocktab = self.pool_next = None
+            self.blocktab = self.pool_next = self.tile_state = None
         self.rec = torch.empty((self.pool_blocks * 512, 2), dtype=torch.int32, device=device)
         self.aux = torch.empty((Q, 4), dtype=torch.int32, device=device)
         self.S = S
@@ -658,7 +664,8 @@ class SampleLists:
                        None if self.blocktab is None else self.blocktab.data_ptr(),
                        self.pool_blocks if self.pooled else 0,
                        None if self.pool_next is None else self.pool_next.data_ptr(),
-                       self.terms_state, self.flags)
+                       self.terms_state, self.flags,
+                       None if self.tile_state is None else self.tile_state.data_ptr())
 
 
 def _list_cap(ct: "_CTree", base: int) -> int:
@@ -877,8 +884,13 @@ def _volume_render(tree, rays, opt, record):
     if ((split or fills == 3) and FWD_SPLIT != "0") if will_record else (split and co.stop_thresh == 0.0):
         _attach_sigma_mask(tree, ct, float(co.sigma_thresh), keep=not will_record)
     LAST_ROUTE["forward_terms"] = False
+    # march and shade of a 3-channel payload as ONE launch (fwd_roles_kernel): the conditions of the library's launch_fwd_roles
+    roles = bool(FWD_OVERLAP and LIST_POOL and ct.sigma_mask and ct.N == 2 and ct.xform is None and ct.weight_accum is None
+                 and cr.Q > 0 and ((co.format == FORMAT_RGBA and ct.K == 4) or
+                                   (co.format == FORMAT_SH and co.basis_dim in (1, 4, 9) and ct.K == 3 * co.basis_dim + 1)))
     LAST_ROUTE["forward"] = (("march_rec_kernel + shade_chan_kernel (two-kernel forward, channels on lanes"
                               + (", native exp / rcp)" if NATIVE_MATH else ")") if wide else
+                              "fwd_roles_kernel (march + shade_tile in one launch)" if roles else
                               "march_rec_kernel + shade_tile_kernel (two-kernel forward)") if split
                              else "render_fwd_kernel") + (", recording sample lists" if record else "")
     with torch.cuda.device(dev):
@@ -896,7 +908,8 @@ def _volume_render(tree, rays, opt, record):
             lists.note_usage()
             LAST_ROUTE["forward_terms"] = lists.terms_state in (2, 3)
             if lists.terms_state == 3 and FWD_SPLIT == "":
-                LAST_ROUTE["forward"] = "march_rec_kernel + shade_tile_kernel (two-kernel forward), recording sample lists"
+                LAST_ROUTE["forward"] = ("fwd_roles_kernel (march + shade_tile in one launch)" if roles else
+                                         "march_rec_kernel + shade_tile_kernel (two-kernel forward)") + ", recording sample lists"
         elif FWD_LIST_SAMPLES > 0 and cr.Q > 0:
             # scratch for the two-kernel forward (march, then shade per tile; the library falls
             # back to the one-kernel forward for payloads it does not cover)

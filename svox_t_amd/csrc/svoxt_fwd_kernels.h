@@ -307,17 +307,18 @@ sigma_mask_kernel(const float* __restrict__ features, int64_t M, int K, float th
 // (svoxt_sigma_mask_build: M / 8 bytes, resident in L2) instead of a 4-byte gather that pulls a
 // 64-byte line of the feature table -- half of this kernel's traffic, and HBM traffic once the table
 // has left the Infinity Cache (r02, depth 9 / 32-float rows: forward 1.29 -> 1.15 ms with no gather at all).
-template <bool N2, bool STOP, int ACC, bool MASK = false>
-__global__ void __launch_bounds__(kBlock)
-march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux,
-                 const uint32_t* __restrict__ sigma_mask = nullptr) {
+// The march of ONE tile by one wavefront (lane = threadIdx.x & 63); rstage / ltab: this wavefront's LDS
+// staging ([kRecBlock * 64] records) and block table ([kMaxRecBlocks]).
+template <bool N2, bool STOP, int ACC, bool MASK>
+__device__ __forceinline__ void march_rec_tile(const TreeDev& tr, const RaysDev& rays, const Opts& opt, const RecLists& L,
+                                               uint4* __restrict__ aux, const uint32_t* __restrict__ sigma_mask,
+                                               int64_t tile, uint2* __restrict__ rstage, int32_t* __restrict__ ltab) {
     static_assert(!(MASK && STOP), "the stop rule needs sigma itself");
-    __shared__ uint2 rstage[kRecBlock * kBlock];
-    __shared__ int32_t ltab[kMaxRecBlocks];
+    const int lane = (int)(threadIdx.x & 63);
     rec_tab_init(ltab);
     const int S = L.S;
     int64_t cur_block = 0;
-    const int64_t tid = ((int64_t)blockIdx.x + rays.tile0) * kBlock + threadIdx.x;
+    const int64_t tid = tile * 64 + lane;
     const int64_t q = ray_of_thread(rays, tid);
     if (q >= rays.Q) return;
     Ray r;
@@ -352,7 +353,7 @@ march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
                 room = cur_block >= 0;
             }
             if (room) {
-                rec_stage_put(rstage, (int)threadIdx.x, L.rec, cur_block, nrec, (uint32_t)p_idx, p_dt);
+                rec_stage_put(rstage, lane, L.rec, cur_block, nrec, (uint32_t)p_idx, p_dt);
                 ++nrec;
                 if constexpr (STOP) {
                     light *= pexpf(-p_dt * r.delta_scale * p_sigma);
@@ -381,41 +382,53 @@ march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
             room = cur_block >= 0;
         }
         if (room) {
-            rec_stage_put(rstage, (int)threadIdx.x, L.rec, cur_block, nrec, (uint32_t)p_idx, p_dt);
+            rec_stage_put(rstage, lane, L.rec, cur_block, nrec, (uint32_t)p_idx, p_dt);
             ++nrec;
         } else {
             over = kRecOverflow;
             t_resume = p_t;
         }
     }
-    rec_stage_finish(rstage, (int)threadIdx.x, L.rec, cur_block, nrec);
+    rec_stage_finish(rstage, lane, L.rec, cur_block, nrec);
     aux[q] = make_uint4((uint32_t)nrec | over, __float_as_uint(t_resume), __float_as_uint(1.f), 0u);
+}
+
+template <bool N2, bool STOP, int ACC, bool MASK = false>
+__global__ void __launch_bounds__(kBlock)
+march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux,
+                 const uint32_t* __restrict__ sigma_mask = nullptr) {
+    __shared__ uint2 rstage[kRecBlock * kBlock];
+    __shared__ int32_t ltab[kMaxRecBlocks];
+    march_rec_tile<N2, STOP, ACC, MASK>(tr, rays, opt, L, aux, sigma_mask, (int64_t)blockIdx.x + rays.tile0, rstage, ltab);
 }
 
 // WTERMS (recording forwards, no view rotations): the wavefronts that form a sample's exponentials also
 // leave them, with the attenuation in the backward's association (rt_kernel.cu:397), in L.terms
 // (position-major: 1 KB per wavefront and list position) for the exact backward.
-template <int FMT, int BD, bool XF, bool STOP, bool WTERMS = false>
-__global__ void __launch_bounds__(512)
-shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
-                  uint4* __restrict__ aux, float* __restrict__ out) {
-    constexpr int C = 3, W = 8, P = W - 1;
+// COH: the lists are read with agent-scope loads (rec_get_coherent ...): for the workgroup that shades a
+// tile inside the launch that marched it (fwd_roles_kernel).
+constexpr int kShadeP = 7;                       // list positions per round: one per wavefront but the first
+typedef float shade_v4f __attribute__((ext_vector_type(4)));
+template <int FMT, int BD, bool XF, bool STOP, bool WTERMS, bool COH>
+__device__ __forceinline__ void shade_tile_body(const TreeDev& tr, const RaysDev& rays, const Opts& opt, const RecLists& L,
+                                                uint4* __restrict__ aux, float* __restrict__ out, int64_t tile,
+                                                shade_v4f (*terms)[kShadeP][64] /* [2]: (att, e_0, e_1, e_2) of a list position, per ray */) {
+    constexpr int C = 3, W = 8, P = kShadeP;
+    static_assert(P == W - 1, "one wavefront runs along the rays");
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     constexpr int NB = (FMT == FMT_SH) ? BD : 1;
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    __shared__ v4f terms[2][P][64];              // (att, e_0, e_1, e_2) of a list position, per ray
+    typedef shade_v4f v4f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tile = (int64_t)blockIdx.x + rays.tile0;
     const int64_t q = ray_of_thread(rays, tile * 64 + lane);
     const bool inb = q < rays.Q;
     uint4 a = make_uint4(0u, 0u, 0u, 0u);
-    if (inb) a = aux[q];
+    if (inb) a = COH ? aux_get_coherent(aux + q) : aux[q];
     const int nrec = (int)(a.x & ~kRecOverflow);
     int maxn = nrec;
     for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
     maxn = __builtin_amdgcn_readfirstlane(maxn);     // what decides the barrier count is scalar
     const int nround = (maxn + P - 1) / P;           // the same in every wavefront of the workgroup
-    const int32_t tabreg = rec_tab_reg(L, tile, lane);
+    const int32_t tabreg = rec_tab_reg<COH>(L, tile, lane);
 
     float delta_scale = 0.f;
     float basis[NB];
@@ -437,7 +450,7 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
             const int k = rd * P + (wave - 1);
             if (rd < nround && k < nrec) {
                 const int64_t blk = rec_block_u(L, tabreg, tile, k >> 3);
-                const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
+                const uint2 e = COH ? rec_get_coherent(L.rec + rec_index_in(blk, lane, k)) : rec_get(L.rec + rec_index_in(blk, lane, k));
                 const int32_t idx = (int32_t)e.x;
                 float row[K];
                 load_row<K>(tr.features + (int64_t)idx * K, row);
@@ -505,6 +518,110 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
         a.z = __float_as_uint(light);                // the final transmittance, for the single-march backward
         aux[q] = a;
     }
+}
+
+// tile_state (optional): tiles whose entry is kTileShaded were shaded inside fwd_roles_kernel -- nothing to do
+constexpr int32_t kTileShaded = 0x200;
+template <int FMT, int BD, bool XF, bool STOP, bool WTERMS = false>
+__global__ void __launch_bounds__(512)
+shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
+                  uint4* __restrict__ aux, float* __restrict__ out, const int32_t* __restrict__ tile_state = nullptr) {
+    __shared__ shade_v4f terms[2][kShadeP][64];
+    const int64_t tile = (int64_t)blockIdx.x + rays.tile0;
+    if (tile_state != nullptr && tile_state[tile] == kTileShaded) return;       // (uniform: one tile per workgroup)
+    shade_tile_body<FMT, BD, XF, STOP, WTERMS, false>(tr, rays, opt, L, aux, out, tile, terms);
+}
+
+// ---------------------------------------------------------------------------
+// March and shade in ONE launch (r03): the forward as two kernels is two serial
+// phases of ~0.14 ms each at 800 x 800 / depth 8 -- a march that is as long as the dependent chain of
+// its longest ray and leaves the vector ALUs nearly idle while its last wavefronts finish, then a shade
+// kernel that is throughput work -- and two kernels on two streams only overlap what is independent
+// (exp/two_stream_halves.py: two half images 0.41 ms serial, 0.30 on two streams, the whole image 0.28 in
+// one call).  Here one grid carries both roles:
+//   workgroups [0, n_march)   8 wavefronts = the marches of 8 consecutive tiles (march_rec_tile, unchanged).
+//                             A wavefront that has written its tile's lists publishes the tile: all its
+//                             stores acknowledged (s_waitcnt vmcnt(0): they are in its XCD's L2), then the
+//                             tile id goes into the READY QUEUE OF ITS XCD (a position from an atomic counter,
+//                             the id stored there).
+//   the workgroups behind     each shades ONE tile (shade_tile_body; lists read with agent-scope loads: from the
+//                             L2, never from a stale line of the CU's vector cache) -- the next one of the
+//                             queue of the XCD IT RUNS ON (hardware register XCC_ID, not an assumption about
+//                             the dispatcher): thread 0 takes a position from the queue's second counter and
+//                             polls that entry (bounded: kRolePolls polls of ~1 us) until a march has filled
+//                             it.  Tiles are shaded in the order their marches finish, so no workgroup ever
+//                             waits for a particular long march while finished tiles queue behind it
+//                             (the first version -- shading workgroup i waits for tile i -- gained 0.018 ms
+//                             of the 0.14 it could; r03 measurement).
+// Termination: workgroups are dispatched in index order, so every march workgroup is resident or done before
+// the first shading workgroup exists -- a waiting workgroup can never keep a march off the machine -- and the
+// poll is bounded, so every wavefront reaches its end whatever happens.  Completeness: an XCD gets exactly as
+// many shading workgroups as tiles were marched on it when workgroup b runs on XCD b mod (number of XCDs) --
+// n_march is a multiple of 8 and shading workgroup i is active iff i / 8 < (tiles of march workgroups congruent
+// to i mod 8).  If the dispatcher does anything else, a queue sees more consumers than entries (they give up
+// after the poll budget) and another fewer (tiles stay unshaded): every tile not marked kTileShaded in
+// tile_state is shaded by the fallback launch that follows (shade_tile_kernel with tile_state) -- slower,
+// never wrong.  Same lists, terms and pixels bit for bit: the same device functions do the work.
+//
+// tile_state layout (int32, all -1 before the launch: lists_begin's fill): [0, T) per-tile state; then 16
+// counter slots of 32 words (a queue's tail at +0, its head at +16: 64 bytes apart; "next position" - 1, like
+// the block pool's counters); then 8 queues of T entries.
+constexpr int kRolePolls = 20000;
+constexpr int kRoleXcds = 8;
+__host__ __device__ inline int64_t roles_state_words(int64_t tiles) { return tiles + 16 * 32 + (int64_t)kRoleXcds * tiles; }
+
+template <int FMT, int BD, int ACC, bool WTERMS>
+__global__ void __launch_bounds__(512)
+fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux, float* __restrict__ out,
+                 const uint32_t* __restrict__ sigma_mask, int32_t* __restrict__ tile_state, int n_march, int ntiles) {
+    constexpr int kMarchBytes = 8 * (kRecBlock * 64 * (int)sizeof(uint2) + kMaxRecBlocks * (int)sizeof(int32_t));
+    constexpr int kShadeBytes = 2 * kShadeP * 64 * (int)sizeof(shade_v4f);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kMarchBytes > kShadeBytes ? kMarchBytes : kShadeBytes];
+    __shared__ int s_tile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (kRoleXcds - 1));      // HW_REG_XCC_ID, bits 3:0
+    int32_t* __restrict__ ctr = tile_state + ntiles + xcc * 32;
+    int32_t* __restrict__ queue = tile_state + ntiles + 16 * 32 + (int64_t)xcc * ntiles;
+    if ((int)blockIdx.x < n_march) {
+        const int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+        if (tile >= ntiles) return;
+        uint2* rstage = reinterpret_cast<uint2*>(lds) + wave * (kRecBlock * 64);
+        int32_t* ltab = reinterpret_cast<int32_t*>(lds + 8 * kRecBlock * 64 * sizeof(uint2)) + wave * kMaxRecBlocks;
+        march_rec_tile<true, false, ACC, true>(tr, rays, opt, L, aux, sigma_mask, tile, rstage, ltab);
+        // publish: every store of this wavefront (records, block table, aux) acknowledged by the L2 first
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) {
+            const int pos = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            __hip_atomic_store(queue + pos, (int32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    // is this shading workgroup one of those its XCD needs?  (see above; the same in every wavefront)
+    const int i = (int)blockIdx.x - n_march, a = i & 7, b = i >> 3;
+    const int G = (ntiles + 7) >> 3;                             // march workgroups that hold tiles
+    int mine = a < G ? 8 * ((G - a + 7) >> 3) : 0;
+    if (((G - 1) & 7) == a) mine -= 8 * G - ntiles;              // the last march workgroup may be partial
+    if (b >= mine) return;
+    if (threadIdx.x == 0) {
+        int32_t tile = -1;
+        const int idx = __hip_atomic_fetch_add(ctr + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        if (idx < ntiles) {
+            for (int p = 0; p < kRolePolls; ++p) {
+                tile = __hip_atomic_load(queue + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tile != -1) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
+        s_tile = tile;
+    }
+    __syncthreads();
+    const int64_t tile = s_tile;
+    if (tile < 0 || tile >= ntiles) return;                      // nothing arrived: left to the fallback launch
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    shade_tile_body<FMT, BD, false, false, WTERMS, true>(tr, rays, opt, L, aux, out, tile,
+                                                          reinterpret_cast<shade_v4f (*)[kShadeP][64]>(lds));
+    if (threadIdx.x == 0) tile_state[tile] = kTileShaded;        // (read by the fallback launch: after this kernel)
 }
 
 // The shade kernel for RGBA-style rows of K = 8, 16 or 32 floats (C = K - 1 feature channels and

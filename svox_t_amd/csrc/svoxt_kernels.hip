@@ -385,13 +385,61 @@ bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float
 // (Measured r02 and removed in r03: the tiles cut into 2..7 ranges pipelined over two streams, so that
 // the shade of one range runs beside the march of the next -- each cross-stream event dependency cost
 // more than the overlap returned: 800x800 depth-8 SH9 0.29 -> 0.59 ms with 4 ranges.)
+// March and shade as ONE launch (fwd_roles_kernel) + the fallback shade + the tail launch: 3-channel
+// payloads of at most 28 floats on N = 2 trees, no view rotations, no stop rule, the sigma bitmask at hand.
+template <bool N2, bool STOP>
+bool launch_fwd_roles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out, RecLists L, uint4* aux,
+                      hipStream_t st, const uint32_t* sigma_mask, int32_t* tile_state) {
+    if constexpr (!N2 || STOP) {
+        return false;
+    } else {
+        const unsigned nb = nblocks(rays.Q);
+        if (nb >= (1u << 30)) return false;
+        const int n_march = (int)(((nb + 7) / 8 + 7) / 8 * 8);          // a multiple of 8: see fwd_roles_kernel
+        const unsigned grid = (unsigned)n_march + (unsigned)n_march * 8;   // + 8 shading workgroups per march workgroup (the active ones: one per tile)
+        const bool acc = tr.accel != nullptr;
+        const bool wt = L.terms != nullptr;
+#define SVOXT_ROLES(F, BB)                                                                                        \
+        {                                                                                                         \
+            if (acc && wt) hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 1, true>), dim3(grid), dim3(512), 0, st,   \
+                                              tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb); \
+            else if (acc) hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 1, false>), dim3(grid), dim3(512), 0, st,   \
+                                             tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb); \
+            else if (wt) hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 0, true>), dim3(grid), dim3(512), 0, st,     \
+                                            tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb); \
+            else hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 0, false>), dim3(grid), dim3(512), 0, st,            \
+                                    tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb);        \
+            if (wt) hipLaunchKernelGGL((shade_tile_kernel<F, BB, false, false, true>), dim3(nb), dim3(512), 0, st, \
+                                       tr, rays, opt, L, aux, out, (const int32_t*)tile_state);                   \
+            else hipLaunchKernelGGL((shade_tile_kernel<F, BB, false, false, false>), dim3(nb), dim3(512), 0, st,  \
+                                    tr, rays, opt, L, aux, out, (const int32_t*)tile_state);                      \
+            hipLaunchKernelGGL((render_fwd_kernel<F, 3, BB, true, false, false, true>), dim3(nb), dim3(kBlock), 0, st, \
+                               tr, rays, opt, out, L, aux);                                                       \
+            return true;                                                                                          \
+        }
+        if (opt.format == FMT_RGBA && tr.K == 4) SVOXT_ROLES(FMT_RGBA, 0)
+        if (opt.format == FMT_SH) {
+            switch (opt.basis_dim) {
+                case 1: SVOXT_ROLES(FMT_SH, 1)
+                case 4: SVOXT_ROLES(FMT_SH, 4)
+                case 9: SVOXT_ROLES(FMT_SH, 9)
+            }
+        }
+#undef SVOXT_ROLES
+        return false;
+    }
+}
+
 template <bool N2, bool STOP>
 bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out,
                       RecLists L, uint4* aux, bool xf, bool fast, hipStream_t st,
-                      const uint32_t* sigma_mask = nullptr) {
+                      const uint32_t* sigma_mask = nullptr, int32_t* tile_state = nullptr) {
     const unsigned nb = nblocks(rays.Q);
     if (xf && !N2) return false;
     const bool acc = N2 && tr.accel != nullptr;
+    if (tile_state != nullptr && sigma_mask != nullptr && !xf && !STOP &&
+        launch_fwd_roles<N2, STOP>(tr, rays, opt, out, L, aux, st, sigma_mask, tile_state))
+        return true;
     if constexpr (!STOP) {
         if (sigma_mask != nullptr) {
             if (acc) hipLaunchKernelGGL((march_rec_kernel<N2, false, 1, true>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, L, aux, sigma_mask);
@@ -675,12 +723,17 @@ static int lists_begin(const svoxt_sample_lists* l, int64_t Q, hipStream_t st, c
     if (l->blocktab == nullptr) return SVOXT_OK;
     const size_t n = (size_t)(rec_rays(Q) / 64) * (l->max_samples / kRecBlock) * sizeof(int32_t);
     const size_t nc = sizeof(int32_t) * kSubPools * kSubPoolStride;
+    const size_t ns = l->tile_state != nullptr ? (size_t)roles_state_words(rec_rays(Q) / 64) * sizeof(int32_t) : 0;   // states, counters, queues: all -1
     hipError_t e;
     if (reinterpret_cast<char*>(l->blocktab) + n == reinterpret_cast<char*>(l->pool_next)) {
-        e = hipMemsetAsync(l->blocktab, 0xff, n + nc, st);       // counters right behind the table: one fill
+        // counters right behind the table (and the tile states right behind the counters): one fill
+        const bool all = ns > 0 && reinterpret_cast<char*>(l->pool_next) + nc == reinterpret_cast<char*>(l->tile_state);
+        e = hipMemsetAsync(l->blocktab, 0xff, n + nc + (all ? ns : 0), st);
+        if (e == hipSuccess && ns > 0 && !all) e = hipMemsetAsync(l->tile_state, 0xff, ns, st);
     } else {
         e = hipMemsetAsync(l->blocktab, 0xff, n, st);
         if (e == hipSuccess) e = hipMemsetAsync(l->pool_next, 0xff, nc, st);
+        if (e == hipSuccess && ns > 0) e = hipMemsetAsync(l->tile_state, 0xff, ns, st);
     }
     if (e != hipSuccess) return fail(SVOXT_ERR_HIP, "%s: hipMemsetAsync: %s", fn, hipGetErrorString(e));
     return SVOXT_OK;
@@ -722,9 +775,13 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
         // one bit per feature row, built for this feature table and this sigma_thresh (else ignored)
         const uint32_t* smask = (tree->sigma_mask != nullptr && tree->sigma_mask_thresh == opt->sigma_thresh)
                                     ? reinterpret_cast<const uint32_t*>(tree->sigma_mask) : nullptr;
+        // (tile states: march and shade as ONE launch; pooled lists only -- their fill clears the states too)
+        auto states = [&](const svoxt_sample_lists* l) -> int32_t* {
+            return (l->blocktab != nullptr && !(lflags & SVOXT_LISTS_FWD_NO_OVERLAP)) ? reinterpret_cast<int32_t*>(l->tile_state) : nullptr;
+        };
         if (lists != nullptr) {
             uint4* aux = reinterpret_cast<uint4*>(lists->aux);
-            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, xf, fast, st, smask)
+            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, xf, fast, st, smask, states(lists))
                       : launch_fwd_split<false, false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, xf, fast, st, smask);
         } else if (scratch != nullptr && smask != nullptr && opt->stop_thresh == 0.f) {
             // With stop_thresh = 0 the stop rule ends a ray only once its transmittance is exactly 0; every
@@ -732,7 +789,7 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
             // outputs are the same without it, and the march needs no sigma value -- the bitmask will do.
             if ((rc = lists_begin(scratch, rays->Q, st, fn))) return rc;
             uint4* aux = reinterpret_cast<uint4*>(scratch->aux);
-            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, lists_dev(scratch, rays->Q), aux, xf, fast, st, smask)
+            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, lists_dev(scratch, rays->Q), aux, xf, fast, st, smask, states(scratch))
                       : launch_fwd_split<false, false>(tr, rd, od, out, lists_dev(scratch, rays->Q), aux, xf, fast, st, smask);
         } else if (scratch != nullptr) {      // caller-owned lists as scratch (dense or pooled): the stop rule applies
             if ((rc = lists_begin(scratch, rays->Q, st, fn))) return rc;

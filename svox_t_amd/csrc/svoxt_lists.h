@@ -45,6 +45,23 @@ __device__ __forceinline__ uint2 rec_get(const uint2* p) {
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 
+// The same reads for a consumer that runs INSIDE the kernel that wrote the lists (fwd_roles_kernel: the
+// shading workgroup of a tile starts as soon as the tile's march has published it): relaxed agent-scope
+// atomic loads -- global_load ... sc1: served by the XCD's L2, never by a stale line of this CU's vector
+// cache (the block table's lines are shared between neighbouring tiles, which other workgroups of the CU
+// may have read before this tile's entries were written).
+__device__ __forceinline__ uint2 rec_get_coherent(const uint2* p) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+__device__ __forceinline__ uint4 aux_get_coherent(const uint4* p) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+}
+
 // Where record k of the ray handled by launch thread `tid` (tile tid >> 6, lane tid & 63) lives:
 // rec[tile][k / 8][lane][k % 8] -- the 8 records of a block are the lane's own 64-byte line.
 // (Round 1 kept rec[k][q]: every record a lone 8-byte store to a different line.  A wavefront's
@@ -91,9 +108,12 @@ __device__ __forceinline__ int64_t rec_block(const RecLists& L, int64_t tile, in
 // Kernels whose wavefronts each work on ONE tile and one block at a time keep the tile's table in a
 // register -- lane b holds block b -- and read it with readlane: no table load in front of every
 // record load (r02: the per-tile backward lost 0.02 ms to exactly that).
+template <bool COHERENT = false>
 __device__ __forceinline__ int32_t rec_tab_reg(const RecLists& L, int64_t tile, int lane) {
     const int nb = L.S >> 3;
-    return (L.tab != nullptr && lane < nb) ? L.tab[tile * (int64_t)nb + lane] : -1;
+    if (L.tab == nullptr || lane >= nb) return -1;
+    if constexpr (COHERENT) return __hip_atomic_load(L.tab + tile * (int64_t)nb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return L.tab[tile * (int64_t)nb + lane];
 }
 __device__ __forceinline__ int64_t rec_block_u(const RecLists& L, int32_t tabreg, int64_t tile, int b /* wavefront-uniform */) {
     if (L.tab == nullptr) return tile * (int64_t)(L.S >> 3) + b;
@@ -117,8 +137,9 @@ __device__ __forceinline__ int64_t rec_index_in(int64_t block, int64_t tid, int 
 // that are about to write the FIRST record of block b (a divergent subset of the wavefront, possibly
 // with different b): the block is taken from the table, or a leader among them takes one from the
 // pool for all.  Returns -2 when the pool is used up (the ray's list then counts as full).
-__device__ __forceinline__ void rec_tab_init(int32_t* ltab) {
-    if (threadIdx.x < kMaxRecBlocks) ltab[threadIdx.x] = -1;
+__device__ __forceinline__ void rec_tab_init(int32_t* ltab) {       // (ltab: this WAVEFRONT's table)
+    static_assert(kMaxRecBlocks <= 64, "one lane per table entry");
+    if ((int)(threadIdx.x & 63) < kMaxRecBlocks) ltab[threadIdx.x & 63] = -1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }

@@ -288,6 +288,59 @@ def test_two_kernel_forward_equals_one_kernel_forward(name, gpu, monkeypatch):
             assert (v - ref).abs().max().item() <= 1e-5 * scale, k
 
 
+@pytest.mark.parametrize("name", ["d5_rgba4", "d5_sh9", "d5_sh4_world", "d5_sh1"])
+@pytest.mark.parametrize("shape", ["image", "ragged"])
+def test_march_and_shade_in_one_launch_change_nothing(name, shape, gpu, monkeypatch):
+    """fwd_roles_kernel (include/svoxt.h, svoxt_sample_lists.tile_state): one grid whose first workgroups
+    march and whose others shade each tile as soon as its march has published it.  Against the two
+    launches it replaces: pixels, lists (through the backward that replays them) and hand-over bit for bit
+    -- recording forward and scratch forward, lists long enough and too short (tail launch), an image and
+    a batch whose last tile is ragged -- and against the oracle."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd import synth
+    from svox_t_amd.renderer import _rays_spec_from_rays
+    c = Case(**CASES[name])
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    opt = r._get_options()
+    spec = tree._spec(tree.features)
+    rays = c.rays_gpu(gpu)
+    W, H = CASES[name]["width"], CASES[name]["height"]
+    if shape == "ragged":
+        n = c.Q - 37                                  # not a multiple of 64, not an image
+        rays = svox.Rays(*(t[:n].contiguous() for t in rays))
+        rs = _rays_spec_from_rays(rays)
+        o, d, v = (a[:n] for a in c.rays_np())
+    else:
+        n = c.Q
+        rs = _rays_spec_from_rays(rays, (H, W))
+        o, d, v = c.rays_np()
+    want = O.volume_render(c.oracle_tree(), o, d, v, c.oracle_opts())
+    g = synth.grad_output(n, want.shape[1]).to(gpu)
+    monkeypatch.setattr(_C, "FWD_SPLIT", "1")          # the march + shade forward also where it is not the default
+    res = {}
+    for overlap in (False, True):
+        monkeypatch.setattr(_C, "FWD_OVERLAP", overlap)
+        for S in (96, 8):
+            monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", S)
+            monkeypatch.setattr(_C, "FWD_LIST_SAMPLES", S)
+            rs.need_grad = False
+            plain = _C.volume_render(spec, rs, opt)                      # scratch lists
+            assert ("fwd_roles_kernel" in _C.LAST_ROUTE["forward"]) == overlap, _C.LAST_ROUTE
+            out, lists = _C.volume_render(spec, rs, opt, record=True)    # recorded lists (+ the backward's hand-over)
+            assert ("fwd_roles_kernel" in _C.LAST_ROUTE["forward"]) == overlap, _C.LAST_ROUTE
+            np.testing.assert_array_equal(plain.cpu().numpy(), want)
+            np.testing.assert_array_equal(out.cpu().numpy(), want)
+            grad = _C.volume_render_backward(spec, rs, opt, g, lists=lists)
+            res[(overlap, S)] = (lists.aux.clone(), None if lists.terms is None else lists.terms.clone(), lists.terms_state, grad)
+    for S in (96, 8):
+        a, b = res[(False, S)], res[(True, S)]
+        assert torch.equal(a[0][:, :3], b[0][:, :3])               # counts / overflow, resume points, final transmittance
+        assert a[2] == b[2]
+        scale = a[3].abs().max().item()
+        assert (a[3] - b[3]).abs().max().item() <= 1e-6 * scale      # the same contributions, float atomics' order aside
+
+
 class _ReferenceShapedFunction(torch.autograd.Function):
     """What the reference's own svox_t/renderer.py:60-77 does with whatever module it found as
     `svox_t.csrc` -- two calls, the same spec objects, nothing else (route B of INTEGRATION.md)."""
@@ -420,7 +473,7 @@ def test_sigma_bitmask_changes_nothing(name, gpu, monkeypatch):
     _C._SIGMA_CACHE.clear()
     with torch.no_grad():
         got = r(tree.features, rays, image_shape=shape)
-    assert "march_rec_kernel" in _C.LAST_ROUTE["forward"]
+    assert "march" in _C.LAST_ROUTE["forward"]
     np.testing.assert_array_equal(got.cpu().numpy(), want)
     assert len(_C._SIGMA_CACHE) == 0             # nothing derived from the features' content is kept by default ...
     tree.static_features = True                  # ... only for a table its owner declares static
