@@ -421,9 +421,10 @@ __device__ __forceinline__ void shade_tile_body(const TreeDev& tr, const RaysDev
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t q = ray_of_thread(rays, tile * 64 + lane);
     const bool inb = q < rays.Q;
-    uint4 a = make_uint4(0u, 0u, 0u, 0u);
-    if (inb) a = COH ? aux_get_coherent(aux + q) : aux[q];
-    const int nrec = (int)(a.x & ~kRecOverflow);
+    // (only the count lives through the rounds; wavefront 0 reads the entry again when it finalises the ray)
+    uint32_t a_x = 0u;
+    if (inb) a_x = COH ? aux_get_coherent(aux + q).x : aux[q].x;
+    const int nrec = (int)(a_x & ~kRecOverflow);
     int maxn = nrec;
     for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
     maxn = __builtin_amdgcn_readfirstlane(maxn);     // what decides the barrier count is scalar
@@ -498,6 +499,7 @@ __device__ __forceinline__ void shade_tile_body(const TreeDev& tr, const RaysDev
         __syncthreads();
     }
     if (wave == 0 && inb) {
+        uint4 a = COH ? aux_get_coherent(aux + q) : aux[q];
         float* o = out + q * (C + 1);
         if (stopped) {
             const float scale = (float)(1.0 / (1.0 - (double)light));
@@ -578,20 +580,25 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
     constexpr int kShadeBytes = 2 * kShadeP * 64 * (int)sizeof(shade_v4f);
     __shared__ __attribute__((aligned(16))) unsigned char lds[kMarchBytes > kShadeBytes ? kMarchBytes : kShadeBytes];
     __shared__ int s_tile;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (kRoleXcds - 1));      // HW_REG_XCC_ID, bits 3:0
-    int32_t* __restrict__ ctr = tile_state + ntiles + xcc * 32;
-    int32_t* __restrict__ queue = tile_state + ntiles + 16 * 32 + (int64_t)xcc * ntiles;
+    const int wave = threadIdx.x >> 6;
+    // (the queue addresses are formed where they are used, behind the march: nothing of them lives across it)
+    auto my_xcc = []() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (kRoleXcds - 1)); };   // HW_REG_XCC_ID, bits 3:0
     if ((int)blockIdx.x < n_march) {
         const int64_t tile = (int64_t)blockIdx.x * 8 + wave;
         if (tile >= ntiles) return;
         uint2* rstage = reinterpret_cast<uint2*>(lds) + wave * (kRecBlock * 64);
         int32_t* ltab = reinterpret_cast<int32_t*>(lds + 8 * kRecBlock * 64 * sizeof(uint2)) + wave * kMaxRecBlocks;
+        // the kernel is as long as its longest march plus that tile's shade: the marching wavefronts' few
+        // instructions per crossing go ahead of the shading wavefronts' many (issue priority 3 of 0..3)
+        __builtin_amdgcn_s_setprio(3);
         march_rec_tile<true, false, ACC, true>(tr, rays, opt, L, aux, sigma_mask, tile, rstage, ltab);
         // publish: every store of this wavefront (records, block table, aux) acknowledged by the L2 first
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
-        if (lane == 0) {
+        if ((threadIdx.x & 63) == 0) {
+            const int xcc = my_xcc();
+            int32_t* ctr = tile_state + ntiles + xcc * 32;
+            int32_t* queue = tile_state + ntiles + 16 * 32 + (int64_t)xcc * ntiles;
             const int pos = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
             __hip_atomic_store(queue + pos, (int32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -605,6 +612,9 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
     if (b >= mine) return;
     if (threadIdx.x == 0) {
         int32_t tile = -1;
+        const int xcc = my_xcc();
+        int32_t* ctr = tile_state + ntiles + xcc * 32;
+        int32_t* queue = tile_state + ntiles + 16 * 32 + (int64_t)xcc * ntiles;
         const int idx = __hip_atomic_fetch_add(ctr + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
         if (idx < ntiles) {
             for (int p = 0; p < kRolePolls; ++p) {
