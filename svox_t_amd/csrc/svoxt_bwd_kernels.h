@@ -826,7 +826,12 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                   RecLists L, const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
                   float* __restrict__ grad, int gstride, unsigned long long* __restrict__ counters = nullptr) {
     float4* __restrict__ terms = L.terms;
-    constexpr int C = 3, W = 8, NT = 64 * W, T = 1024, R = 1024, RPP = R / (64 * W);
+    // P list positions per round, formed by wavefronts W - P .. W - 1 (pw = the wavefront's position in the round);
+    // wavefront 0 only runs along the rays.  (r03: with P = W wavefront 0 also formed the terms of a position
+    // and was every round's critical path -- its own terms, then the barrier, then the advance of the
+    // round while the others already waited at the next barrier: 5 100 cycles per round of sweep 2.)
+    constexpr int C = 3, W = 8, P = W - 1, NT = 64 * W, T = 1024, R = 1024, RPP = 2;
+    static_assert(RPP * P * 64 <= R && P >= 1 && P <= W, "a pass must fit the record arrays");
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     constexpr int NB = (FMT == FMT_SH) ? BD : 0;
     constexpr int BDS = (FMT == FMT_SH) ? (BD | 1) : 1;
@@ -843,7 +848,10 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     __shared__ float stage_all[W * 64 * KS];
     __shared__ int32_t seg_all[W * 64];
     __shared__ int32_t s_nb;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wavefront's number as a SCALAR: what is decided by it -- who forms terms, who prefetches -- is then
+    // uniform control flow for the compiler too, with no per-lane merge of the values defined under it)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pw = wave - (W - P);                           // < 0: this wavefront forms no terms
     float* stage = stage_all + wave * 64 * KS;
     int32_t* seg = seg_all + wave * 64;
     const int32_t tabreg = rec_tab_reg(L, blockIdx.x, lane);
@@ -891,14 +899,36 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         // round; r_w / r_sg carry (att, total_color) from the wavefront that formed them to wavefront 0,
         // double-buffered by the parity of the round (one barrier per round)
         float light1 = 1.f;
-        const int nr1 = (maxn + W - 1) / W;                  // the same in every wavefront
+        const int nr1 = (maxn + P - 1) / P;                  // the same in every wavefront
+        // (r03) The hand-over of a round is requested one round ahead and the rounds' barriers order LDS
+        // traffic only (lds_barrier), so the request stays in flight across them: a round used to begin with
+        // a load from memory that nothing overlapped -- 2 900 shader-clock cycles per round of sweep 1, 5 100
+        // per round of sweep 2, most of it that latency (exp/trace_fused.py, r02).
+        float4 tv_next = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto terms_at = [&](int k) {
+            const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
+            return terms[TERMS == 2 ? terms_index(blk, lane, k) : terms_index_pm(blk, lane, k)];
+        };
+        if constexpr (TERMS >= 2) {
+            if (pw >= 0 && pw < maxn) tv_next = terms_at(pw);
+        }
+#pragma unroll 2
         for (int rd = 0; rd <= nr1; ++rd) {
-            const int k = rd * W + wave;
-            if (rd < nr1 && k < nrec) {
+            const int k = rd * P + pw;
+            // The next round's request, by EVERY lane of the wavefront under SCALAR conditions: a lane whose list
+            // ends before k + P reads a stale slot of the same block and never looks at it (a load under a per-lane
+            // condition comes with a merge of old and new value that waits for it on the spot); the block of
+            // position k + P exists iff some ray of the tile has that many records, and the block index handed to
+            // rec_block_u must be the same in all lanes.
+            float4 tv_cur = tv_next;
+            if constexpr (TERMS >= 2) {
+                if (pw >= 0 && rd < nr1 && k + P < maxn) tv_next = terms_at(k + P);
+            }
+            if (pw >= 0 && rd < nr1 && k < nrec) {
                 const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
                 float att, ex[C];                             // exp(-x_c): sigmoid_d(x) = 1.0 / (1.0 + double(exp(-x)))
                 if constexpr (TERMS >= 2) {
-                    const float4 tv = terms[TERMS == 2 ? terms_index(blk, lane, k) : terms_index_pm(blk, lane, k)];
+                    const float4 tv = tv_cur;
                     att = tv.x; ex[0] = tv.y; ex[1] = tv.z; ex[2] = tv.w;
                 } else {
                     const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
@@ -924,27 +954,28 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 float total_color = 0.f;
 #pragma unroll
                 for (int c = 0; c < C; ++c) total_color += (float)(1.0 / (1.0 + (double)ex[c])) * g[c];
-                const int sl = ((rd & 1) * W + wave) * 64 + lane;
+                const int sl = ((rd & 1) * P + pw) * 64 + lane;
                 r_w[sl] = att; r_sg[sl] = total_color;
             }
             if (wave == 0 && rd > 0) {
                 // (the operands of the round's eight positions first, then what depends on the step before)
-                float av[W], tv[W];
+                float av[P], tv[P];
 #pragma unroll
-                for (int j = 0; j < W; ++j) {
-                    const int sl = (((rd - 1) & 1) * W + j) * 64 + lane;
+                for (int j = 0; j < P; ++j) {
+                    const int sl = (((rd - 1) & 1) * P + j) * 64 + lane;
                     av[j] = r_w[sl]; tv[j] = r_sg[sl];
                 }
 #pragma unroll
-                for (int j = 0; j < W; ++j) {
-                    if ((rd - 1) * W + j < nrec) {
+                for (int j = 0; j < P; ++j) {
+                    if ((rd - 1) * P + j < nrec) {
                         const float weight = light1 * (1.f - av[j]);
                         light1 *= av[j];
                         accum += weight * tv[j];
                     }
                 }
             }
-            __syncthreads();
+            if constexpr (TERMS >= 2) lds_barrier();         // (TERMS 1: this sweep's global stores are read by the next)
+            else __syncthreads();
         }
         if (wave == 0) {
             if (a.x & kRecOverflow) {                        // list + tail: from the tail-only launch in front
@@ -961,20 +992,40 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     }
     __syncthreads();
 
-    for (int k0 = 0; k0 < maxn; k0 += RPP * W) {
-        // ---- terms + advance, RPP rounds of W list positions
-#pragma unroll 1
+    // this wavefront's record (and hand-over) of the NEXT round, requested a round ahead: rounds follow each
+    // other at k + P across the passes' boundaries as well
+    constexpr bool PRE = EXACT && TERMS != 0;
+    uint2 e_next = make_uint2(0u, 0u);
+    float4 t2_next = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto request = [&](int k) {
+        const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
+        e_next = rec_get(L.rec + rec_index_in(blk, lane, k));
+        t2_next = terms[TERMS == 2 ? terms_index(blk, lane, k) : terms_index_pm(blk, lane, k)];
+    };
+    if constexpr (PRE) {
+        if (pw >= 0 && pw < maxn) request(pw);
+    }
+    for (int k0 = 0; k0 < maxn; k0 += RPP * P) {
+        // ---- terms + advance, RPP rounds of P list positions (unrolled: the two rounds take turns with the two
+        // register sets of the prefetch -- rolled up, the set just loaded is moved into the loop-carried one at the
+        // end of every round, which waits for the load there)
+#pragma unroll
         for (int rd = 0; rd < RPP; ++rd) {
-            const int kb = k0 + rd * W;                      // the same in every wavefront
+            const int kb = k0 + rd * P;                      // the same in every wavefront
             if (kb >= maxn) break;
-            const int k = kb + wave;
-            const int slot = (rd * W + wave) * 64 + lane;
-            if (k < nrec) {
+            const int k = kb + pw;
+            const int slot = (rd * P + pw) * 64 + lane;
+            uint2 e = e_next;
+            const float4 tv_pre = t2_next;
+            if constexpr (PRE) {
+                if (pw >= 0 && k + P < maxn) request(k + P);      // (scalar conditions, every lane loads: see sweep 1)
+            }
+            if (pw >= 0 && k < nrec) {
                 const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
-                const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
+                if constexpr (!PRE) e = rec_get(L.rec + rec_index_in(blk, lane, k));
                 float att, tc, cf[C];
                 if constexpr (EXACT && TERMS != 0) {
-                    const float4 tv = terms[TERMS == 2 ? terms_index(blk, lane, k) : terms_index_pm(blk, lane, k)];
+                    const float4 tv = tv_pre;
                     const float ex[C] = {tv.y, tv.z, tv.w};
                     att = tv.x;
                     tc = 0.f;
@@ -1006,18 +1057,19 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 r_w[slot] = att; r_sg[slot] = tc; r_dt[slot] = __uint_as_float(e.y);
                 r_c[slot] = cf[0]; r_c[R + slot] = cf[1]; r_c[2 * R + slot] = cf[2];
             }
-            __syncthreads();
+            if constexpr (PRE) lds_barrier();
+            else __syncthreads();
             if (wave == 0) {
-                float av[W], tv[W], dv[W];
+                float av[P], tv[P], dv[P];
 #pragma unroll
-                for (int j = 0; j < W; ++j) {
-                    const int s2 = (rd * W + j) * 64 + lane;
+                for (int j = 0; j < P; ++j) {
+                    const int s2 = (rd * P + j) * 64 + lane;
                     av[j] = r_w[s2]; tv[j] = r_sg[s2]; dv[j] = r_dt[s2];
                 }
 #pragma unroll
-                for (int j = 0; j < W; ++j) {
+                for (int j = 0; j < P; ++j) {
                     if (kb + j < nrec) {
-                        const int s2 = (rd * W + j) * 64 + lane;
+                        const int s2 = (rd * P + j) * 64 + lane;
                         float cf[C] = {0.f, 0.f, 0.f};
                         if constexpr (FMT == FMT_RGBA) { cf[0] = r_c[s2]; cf[1] = r_c[R + s2]; cf[2] = r_c[2 * R + s2]; }
                         float wgt, sg;
@@ -1046,7 +1098,8 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             for (int j2 = 0; j2 < PER; ++j2) { cnt[lane * PER + j2] = run; run += mine[j2]; }
             if (lane == 63) s_nb = incl;
         }
-        __syncthreads();
+        lds_barrier();       // (the phases of a pass hand over through LDS alone: the next round's request and the
+                             // gradient atomics stay in flight across their barriers)
         const int nb = __builtin_amdgcn_readfirstlane(s_nb);
         if constexpr (COUNT) {          // distinct feature rows of this pass = occupied table slots
             unsigned long long rows = 0;
@@ -1058,7 +1111,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             const uint32_t v = r_sl[rr];
             if (v != 0xffffffffu) order[atomicAdd(cnt + (v >> 6), 1)] = (uint16_t)rr;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- reduce: 64 sorted records at a time per wavefront, the K columns in two rounds
         // (0-15, 16-K: each atomic instruction of a row touches one 64-byte line of a row that
         // starts on a 128-byte boundary)
@@ -1140,11 +1193,11 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 }
             }
         }
-        if (k0 + RPP * W >= maxn) break;                 // last pass (scalar condition)
-        __syncthreads();
+        if (k0 + RPP * P >= maxn) break;                 // last pass (scalar condition)
+        lds_barrier();
         for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
         for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
-        __syncthreads();
+        lds_barrier();
     }
 }
 

@@ -202,6 +202,16 @@ __device__ __forceinline__ void terms_flush(const float4* __restrict__ lds, int 
     }
 }
 
+// A workgroup barrier that orders LDS traffic only: global loads a wavefront has already requested (the
+// next round's record and hand-over) stay in flight across it, where __syncthreads() waits for them
+// (its release fence covers global memory: s_waitcnt vmcnt(0)).  For barriers between phases that hand
+// data over through LDS alone.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
