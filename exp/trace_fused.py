@@ -29,17 +29,17 @@ def build():
     sub("    if (maxn == 0) return;                                   // the same in every wavefront of the workgroup\n",
         "    if (maxn == 0) return;\n    unsigned long long tprev_ = clock64();\n    if (threadIdx.x == 0) atomicAdd(&g_ph[7], 1ull);\n")
     sub("    if constexpr (EXACT) {\n        // ---- sweep 1", ph(0) + "    if constexpr (EXACT) {\n        // ---- sweep 1")
-    sub("    __syncthreads();\n\n    for (int k0 = 0; k0 < maxn; k0 += RPP * P) {\n        // ---- terms + advance",
-        "    __syncthreads();\n" + ph(1) + "\n    for (int k0 = 0; k0 < maxn; k0 += RPP * P) {\n        // ---- terms + advance")
+    sub("    for (int k0 = 0; k0 < maxn; k0 += RPP * P) {\n        // ---- terms + advance",
+        ph(1) + "    for (int k0 = 0; k0 < maxn; k0 += RPP * P) {\n        // ---- terms + advance")
     sub("        if (wave == 1) {\n            constexpr int PER = T / 64;", ph(2) + "        if (wave == 1) {\n            constexpr int PER = T / 64;")
-    sub("        __syncthreads();\n        const int nb = __builtin_amdgcn_readfirstlane(s_nb);",
-        "        __syncthreads();\n" + ph(3) + "        const int nb = __builtin_amdgcn_readfirstlane(s_nb);")
-    sub("        __syncthreads();\n        // ---- reduce: 64 sorted records at a time per wavefront",
-        "        __syncthreads();\n" + ph(4) + "        // ---- reduce: 64 sorted records at a time per wavefront")
+    sub("        const int nb = __builtin_amdgcn_readfirstlane(s_nb);",
+        ph(3) + "        const int nb = __builtin_amdgcn_readfirstlane(s_nb);")
+    sub("        lds_barrier();\n        // ---- reduce: 64 sorted records at a time per wavefront",
+        "        lds_barrier();\n" + ph(4) + "        // ---- reduce: 64 sorted records at a time per wavefront")
     sub("        if (k0 + RPP * P >= maxn) break;                 // last pass (scalar condition)\n",
         ph(5) + "        if (k0 + RPP * P >= maxn) break;\n")
-    sub("        for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;\n        __syncthreads();\n    }\n}",
-        "        for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;\n        __syncthreads();\n" + ph(6) + "    }\n}")
+    sub("        for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;\n        lds_barrier();\n    }\n}",
+        "        for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;\n        lds_barrier();\n" + ph(6) + "    }\n}")
     # the device array goes in front of the kernel's template line
     t = src.rindex("template <int FMT, int BD, bool EXACT, bool COUNT = false, int TERMS = 0>", 0, a)
     src = src[:t] + "__device__ unsigned long long g_ph[8];\n" + src[t:a] + body + src[b:]

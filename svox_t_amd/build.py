@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(CSRC, LIB_NAME)
 RESOURCES_PATH = os.path.join(CSRC, "libsvoxt_hip.resources.txt")
 SOURCES = ["svoxt_kernels.hip", "svoxt_build.hip", "svoxt_motion.hip", "svoxt_order.hip"]
 HEADERS = ["svoxt_device.h", "svoxt_host.h", "svoxt_lists.h", "svoxt_fwd_kernels.h", "svoxt_bwd_kernels.h",
-           "svoxt_misc_kernels.h", os.path.join("..", "..", "include", "svoxt.h")]
+           "svoxt_misc_kernels.h", "svoxt_tile_reduce.inc", os.path.join("..", "..", "include", "svoxt.h")]
 
 # -ffp-contract=off is part of the numerical contract (svoxt_device.h): the
 # stepping arithmetic must not be fused into FMAs.

@@ -1080,119 +1080,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 }
             }
         }
-        // ---- sort: exclusive scan of the counters -- by wavefront 1, while wavefront 0 still advances
-        // the last round (the counters are complete since the round's barrier) -- then the
-        // counting sort of the record numbers
-        if (wave == 1) {
-            constexpr int PER = T / 64;
-            int mine[PER], sum = 0;
-#pragma unroll
-            for (int j2 = 0; j2 < PER; ++j2) { mine[j2] = cnt[lane * PER + j2]; sum += mine[j2]; }
-            int incl = sum;
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += v;
-            }
-            int run = incl - sum;
-#pragma unroll
-            for (int j2 = 0; j2 < PER; ++j2) { cnt[lane * PER + j2] = run; run += mine[j2]; }
-            if (lane == 63) s_nb = incl;
-        }
-        lds_barrier();       // (the phases of a pass hand over through LDS alone: the next round's request and the
-                             // gradient atomics stay in flight across their barriers)
-        const int nb = __builtin_amdgcn_readfirstlane(s_nb);
-        if constexpr (COUNT) {          // distinct feature rows of this pass = occupied table slots
-            unsigned long long rows = 0;
-            for (int i = threadIdx.x; i < T; i += NT) rows += keys[i] >= 0 ? 1u : 0u;
-            rows = wave_sum(rows);
-            if (lane == 0 && rows) atomicAdd(counters + 1, rows);
-        }
-        for (int rr = threadIdx.x; rr < R; rr += NT) {
-            const uint32_t v = r_sl[rr];
-            if (v != 0xffffffffu) order[atomicAdd(cnt + (v >> 6), 1)] = (uint16_t)rr;
-        }
-        lds_barrier();
-        // ---- reduce: 64 sorted records at a time per wavefront, the K columns in two rounds
-        // (0-15, 16-K: each atomic instruction of a row touches one 64-byte line of a row that
-        // starts on a 128-byte boundary)
-        for (int base = wave * 64; base < nb; base += NT) {
-            const int p = base + lane;
-            int my_sl = -1;
-            float w = 0.f, sgv = 0.f, cc[3] = {0.f, 0.f, 0.f}, gc[3] = {0.f, 0.f, 0.f};
-            float bx[NB > 0 ? NB : 1];
-            if (p < nb) {
-                const int rr = (int)order[p];
-                const int v = (int)r_sl[rr];
-                my_sl = v >> 6;
-                const int rl = v & 63;
-                sgv = r_sg[rr];
-#pragma unroll
-                for (int c3 = 0; c3 < C; ++c3) cc[c3] = r_c[c3 * R + rr];
-                if constexpr (FMT == FMT_SH) {
-                    w = r_w[rr];
-#pragma unroll
-                    for (int i = 0; i < NB; ++i) bx[i] = bases[rl * BDS + i];
-#pragma unroll
-                    for (int c3 = 0; c3 < C; ++c3) gc[c3] = gl[rl * 3 + c3];
-                }
-            }
-            seg[lane] = my_sl >= 0 ? keys[my_sl] : -1;          // the feature row staged row `lane` belongs to
-            const int grp = lane >> 4, sub = lane & 15;
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int c_lo = h2 * HALF;
-                const int ncol = (h2 == 0) ? HALF : K - HALF;
-                if (ncol > 0) {
-                    if (p < nb) {
-                        float* st = stage + lane * KS;
-#pragma unroll
-                        for (int j = 0; j < HALF; ++j) {
-                            const int col = c_lo + j;           // compile-time after unrolling
-                            if (col < K) {
-                                float val;
-                                if (col == K - 1) val = sgv;
-                                else if constexpr (FMT == FMT_SH) val = w * bx[col % (NB > 0 ? NB : 1)] * cc[col / (NB > 0 ? NB : 1)] * gc[col / (NB > 0 ? NB : 1)];
-                                else val = cc[col];
-                                st[j] = val;
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const bool has = sub < ncol;
-                    int cur = -1;
-                    float acc = 0.f;
-                    unsigned long long nreq = 0;
-                    int keyv[16];
-                    float xv[16];
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        const int row = grp * 16 + t;
-                        keyv[t] = seg[row];
-                        xv[t] = stage[row * KS + (has ? sub : 0)];
-                    }
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        const int key = keyv[t];
-                        if (key != cur) {
-                            if (cur >= 0 && has) atomicAdd(grad + (int64_t)cur * gstride + c_lo + sub, acc);
-                            if constexpr (COUNT) nreq += (cur >= 0 && sub == 0) ? 1u : 0u;
-                            acc = 0.f;
-                            cur = key;
-                        }
-                        acc += xv[t];
-                    }
-                    if (cur >= 0 && has) atomicAdd(grad + (int64_t)cur * gstride + c_lo + sub, acc);
-                    if constexpr (COUNT) {
-                        nreq += (cur >= 0 && sub == 0) ? 1u : 0u;
-                        nreq = wave_sum(nreq);
-                        if (lane == 0 && nreq) atomicAdd(counters, nreq);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
+#include "svoxt_tile_reduce.inc"
         if (k0 + RPP * P >= maxn) break;                 // last pass (scalar condition)
         lds_barrier();
         for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }

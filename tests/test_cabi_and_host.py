@@ -75,11 +75,16 @@ def test_no_kernel_keeps_private_arrays_in_scratch_memory():
         sc = int(r["ScratchSize [bytes/lane]"])
         if sc:
             worst[name] = sc
-    # today: grad_wide_kernel alone -- 7 registers (24 bytes) of the exact instances at their 80-register budget,
-    # 7-9 loop-invariant ones (shuffle lane indices, a pointer: written once in front of sweep 2) of the
-    # native-math instances at the 64 registers that let four workgroups share a CU
+    # today: grad_wide_kernel (12 bytes in the exact instances at their 80-register budget, 32-40 in the
+    # native-math ones at the 64 registers that let four workgroups share a CU: loop-invariant LDS addresses and
+    # pointers, written once in front of a sweep) and the COUNTING instances of grad_fused_kernel<SH9> (16-20 bytes;
+    # instrumentation).  Nothing above 48 bytes: the two GPU faults in this project's records both came with the
+    # first dispatch of a kernel that needed a much larger frame than anything before it (r02: 152 bytes, an
+    # experiment build; r03: 88 bytes, grad_fused_kernel<SH9> when its sort / reduce phase was a function with a
+    # dozen pointer parameters -- the same source as a textual include spills nothing).
     assert all(v <= 48 for v in worst.values()), worst
-    assert all("grad_wide_kernel" in k for k in worst), worst
+    assert all(("grad_wide_kernel" in k) or ("grad_fused_kernel" in k and k.split("grad_fused_kernel")[1].startswith("ILi1ELi9ELb")
+                                             and "ELb1ELi0E" in k) for k in worst), worst
 
 
 def test_out_data_dim():
