@@ -496,7 +496,7 @@ __device__ __forceinline__ void shade_tile_body(const TreeDev& tr, const RaysDev
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();       // (the rounds hand over through LDS alone: the hand-over stores to memory stay in flight)
     }
     if (wave == 0 && inb) {
         uint4 a = COH ? aux_get_coherent(aux + q) : aux[q];
