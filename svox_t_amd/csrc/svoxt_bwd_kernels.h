@@ -830,14 +830,14 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     // wavefront 0 only runs along the rays.  (r03: with P = W wavefront 0 also formed the terms of a position
     // and was every round's critical path -- its own terms, then the barrier, then the advance of the
     // round while the others already waited at the next barrier: 5 100 cycles per round of sweep 2.)
-    constexpr int C = 3, W = 8, P = W - 1, NT = 64 * W, T = 1024, R = 1024, RPP = 2;
-    static_assert(RPP * P * 64 <= R && P >= 1 && P <= W, "a pass must fit the record arrays");
+    constexpr int C = 3, W = 8, P = W - 1, NT = 64 * W, T = 1024, R = 1024;
+    static_assert(P * 64 <= R && P >= 1 && P <= W && R <= T, "a round must fit the record arrays, a pass the hash table");
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     constexpr int NB = (FMT == FMT_SH) ? BD : 0;
     constexpr int BDS = (FMT == FMT_SH) ? (BD | 1) : 1;
     constexpr int HALF = K < 16 ? K : 16;                    // columns 0-15 / 16-K: see grad_merge_kernel
     constexpr int KS = HALF | 1;                             // staging row: one round of columns
-    static_assert(K <= 32 && RPP == 2, "sizes");
+    static_assert(K <= 32, "sizes");
     __shared__ int32_t keys[T];
     __shared__ int32_t cnt[T];
     __shared__ uint16_t order[R];
@@ -893,7 +893,6 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         }
     }
     for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
-    for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
     if constexpr (EXACT) {
         // ---- sweep 1: pass 1 of the reference without its atomics (accum_sample), W positions per
         // round; r_w / r_sg carry (att, total_color) from the wavefront that formed them to wavefront 0,
@@ -992,6 +991,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     }
     __syncthreads();
 
+    // ---- sweep 2 (rt_kernel.cu:439-494 + the colour entries :410-425).
     // this wavefront's record (and hand-over) of the NEXT round, requested a round ahead: rounds follow each
     // other at k + P across the passes' boundaries as well
     constexpr bool PRE = EXACT && TERMS != 0;
@@ -1005,86 +1005,122 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     if constexpr (PRE) {
         if (pw >= 0 && pw < maxn) request(pw);
     }
-    for (int k0 = 0; k0 < maxn; k0 += RPP * P) {
-        // ---- terms + advance, RPP rounds of P list positions (unrolled: the two rounds take turns with the two
-        // register sets of the prefetch -- rolled up, the set just loaded is moved into the loop-carried one at the
-        // end of every round, which waits for the load there)
+    // (r03) A PASS is as many rounds as fit the record arrays, its records compact: the slot of (position k, ray l)
+    // is the number of records of the pass in front of position k plus the number of rays below l that have
+    // position k -- both from the ballot "nrec > k", which every wavefront forms for itself (lane = ray in all
+    // of them).  With the fixed window of 14 positions the arrays were a third full on the headline workload
+    // (~300 of 896 slots: lists are ragged), i.e. three times the scans, sorts, table clears and barriers, and a
+    // feature row left the CU once per window instead of once per ~40 positions.
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    // one round: positions kb .. kb + P - 1 (kb uniform), records from slot `nslot` on; returns the round's records
+    auto round = [&](int kb, int nslot) -> int {
+        int basep[P], total = 0;                                 // slots in front of position kb + j within the round
+        unsigned long long maskp[P];
 #pragma unroll
-        for (int rd = 0; rd < RPP; ++rd) {
-            const int kb = k0 + rd * P;                      // the same in every wavefront
-            if (kb >= maxn) break;
-            const int k = kb + pw;
-            const int slot = (rd * P + pw) * 64 + lane;
-            uint2 e = e_next;
-            const float4 tv_pre = t2_next;
-            if constexpr (PRE) {
-                if (pw >= 0 && k + P < maxn) request(k + P);      // (scalar conditions, every lane loads: see sweep 1)
-            }
-            if (pw >= 0 && k < nrec) {
-                const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
-                if constexpr (!PRE) e = rec_get(L.rec + rec_index_in(blk, lane, k));
-                float att, tc, cf[C];
-                if constexpr (EXACT && TERMS != 0) {
-                    const float4 tv = tv_pre;
-                    const float ex[C] = {tv.y, tv.z, tv.w};
-                    att = tv.x;
-                    tc = 0.f;
+        for (int j = 0; j < P; ++j) {
+            maskp[j] = __ballot(nrec > kb + j);
+            basep[j] = total;
+            total += (int)__popcll(maskp[j]);
+        }
+        const int k = kb + pw;
+        uint2 e = e_next;
+        const float4 tv_pre = t2_next;
+        if constexpr (PRE) {
+            if (pw >= 0 && k + P < maxn) request(k + P);          // (scalar conditions, every lane loads: see sweep 1)
+        }
+        if (pw >= 0 && k < nrec) {
+            int myb = 0;
+            unsigned long long mym = 0ull;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) {             // sample_terms from here on, operation for operation
-                        const double sd = 1.0 / (1.0 + (double)ex[c]);
-                        if constexpr (FMT == FMT_SH) {
-                            const float sig = (float)sd;
-                            cf[c] = (float)((double)sig * (1.0 - (double)sig));
-                        } else {
-                            cf[c] = (float)sd;
-                        }
-                        tc = (float)((double)tc + sd * (double)g[c]);
+            for (int j = 0; j < P; ++j) { if (j == pw) { myb = basep[j]; mym = maskp[j]; } }      // (pw is scalar)
+            const int slot = nslot + myb + (int)__popcll(mym & lane_lt);
+            const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
+            if constexpr (!PRE) e = rec_get(L.rec + rec_index_in(blk, lane, k));
+            float att, tc, cf[C];
+            if constexpr (EXACT && TERMS != 0) {
+                const float4 tv = tv_pre;
+                const float ex[C] = {tv.y, tv.z, tv.w};
+                att = tv.x;
+                tc = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {                     // sample_terms from here on, operation for operation
+                    const double sd = 1.0 / (1.0 + (double)ex[c]);
+                    if constexpr (FMT == FMT_SH) {
+                        const float sig = (float)sd;
+                        cf[c] = (float)((double)sig * (1.0 - (double)sig));
+                    } else {
+                        cf[c] = (float)sd;
                     }
-                } else {
-                    float row[K];
-                    load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
-                    sample_terms<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, att, tc, cf);
+                    tc = (float)((double)tc + sd * (double)g[c]);
                 }
-                const int32_t idx = (int32_t)e.x;
-                uint32_t h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
-                while (true) {
-                    const int32_t old = atomicCAS(keys + h, -1, idx);
-                    if (old == -1 || old == idx) break;
-                    h = (h + 1u) & (uint32_t)(T - 1);
-                }
-                atomicAdd(cnt + h, 1);
-                r_sl[slot] = (h << 6) | (uint32_t)lane;
-                r_w[slot] = att; r_sg[slot] = tc; r_dt[slot] = __uint_as_float(e.y);
-                r_c[slot] = cf[0]; r_c[R + slot] = cf[1]; r_c[2 * R + slot] = cf[2];
+            } else {
+                float row[K];
+                load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
+                sample_terms<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, att, tc, cf);
             }
-            if constexpr (PRE) lds_barrier();
-            else __syncthreads();
-            if (wave == 0) {
-                float av[P], tv[P], dv[P];
+            const int32_t idx = (int32_t)e.x;
+            uint32_t h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
+            while (true) {
+                const int32_t old = atomicCAS(keys + h, -1, idx);
+                if (old == -1 || old == idx) break;
+                h = (h + 1u) & (uint32_t)(T - 1);
+            }
+            atomicAdd(cnt + h, 1);
+            r_sl[slot] = (h << 6) | (uint32_t)lane;
+            r_w[slot] = att; r_sg[slot] = tc; r_dt[slot] = __uint_as_float(e.y);
+            r_c[slot] = cf[0]; r_c[R + slot] = cf[1]; r_c[2 * R + slot] = cf[2];
+        }
+        if constexpr (PRE) lds_barrier();
+        else __syncthreads();
+        if (wave == 0) {
+            float av[P], tv[P], dv[P];
+            int sl[P];
 #pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    const int s2 = (rd * P + j) * 64 + lane;
-                    av[j] = r_w[s2]; tv[j] = r_sg[s2]; dv[j] = r_dt[s2];
-                }
+            for (int j = 0; j < P; ++j) {
+                sl[j] = nslot + basep[j] + (int)__popcll(maskp[j] & lane_lt);
+                av[j] = 1.f; tv[j] = 0.f; dv[j] = 0.f;
+                if (kb + j < nrec) { av[j] = r_w[sl[j]]; tv[j] = r_sg[sl[j]]; dv[j] = r_dt[sl[j]]; }
+            }
 #pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    if (kb + j < nrec) {
-                        const int s2 = (rd * P + j) * 64 + lane;
-                        float cf[C] = {0.f, 0.f, 0.f};
-                        if constexpr (FMT == FMT_RGBA) { cf[0] = r_c[s2]; cf[1] = r_c[R + s2]; cf[2] = r_c[2 * R + s2]; }
-                        float wgt, sg;
-                        sample_advance<FMT, C>(av[j], tv[j], cf, g, dv[j], r.delta_scale, light_ray, light, accum, wgt, sg);
-                        r_w[s2] = wgt; r_sg[s2] = sg;
-                        if constexpr (FMT == FMT_RGBA) { r_c[s2] = cf[0]; r_c[R + s2] = cf[1]; r_c[2 * R + s2] = cf[2]; }
-                    }
+            for (int j = 0; j < P; ++j) {
+                if (kb + j < nrec) {
+                    const int s2 = sl[j];
+                    float cf[C] = {0.f, 0.f, 0.f};
+                    if constexpr (FMT == FMT_RGBA) { cf[0] = r_c[s2]; cf[1] = r_c[R + s2]; cf[2] = r_c[2 * R + s2]; }
+                    float wgt, sg;
+                    sample_advance<FMT, C>(av[j], tv[j], cf, g, dv[j], r.delta_scale, light_ray, light, accum, wgt, sg);
+                    r_w[s2] = wgt; r_sg[s2] = sg;
+                    if constexpr (FMT == FMT_RGBA) { r_c[s2] = cf[0]; r_c[R + s2] = cf[1]; r_c[2 * R + s2] = cf[2]; }
                 }
             }
         }
+        return total;
+    };
+    // records of the round that starts at position kb (scalar)
+    auto round_records = [&](int kb) {
+        int n = 0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) n += (int)__popcll(__ballot(nrec > kb + j));
+        return n;
+    };
+    int kb = 0;
+    while (kb < maxn) {
+        // ---- terms + advance: rounds of P list positions while the next one still fits (two per trip: the two
+        // register sets of the prefetch take turns, see sweep 1)
+        int npass = 0;                                           // records of this pass
+        while (true) {
+            npass += round(kb, npass);
+            kb += P;
+            if (kb >= maxn || npass + round_records(kb) > R) break;
+            npass += round(kb, npass);
+            kb += P;
+            if (kb >= maxn || npass + round_records(kb) > R) break;
+        }
+        const int nscan = npass;                                 // (svoxt_tile_reduce.inc: the slots in use are 0 .. nscan - 1)
 #include "svoxt_tile_reduce.inc"
-        if (k0 + RPP * P >= maxn) break;                 // last pass (scalar condition)
+        if (kb >= maxn) break;                                   // last pass (scalar condition)
         lds_barrier();
         for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
-        for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
         lds_barrier();
     }
 }
@@ -1118,6 +1154,9 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 // COUNT (instrumentation, svoxt_set_bwd_counters): counters[0] += 64-byte atomic requests sent (a row of
 // K floats that starts on a K * 4-byte boundary: two for K = 32, one for K = 16 / 8), counters[1] +=
 // (tile, window, feature row) groups.
+// (r03: every barrier of this kernel is lds_barrier() -- its phases hand over through LDS alone, the hand-over
+// between the sweeps through memory is written and read by the same lane -- so the gradient atomics and the
+// hand-over stores stay in flight across them.)
 template <int K, bool FAST = false, bool COUNT = false>
 __global__ void __launch_bounds__(512, FAST ? 8 : 6)
 grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
@@ -1164,7 +1203,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
         for (int j = 0; j < C; ++j) gl[lane * KG + j] = nrec > 0 ? grad_out[q * K + j] : 0.f;
     }
     if (threadIdx.x == 0) { s_nb = 0; s_ns = 0; }
-    __syncthreads();
+    lds_barrier();
 
     // ---- sweep 1
     float light1 = 1.f, accum = 0.f, light_ray = 1.f;
@@ -1196,7 +1235,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         const int nb1 = __builtin_amdgcn_readfirstlane(s_nb);
         // G = K / 8 neighbouring lanes per record, 8 row columns each: four times the busy lanes and a
         // quarter of the dependent work per lane (a window holds a few hundred records for 512 lanes);
@@ -1270,7 +1309,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
             }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (threadIdx.x == 0) s_nb = 0;
         // along the rays (wavefront 0); everybody: the hand-over, 256 contiguous bytes per position
 #pragma unroll 1
@@ -1299,7 +1338,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (wave == 0) {
         if (a.x & kRecOverflow) {                            // list + tail: from the tail-only launch in front
@@ -1318,7 +1357,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
     float light = 1.f;
     for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
     for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
-    __syncthreads();
+    lds_barrier();
     for (int k0 = 0; k0 < maxn; k0 += RPP * W) {
         {   // the window's two rounds together: records and hand-over first, then the sigma gathers, then the table
             uint2 e[RPP];
@@ -1355,7 +1394,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (wave == 0) {                                     // along the rays: (att, total_color) -> (weight, sigma entry)
 #pragma unroll
             for (int j0 = 0; j0 < RPP * W; j0 += 8) {        // eight positions' operands at a time
@@ -1397,7 +1436,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
             }
             if (lane == 63) { s_nb = incl; s_ns = uincl; }
         }
-        __syncthreads();
+        lds_barrier();
         for (int rr = threadIdx.x; rr < R; rr += NT) {
             const uint32_t v = r_sl[rr];
             if (v != 0xffffffffu) {
@@ -1407,7 +1446,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                 s_ray[pos] = (uint8_t)(v & 63u);
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- reduce: lane = column; after the scatter cnt[h] is where the records of entry h END
         const int ns = __builtin_amdgcn_readfirstlane(s_ns);
         if constexpr (COUNT) {
@@ -1461,10 +1500,10 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
             }
         }
         if (k0 + RPP * W >= maxn) break;                     // last window (scalar condition)
-        __syncthreads();
+        lds_barrier();
         for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
         for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
-        __syncthreads();
+        lds_barrier();
     }
 }
 
