@@ -399,7 +399,8 @@ march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
                  const uint32_t* __restrict__ sigma_mask = nullptr) {
     __shared__ uint2 rstage[kRecBlock * kBlock];
     __shared__ int32_t ltab[kMaxRecBlocks];
-    march_rec_tile<N2, STOP, ACC, MASK>(tr, rays, opt, L, aux, sigma_mask, (int64_t)blockIdx.x + rays.tile0, rstage, ltab);
+    const int64_t tile = (int64_t)blockIdx.x + rays.tile0;
+    march_rec_tile<N2, STOP, ACC, MASK>(tr, rays, opt, L, aux, sigma_mask, tile, rstage, ltab);
 }
 
 // WTERMS (recording forwards, no view rotations): the wavefronts that form a sample's exponentials also
@@ -571,6 +572,37 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
 constexpr int kRolePolls = 20000;
 constexpr int kRoleXcds = 8;
 __host__ __device__ inline int64_t roles_state_words(int64_t tiles) { return tiles + 16 * 32 + (int64_t)kRoleXcds * tiles; }
+__device__ __forceinline__ int my_xcc() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (kRoleXcds - 1)); }   // HW_REG_XCC_ID, bits 3:0
+
+// The marching wavefront's side: every store of the wavefront (records, block table, aux) acknowledged by the L2
+// first, then a position from the queue's tail counter and the tile id into that entry.
+__device__ __forceinline__ void publish_tile(int32_t* __restrict__ tile_state, int ntiles, int64_t tile) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    if ((threadIdx.x & 63) == 0) {
+        const int xcc = my_xcc();
+        int32_t* ctr = tile_state + ntiles + xcc * 32;
+        int32_t* queue = tile_state + ntiles + 16 * 32 + (int64_t)xcc * ntiles;
+        const int pos = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        __hip_atomic_store(queue + pos, (int32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// The shading workgroup's side (thread 0): the next tile of the queue of the XCD it runs on, or -1.
+__device__ __forceinline__ int32_t pop_tile(int32_t* __restrict__ tile_state, int ntiles) {
+    const int xcc = my_xcc();
+    int32_t* ctr = tile_state + ntiles + xcc * 32;
+    int32_t* queue = tile_state + ntiles + 16 * 32 + (int64_t)xcc * ntiles;
+    int32_t tile = -1;
+    const int idx = __hip_atomic_fetch_add(ctr + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    if (idx < ntiles) {
+        for (int p = 0; p < kRolePolls; ++p) {
+            tile = __hip_atomic_load(queue + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tile != -1) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    return tile;
+}
 
 template <int FMT, int BD, int ACC, bool WTERMS>
 __global__ void __launch_bounds__(512)
@@ -581,8 +613,6 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
     __shared__ __attribute__((aligned(16))) unsigned char lds[kMarchBytes > kShadeBytes ? kMarchBytes : kShadeBytes];
     __shared__ int s_tile;
     const int wave = threadIdx.x >> 6;
-    // (the queue addresses are formed where they are used, behind the march: nothing of them lives across it)
-    auto my_xcc = []() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (kRoleXcds - 1)); };   // HW_REG_XCC_ID, bits 3:0
     if ((int)blockIdx.x < n_march) {
         const int64_t tile = (int64_t)blockIdx.x * 8 + wave;
         if (tile >= ntiles) return;
@@ -592,16 +622,7 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
         // instructions per crossing go ahead of the shading wavefronts' many (issue priority 3 of 0..3)
         __builtin_amdgcn_s_setprio(3);
         march_rec_tile<true, false, ACC, true>(tr, rays, opt, L, aux, sigma_mask, tile, rstage, ltab);
-        // publish: every store of this wavefront (records, block table, aux) acknowledged by the L2 first
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-        if ((threadIdx.x & 63) == 0) {
-            const int xcc = my_xcc();
-            int32_t* ctr = tile_state + ntiles + xcc * 32;
-            int32_t* queue = tile_state + ntiles + 16 * 32 + (int64_t)xcc * ntiles;
-            const int pos = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-            __hip_atomic_store(queue + pos, (int32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        publish_tile(tile_state, ntiles, tile);      // (the queue addresses are formed behind the march: nothing of them lives across it)
         return;
     }
     // is this shading workgroup one of those its XCD needs?  (see above; the same in every wavefront)
@@ -610,21 +631,7 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
     int mine = a < G ? 8 * ((G - a + 7) >> 3) : 0;
     if (((G - 1) & 7) == a) mine -= 8 * G - ntiles;              // the last march workgroup may be partial
     if (b >= mine) return;
-    if (threadIdx.x == 0) {
-        int32_t tile = -1;
-        const int xcc = my_xcc();
-        int32_t* ctr = tile_state + ntiles + xcc * 32;
-        int32_t* queue = tile_state + ntiles + 16 * 32 + (int64_t)xcc * ntiles;
-        const int idx = __hip_atomic_fetch_add(ctr + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-        if (idx < ntiles) {
-            for (int p = 0; p < kRolePolls; ++p) {
-                tile = __hip_atomic_load(queue + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (tile != -1) break;
-                __builtin_amdgcn_s_sleep(16);
-            }
-        }
-        s_tile = tile;
-    }
+    if (threadIdx.x == 0) s_tile = pop_tile(tile_state, ntiles);
     __syncthreads();
     const int64_t tile = s_tile;
     if (tile < 0 || tile >= ntiles) return;                      // nothing arrived: left to the fallback launch
