@@ -15,4 +15,6 @@ def flat_source() -> str:
         inc = f'#include "{name}"\n'
         assert src.count(inc) == 1, name
         src = src.replace(inc, body)
+    for name in ("svoxt_tile_reduce.inc",):          # textual includes inside kernels
+        src = src.replace(f'#include "{name}"\n', open(os.path.join(CSRC, name)).read())
     return src

@@ -8,7 +8,7 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "svox_t_amd", "csrc")
 OUT = os.path.join(ROOT, "exp", "libsvoxt_trace.so")
-PHASES = ["setup", "sweep 1 (terms of 8 positions per round, wavefront 0 along the rays)",
+PHASES = ["setup", "sweep 1 (terms of 7 positions per round, wavefront 0 along the rays)",
           "sweep 2: terms + hash insert + advance", "sweep 2: wait for scan", "sweep 2: counting-sort scatter",
           "sweep 2: reduce (expand, stage, sum, atomics)", "sweep 2: table clear"]
 
@@ -29,17 +29,15 @@ def build():
     sub("    if (maxn == 0) return;                                   // the same in every wavefront of the workgroup\n",
         "    if (maxn == 0) return;\n    unsigned long long tprev_ = clock64();\n    if (threadIdx.x == 0) atomicAdd(&g_ph[7], 1ull);\n")
     sub("    if constexpr (EXACT) {\n        // ---- sweep 1", ph(0) + "    if constexpr (EXACT) {\n        // ---- sweep 1")
-    sub("    for (int k0 = 0; k0 < maxn; k0 += RPP * P) {\n        // ---- terms + advance",
-        ph(1) + "    for (int k0 = 0; k0 < maxn; k0 += RPP * P) {\n        // ---- terms + advance")
-    sub("        if (wave == 1) {\n            constexpr int PER = T / 64;", ph(2) + "        if (wave == 1) {\n            constexpr int PER = T / 64;")
-    sub("        const int nb = __builtin_amdgcn_readfirstlane(s_nb);",
-        ph(3) + "        const int nb = __builtin_amdgcn_readfirstlane(s_nb);")
-    sub("        lds_barrier();\n        // ---- reduce: 64 sorted records at a time per wavefront",
-        "        lds_barrier();\n" + ph(4) + "        // ---- reduce: 64 sorted records at a time per wavefront")
-    sub("        if (k0 + RPP * P >= maxn) break;                 // last pass (scalar condition)\n",
-        ph(5) + "        if (k0 + RPP * P >= maxn) break;\n")
-    sub("        for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;\n        lds_barrier();\n    }\n}",
-        "        for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;\n        lds_barrier();\n" + ph(6) + "    }\n}")
+    sub("    int kb = 0;\n    while (kb < maxn) {\n", ph(1) + "    int kb = 0;\n    while (kb < maxn) {\n")
+    sub("    if (wave == 1) {\n        constexpr int PER = T / 64;", ph(2) + "    if (wave == 1) {\n        constexpr int PER = T / 64;")
+    sub("    const int nb = __builtin_amdgcn_readfirstlane(s_nb);", ph(3) + "    const int nb = __builtin_amdgcn_readfirstlane(s_nb);")
+    sub("    lds_barrier();\n    // ---- reduce: 64 sorted records at a time per wavefront",
+        "    lds_barrier();\n" + ph(4) + "    // ---- reduce: 64 sorted records at a time per wavefront")
+    sub("        if (kb >= maxn) break;                                   // last pass (scalar condition)\n",
+        ph(5) + "        if (kb >= maxn) break;\n")
+    sub("        for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }\n        lds_barrier();\n    }\n}",
+        "        for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }\n        lds_barrier();\n" + ph(6) + "    }\n}")
     # the device array goes in front of the kernel's template line
     t = src.rindex("template <int FMT, int BD, bool EXACT, bool COUNT = false, int TERMS = 0>", 0, a)
     src = src[:t] + "__device__ unsigned long long g_ph[8];\n" + src[t:a] + body + src[b:]

@@ -903,26 +903,28 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         // traffic only (lds_barrier), so the request stays in flight across them: a round used to begin with
         // a load from memory that nothing overlapped -- 2 900 shader-clock cycles per round of sweep 1, 5 100
         // per round of sweep 2, most of it that latency (exp/trace_fused.py, r02).
-        float4 tv_next = make_float4(0.f, 0.f, 0.f, 0.f);
+        // D1 rounds ahead (the latency of a request under load is longer than a round), each of the D1 register
+        // sets refilled by the round that used it: the loop body is written out D1 times per trip so that no set is
+        // ever copied into another (a copy waits for the load it copies)
+        constexpr int D1 = 3;
+        float4 tq0 = make_float4(0.f, 0.f, 0.f, 0.f), tq1 = tq0, tq2 = tq0;
         auto terms_at = [&](int k) {
             const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
             return terms[TERMS == 2 ? terms_index(blk, lane, k) : terms_index_pm(blk, lane, k)];
         };
         if constexpr (TERMS >= 2) {
-            if (pw >= 0 && pw < maxn) tv_next = terms_at(pw);
+            tq0 = terms_at(min(max(pw, 0), maxn - 1));
+            tq1 = terms_at(min(max(pw, 0) + P, maxn - 1));
+            tq2 = terms_at(min(max(pw, 0) + 2 * P, maxn - 1));
         }
-#pragma unroll 2
-        for (int rd = 0; rd <= nr1; ++rd) {
+        auto round1 = [&](int rd, float4& tq) {
             const int k = rd * P + pw;
-            // The next round's request, by EVERY lane of the wavefront under SCALAR conditions: a lane whose list
-            // ends before k + P reads a stale slot of the same block and never looks at it (a load under a per-lane
+            // The request of round rd + D1, by EVERY lane of the wavefront under SCALAR conditions: a lane whose list
+            // ends before that position reads a stale slot of the same block and never looks at it (a load under a per-lane
             // condition comes with a merge of old and new value that waits for it on the spot); the block of
-            // position k + P exists iff some ray of the tile has that many records, and the block index handed to
+            // a position exists iff some ray of the tile has that many records, and the block index handed to
             // rec_block_u must be the same in all lanes.
-            float4 tv_cur = tv_next;
-            if constexpr (TERMS >= 2) {
-                if (pw >= 0 && rd < nr1 && k + P < maxn) tv_next = terms_at(k + P);
-            }
+            const float4 tv_cur = tq;
             if (pw >= 0 && rd < nr1 && k < nrec) {
                 const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
                 float att, ex[C];                             // exp(-x_c): sigmoid_d(x) = 1.0 / (1.0 + double(exp(-x)))
@@ -956,6 +958,9 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 const int sl = ((rd & 1) * P + pw) * 64 + lane;
                 r_w[sl] = att; r_sg[sl] = total_color;
             }
+            // (unconditional, at a clamped position, and behind the last use of the set it refills: no merge of old and
+            // new value, no second register set, no copy)
+            if constexpr (TERMS >= 2) tq = terms_at(min(max(k, 0) + D1 * P, maxn - 1));
             if (wave == 0 && rd > 0) {
                 // (the operands of the round's eight positions first, then what depends on the step before)
                 float av[P], tv[P];
@@ -975,6 +980,11 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             }
             if constexpr (TERMS >= 2) lds_barrier();         // (TERMS 1: this sweep's global stores are read by the next)
             else __syncthreads();
+        };
+        for (int rd = 0;;) {                                 // rounds 0 .. nr1 (the last one only advances)
+            round1(rd, tq0); if (++rd > nr1) break;
+            round1(rd, tq1); if (++rd > nr1) break;
+            round1(rd, tq2); if (++rd > nr1) break;
         }
         if (wave == 0) {
             if (a.x & kRecOverflow) {                        // list + tail: from the tail-only launch in front
