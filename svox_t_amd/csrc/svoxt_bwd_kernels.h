@@ -1005,15 +1005,19 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     // this wavefront's record (and hand-over) of the NEXT round, requested a round ahead: rounds follow each
     // other at k + P across the passes' boundaries as well
     constexpr bool PRE = EXACT && TERMS != 0;
-    uint2 e_next = make_uint2(0u, 0u);
-    float4 t2_next = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto request = [&](int k) {
+    // (two rounds ahead, two register sets that take turns, each refilled in place: see sweep 1)
+    constexpr int D2 = 2;
+    uint2 eq0 = make_uint2(0u, 0u), eq1 = eq0;
+    float4 uq0 = make_float4(0.f, 0.f, 0.f, 0.f), uq1 = uq0;
+    auto request = [&](int k, uint2& eq, float4& uq) {
+        k = min(max(k, 0), maxn - 1);                             // (a position some ray of the tile has: its block exists)
         const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
-        e_next = rec_get(L.rec + rec_index_in(blk, lane, k));
-        t2_next = terms[TERMS == 2 ? terms_index(blk, lane, k) : terms_index_pm(blk, lane, k)];
+        eq = rec_get(L.rec + rec_index_in(blk, lane, k));
+        uq = terms[TERMS == 2 ? terms_index(blk, lane, k) : terms_index_pm(blk, lane, k)];
     };
     if constexpr (PRE) {
-        if (pw >= 0 && pw < maxn) request(pw);
+        request(pw, eq0, uq0);
+        request(pw + P, eq1, uq1);
     }
     // (r03) A PASS is as many rounds as fit the record arrays, its records compact: the slot of (position k, ray l)
     // is the number of records of the pass in front of position k plus the number of rays below l that have
@@ -1023,7 +1027,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     // feature row left the CU once per window instead of once per ~40 positions.
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     // one round: positions kb .. kb + P - 1 (kb uniform), records from slot `nslot` on; returns the round's records
-    auto round = [&](int kb, int nslot) -> int {
+    auto round = [&](int kb, int nslot, uint2& eq, float4& uq) -> int {
         int basep[P], total = 0;                                 // slots in front of position kb + j within the round
         unsigned long long maskp[P];
 #pragma unroll
@@ -1033,11 +1037,8 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             total += (int)__popcll(maskp[j]);
         }
         const int k = kb + pw;
-        uint2 e = e_next;
-        const float4 tv_pre = t2_next;
-        if constexpr (PRE) {
-            if (pw >= 0 && k + P < maxn) request(k + P);          // (scalar conditions, every lane loads: see sweep 1)
-        }
+        uint2 e = eq;
+        const float4 tv_pre = uq;
         if (pw >= 0 && k < nrec) {
             int myb = 0;
             unsigned long long mym = 0ull;
@@ -1080,8 +1081,12 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             r_w[slot] = att; r_sg[slot] = tc; r_dt[slot] = __uint_as_float(e.y);
             r_c[slot] = cf[0]; r_c[R + slot] = cf[1]; r_c[2 * R + slot] = cf[2];
         }
-        if constexpr (PRE) lds_barrier();
-        else __syncthreads();
+        if constexpr (PRE) {
+            request(k + D2 * P, eq, uq);
+            lds_barrier();
+        } else {
+            __syncthreads();
+        }
         if (wave == 0) {
             float av[P], tv[P], dv[P];
             int sl[P];
@@ -1115,16 +1120,16 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     };
     int kb = 0;
     while (kb < maxn) {
-        // ---- terms + advance: rounds of P list positions while the next one still fits (two per trip: the two
-        // register sets of the prefetch take turns, see sweep 1)
+        // ---- terms + advance: rounds of P list positions, two at a time (the two register sets of the prefetch take
+        // turns and a pass is a whole number of such pairs: the second round of a tile's last pair may be empty), while
+        // the next pair still fits
         int npass = 0;                                           // records of this pass
         while (true) {
-            npass += round(kb, npass);
+            npass += round(kb, npass, eq0, uq0);
             kb += P;
-            if (kb >= maxn || npass + round_records(kb) > R) break;
-            npass += round(kb, npass);
+            npass += round(kb, npass, eq1, uq1);
             kb += P;
-            if (kb >= maxn || npass + round_records(kb) > R) break;
+            if (kb >= maxn || npass + round_records(kb) + round_records(kb + P) > R) break;
         }
         const int nscan = npass;                                 // (svoxt_tile_reduce.inc: the slots in use are 0 .. nscan - 1)
 #include "svoxt_tile_reduce.inc"
