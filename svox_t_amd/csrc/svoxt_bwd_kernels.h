@@ -856,8 +856,26 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     int32_t* seg = seg_all + wave * 64;
     const int32_t tabreg = rec_tab_reg(L, blockIdx.x, lane);
     const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * 64 + lane);
-    uint4 a = make_uint4(0u, 0u, 0u, 0u);
-    if (q < rays.Q) a = aux[q];
+    // (r03) What the tile needs of its rays is requested together with their list lengths, by every lane at a ray that
+    // exists -- the lengths decide who needs it, but a second and a third round trip to memory in front of the first
+    // round cost every tile with samples a tenth of its time (exp/trace_fused.py) -- and the table is cleared under it.
+    const bool in_batch = q < rays.Q;
+    const int64_t qc = in_batch ? q : 0;
+    const bool from_tensors = rays.c2w == nullptr;           // (scalar) else the rays come from the camera: arithmetic only
+    uint4 a = aux[qc];
+    float g[C + 1], dsrc[3] = {0.f, 0.f, 1.f}, vsrc[3] = {0.f, 0.f, 1.f};
+    if (from_tensors) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dsrc[j] = rays.dirs[3 * qc + j];
+        if constexpr (FMT == FMT_SH) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vsrc[j] = rays.vdirs[3 * qc + j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j <= C; ++j) g[j] = grad_out[qc * (C + 1) + j];
+    for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
+    if (!in_batch) a = make_uint4(0u, 0u, 0u, 0u);
     const int nrec = (int)(a.x & ~kRecOverflow);
     int maxn = nrec;
     for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
@@ -865,34 +883,35 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     if (maxn == 0) return;                                   // the same in every wavefront of the workgroup
 
     Ray r;
-    float basis[NB > 0 ? NB : 1], g[C + 1];
+    float basis[NB > 0 ? NB : 1];
     float accum = 0.f, light = 1.f;
     float light_ray = __uint_as_float(a.z);
     r.delta_scale = 0.f;
-#pragma unroll
-    for (int j = 0; j <= C; ++j) g[j] = 0.f;
-    if (nrec > 0) {
+    if (from_tensors) {
+        float dx, dy, dz;
+        r.delta_scale = dir_to_tree(tr, dsrc, dx, dy, dz);   // setup_ray's, from the direction already at hand
+        if constexpr (FMT == FMT_SH) precalc_basis<BD>(FMT_SH, BD, tr, vsrc[0], vsrc[1], vsrc[2], basis);
+    } else if (nrec > 0) {
         setup_ray(tr, rays, opt, q, r);                      // for delta_scale (a ray with samples hits the cube)
         if constexpr (FMT == FMT_SH) {
             float vd[3];
             load_vdir(rays, q, vd);
             precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
         }
-#pragma unroll
-        for (int j = 0; j <= C; ++j) g[j] = grad_out[q * (C + 1) + j];
-        if (wave == 0) {
-            if constexpr (!EXACT) {
+    }
+    if (wave == 0) {
+        if constexpr (!EXACT) {
+            if (nrec > 0) {
                 const float* o = fwd_out + q * (C + 1);      // see render_bwd_kernel: single march
 #pragma unroll
                 for (int c = 0; c < C; ++c) accum += g[c] * o[c];
             }
-#pragma unroll
-            for (int i = 0; i < NB; ++i) bases[lane * BDS + i] = basis[i];
-#pragma unroll
-            for (int c = 0; c < C; ++c) gl[lane * 3 + c] = g[c];
         }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) bases[lane * BDS + i] = basis[i];
+#pragma unroll
+        for (int c = 0; c < C; ++c) gl[lane * 3 + c] = g[c];
     }
-    for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
     if constexpr (EXACT) {
         // ---- sweep 1: pass 1 of the reference without its atomics (accum_sample), W positions per
         // round; r_w / r_sg carry (att, total_color) from the wavefront that formed them to wavefront 0,

@@ -150,6 +150,19 @@ __device__ __forceinline__ void load_vdir(const RaysDev& rays, int64_t q, float 
     }
 }
 
+// The direction part of the preamble: a world-space direction scaled into tree space and normalised
+// (common.cuh:45-51), and _get_delta_scale (rt_kernel.cu:188-199) = 1 / the scaled direction's length.
+__device__ __forceinline__ float dir_to_tree(const TreeDev& tr, const float d[3], float& dx, float& dy, float& dz) {
+    dx = d[0] * tr.scaling[0]; dy = d[1] * tr.scaling[1]; dz = d[2] * tr.scaling[2];
+    // sqrtf and `/` are the correctly rounded forms under hipcc's default
+    // -fhip-fp32-correctly-rounded-divide-sqrt (__fsqrt_rn is NOT: it maps to
+    // the native approximation unless OCML_BASIC_ROUNDED_OPERATIONS is set).
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float ds = 1.f / nrm;
+    dx *= ds; dy *= ds; dz *= ds;
+    return ds;
+}
+
 // Ray preamble: render_ray_kernel's transform (rt_kernel.cu:663-665,
 // common.cuh:45-51), _get_delta_scale (:188-199), invdir (:237, double) and
 // the cube slab test (:239-241).  Returns false when the ray misses the cube.
@@ -186,13 +199,8 @@ __device__ __forceinline__ bool setup_ray(const TreeDev& tr, const RaysDev& rays
     r.ox = f0 + s0 * o[0];
     r.oy = f1 + s1 * o[1];
     r.oz = f2 + s2 * o[2];
-    float dx = d[0] * s0, dy = d[1] * s1, dz = d[2] * s2;
-    // sqrtf and `/` are the correctly rounded forms under hipcc's default
-    // -fhip-fp32-correctly-rounded-divide-sqrt (__fsqrt_rn is NOT: it maps to
-    // the native approximation unless OCML_BASIC_ROUNDED_OPERATIONS is set).
-    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-    const float ds = 1.f / nrm;
-    dx *= ds; dy *= ds; dz *= ds;
+    float dx, dy, dz;
+    const float ds = dir_to_tree(tr, d, dx, dy, dz);
     r.dx = dx; r.dy = dy; r.dz = dz;
     r.delta_scale = ds;
     r.ix = (float)(1.0 / ((double)dx + 1e-9));
