@@ -381,15 +381,18 @@ def main():
             "backward_terms_written": 16 * A if (recording and forward_terms) else 0,
         }
         bwd_parts = None
+        kept_scratch = bool(_C.GRAD_SCRATCH and "render_bwd_kernel (marches" not in (route_bwd or ""))
         if not args.forward_only:
             bwd_parts = {
-                "grad_memset": 4 * M * stride, "upstream_gradient_read": 4 * (C + 1) * Q, "aux_read": 16 * Q,
+                # (the padded scratch kept between steps is left zeroed by the row compaction: no fill of its own)
+                "grad_memset": 0 if (kept_scratch and stride != K) else 4 * M * stride,
+                "upstream_gradient_read": 4 * (C + 1) * Q, "aux_read": 16 * Q,
                 "rays": 36 * cnt[0], "records_read": 8 * A,
                 # with the forward's hand-over the backward reads 16 B per sample instead of the feature rows
                 "feature_rows_read": 0 if forward_terms else 4 * K * touched["rows_composited"],
                 "terms_read": 16 * A if forward_terms else 0,
                 "atomic_requests_64B": 64 * atomic_requests if atomic_requests else 4 * K * A,
-                "row_compaction": (4 * M * stride + 4 * M * K) if stride != K else 0,
+                "row_compaction": (4 * M * stride + 4 * M * K + (4 * M * K if kept_scratch else 0)) if stride != K else 0,
             }
             if "grad_wide_kernel" in (route_bwd or "") or "ONEPASS" in (route_bwd or ""):
                 # sweep 1 -> sweep 2: (attenuation,) second-pass total_color per sample, written and read

@@ -21,7 +21,7 @@
  *   svoxt_accel_build / svoxt_accel_bytes            cached prefix of the root descent
  *   svoxt_ray_order                                  coherent order for ray batches that are not images
  *   svoxt_volume_render_fwd_record / _bwd_replay     backward without tree traversal
- *   svoxt_can_record, svoxt_bwd_workspace_bytes, svoxt_compact_rows, svoxt_count_fwd,
+ *   svoxt_can_record, svoxt_bwd_workspace_bytes, svoxt_compact_rows(_clear), svoxt_count_fwd,
  *   svoxt_query_leaves (the reference's mask compaction, made deterministic)
  *
  * Conventions
@@ -241,6 +241,12 @@ int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
 /*   SVOXT_LISTS_FWD_NO_OVERLAP   march and shade of the two-kernel forward as two launches even where lists.tile_state
  *                                would let one launch carry both (below).  Result-neutral. */
 #define SVOXT_LISTS_FWD_NO_OVERLAP 8
+/*   SVOXT_LISTS_GRAD_ZEROED      (read by svoxt_volume_render_bwd_replay) grad_features is all zeros on entry and the call
+ *                                need not fill it: the caller keeps a padded gradient scratch between steps and turns
+ *                                it into the dense [M, K] gradient with svoxt_compact_rows_clear, which leaves it zeroed
+ *                                again -- a fill of M * grad_stride floats per step less.  The caller answers for the
+ *                                zeros (a scratch a failed call may have left half written must be filled again). */
+#define SVOXT_LISTS_GRAD_ZEROED 16
 typedef struct svoxt_sample_lists {
     void*   rec;           /* device, 64-byte aligned, max_samples * ceil(Q / 64) * 64 * 8 bytes: record k of the
                               ray handled by launch thread t lives at rec[t / 64][k / 8][t % 64][k % 8] (8 bytes
@@ -327,6 +333,8 @@ int svoxt_volume_render_bwd_replay(const svoxt_tree* tree, const svoxt_rays* ray
 /* Copy the first K columns of src [M, stride] into dense dst [M, K] (streaming,
  * non-temporal): turns a strided gradient buffer into the reference's layout. */
 int svoxt_compact_rows(const float* src, int64_t M, int32_t K, int32_t stride, float* dst, void* stream);
+/* The same copy, and all of src [M, stride] is zero afterwards (SVOXT_LISTS_GRAD_ZEROED above). */
+int svoxt_compact_rows_clear(float* src, int64_t M, int32_t K, int32_t stride, float* dst, void* stream);
 
 /* out: device [Q, 1] = accumulated opacity (alpha). */
 int svoxt_opacity_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,

@@ -97,7 +97,7 @@ class _CLists(ctypes.Structure):         # struct svoxt_sample_lists
 
 
 # svoxt_sample_lists.flags (include/svoxt.h)
-LISTS_NATIVE_MATH, LISTS_FWD_ONE_KERNEL, LISTS_FWD_TWO_KERNELS, LISTS_FWD_NO_OVERLAP = 1, 2, 4, 8
+LISTS_NATIVE_MATH, LISTS_FWD_ONE_KERNEL, LISTS_FWD_TWO_KERNELS, LISTS_FWD_NO_OVERLAP, LISTS_GRAD_ZEROED = 1, 2, 4, 8, 16
 
 
 _P = ctypes.POINTER
@@ -119,6 +119,7 @@ EXPORTS = {
     "svoxt_sigma_mask_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "svoxt_sigma_mask_build": (ctypes.c_int, [_P(_CTree), ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "svoxt_compact_rows": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "svoxt_compact_rows_clear": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "svoxt_query_leaves_workspace_bytes": (ctypes.c_int64, [_i64]),
     "svoxt_query_leaves": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "svoxt_volume_render_fwd_record": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _P(_CLists), _vp]),
@@ -479,6 +480,27 @@ def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool) ->
     ct._keepalive_mask = mask
 
 
+# SVOXT_GRAD_SCRATCH=0: every backward over sample lists allocates and fills its padded gradient buffer itself.
+# Default: the padded [M, stride] buffer the atomics go to is kept between steps (per device, stream and shape)
+# and svoxt_compact_rows_clear leaves it zeroed while it produces the dense gradient: one fill of M * stride
+# floats per step less; result-neutral
+GRAD_SCRATCH = _env_flag("SVOXT_GRAD_SCRATCH", "1")
+_GRAD_SCRATCH: dict = {}      # (device, stream, M, stride) -> [buffer, known to be all zeros]
+
+
+def _grad_scratch(dev, M: int, stride: int):
+    key = (dev.index or 0, torch.cuda.current_stream(dev).cuda_stream, M, stride)
+    ent = _GRAD_SCRATCH.get(key)
+    if ent is None:
+        if len(_GRAD_SCRATCH) >= 2:
+            _GRAD_SCRATCH.clear()                     # (a tree that is refined changes M: no pile of old shapes)
+        ent = _GRAD_SCRATCH[key] = [torch.zeros((M, stride), dtype=torch.float32, device=dev), True]
+    elif not ent[1]:
+        ent[0].zero_()                                # a call that failed half way left it in an unknown state
+    ent[1] = False                                    # ... until svoxt_compact_rows_clear has been enqueued
+    return ent
+
+
 def invalidate_caches(*tensors) -> None:
     """Drop what this module derived from the CONTENT of the given tensors (child / data: the acceleration
     grid; features: a cached sigma bitmask) and bump their torch version counters.  For writers that bypass
@@ -486,6 +508,7 @@ def invalidate_caches(*tensors) -> None:
     if not tensors:
         _ACCEL_CACHE.clear()
         _SIGMA_CACHE.clear()
+        _GRAD_SCRATCH.clear()
         return
     ids = {id(t) for t in tensors if isinstance(t, torch.Tensor)}
     for k in [k for k, ent in _ACCEL_CACHE.items() if k in ids or id(ent[2]()) in ids]:
@@ -981,7 +1004,8 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
     gather = lists is not None and K <= 32 and grad_output.shape[1] == 4 and ct.N == 2 and \
         (BWD_GATHER == 2 or (BWD_GATHER == 1 and coherent))
     with torch.cuda.device(dev):
-        buf = torch.empty((M, stride), dtype=torch.float32, device=dev)
+        kept = _grad_scratch(dev, M, stride) if (GRAD_SCRATCH and lists is not None and stride != K and M > 0) else None
+        buf = kept[0] if kept is not None else torch.empty((M, stride), dtype=torch.float32, device=dev)
         if lists is not None:
             if lists.aux.shape[0] != cr.Q or lists.aux.device != dev:
                 raise RuntimeError("sample lists do not belong to this ray batch")
@@ -1024,6 +1048,8 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
                 "render_bwd_kernel<REPLAY> (list walk, one atomic row per sample)")
             if fused or wide_tile:
                 cl.coef_bytes = -1            # list walk and merge as one kernel: no buffer, rec stays as recorded
+            if kept is not None:
+                cl.flags |= LISTS_GRAD_ZEROED
             _call("svoxt_volume_render_bwd_replay", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(grad_output), grad_output.shape[1], _ptr(buf), stride, ctypes.byref(cl), _ptr(fo),
                   _stream(dev))
@@ -1037,7 +1063,11 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
             grad = buf
         else:
             grad = torch.empty((M, K), dtype=torch.float32, device=dev)
-            _call("svoxt_compact_rows", _ptr(buf), M, K, stride, _ptr(grad), _stream(dev))
+            if kept is not None:
+                _call("svoxt_compact_rows_clear", _ptr(buf), M, K, stride, _ptr(grad), _stream(dev))
+                kept[1] = True
+            else:
+                _call("svoxt_compact_rows", _ptr(buf), M, K, stride, _ptr(grad), _stream(dev))
     return grad
 
 

@@ -614,7 +614,8 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
     const int gs = grad_stride > 0 ? grad_stride : tree->K;
     if (gs < tree->K) return fail(SVOXT_ERR_INVALID, "%s: grad_stride smaller than data_dim", fn);
     hipStream_t st = (hipStream_t)stream;
-    if (tree->M > 0) {
+    // (SVOXT_LISTS_GRAD_ZEROED: the caller's buffer is the scratch svoxt_compact_rows_clear left zeroed)
+    if (tree->M > 0 && !(lists != nullptr && (lists->flags & SVOXT_LISTS_GRAD_ZEROED))) {
         const hipError_t e = hipMemsetAsync(grad_features, 0, sizeof(float) * (size_t)tree->M * gs, st);
         if (e != hipSuccess) return fail(SVOXT_ERR_HIP, "%s: hipMemsetAsync: %s", fn, hipGetErrorString(e));
     }
@@ -1124,19 +1125,36 @@ int svoxt_query_leaves(const uint8_t* hit_mask, int64_t n_slots, int32_t N, int6
     return check_launch(fn);
 }
 
+static int compact_rows(const float* src, float* src_clear, int64_t M, int32_t K, int32_t stride, float* dst, void* stream, const char* fn);
+
 int svoxt_compact_rows(const float* src, int64_t M, int32_t K, int32_t stride, float* dst, void* stream) {
-    const char* fn = "svoxt_compact_rows";
+    return compact_rows(src, nullptr, M, K, stride, dst, stream, "svoxt_compact_rows");
+}
+
+int svoxt_compact_rows_clear(float* src, int64_t M, int32_t K, int32_t stride, float* dst, void* stream) {
+    return compact_rows(src, src, M, K, stride, dst, stream, "svoxt_compact_rows_clear");
+}
+
+static int compact_rows(const float* src, float* src_clear, int64_t M, int32_t K, int32_t stride, float* dst, void* stream, const char* fn) {
     if (M < 0 || K < 1 || stride < K) return fail(SVOXT_ERR_INVALID, "%s: bad extents", fn);
     if (M == 0) return SVOXT_OK;
     if (src == nullptr || dst == nullptr) return fail(SVOXT_ERR_INVALID, "%s: src / dst is NULL", fn);
     typedef float v4f __attribute__((ext_vector_type(4)));
     const bool vec = K % 4 == 0 && stride % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0);
-    const int64_t n = vec ? M * (K / 4) : M * K;
+    const int64_t n = src_clear != nullptr ? (vec ? M * (stride / 4) : M * (int64_t)stride)       // (the clearing form covers the padded rows)
+                                           : (vec ? M * (K / 4) : M * K);
     const int64_t want = (n + kBlock - 1) / kBlock;
     const unsigned nb = (unsigned)(want < 16384 ? want : 16384);
-    if (vec)
+    if (src_clear != nullptr && src_clear == dst) return fail(SVOXT_ERR_INVALID, "%s: src and dst are the same buffer", fn);
+    if (vec && src_clear != nullptr)
+        hipLaunchKernelGGL((compact_rows_kernel<v4f, true>), dim3(nb), dim3(kBlock), 0, (hipStream_t)stream,
+                           reinterpret_cast<v4f*>(src_clear), n, (int)(K / 4), (int)(stride / 4), reinterpret_cast<v4f*>(dst));
+    else if (vec)
         hipLaunchKernelGGL((compact_rows_kernel<v4f>), dim3(nb), dim3(kBlock), 0, (hipStream_t)stream,
                            reinterpret_cast<const v4f*>(src), n, (int)(K / 4), (int)(stride / 4), reinterpret_cast<v4f*>(dst));
+    else if (src_clear != nullptr)
+        hipLaunchKernelGGL((compact_rows_kernel<float, true>), dim3(nb), dim3(kBlock), 0, (hipStream_t)stream,
+                           src_clear, n, (int)K, (int)stride, dst);
     else
         hipLaunchKernelGGL((compact_rows_kernel<float>), dim3(nb), dim3(kBlock), 0, (hipStream_t)stream,
                            src, n, (int)K, (int)stride, dst);

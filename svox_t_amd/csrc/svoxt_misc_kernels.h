@@ -2,6 +2,7 @@
 // depth, the roofline counters, point query and its unique-leaf compaction, row compaction, and the
 // acceleration-grid build.  See the file header of svoxt_kernels.hip.
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -435,13 +436,27 @@ leaves_scatter_kernel(const uint8_t* __restrict__ mask, int64_t n, int N, const 
 // ---------------------------------------------------------------------------
 
 // streaming copy: non-temporal both ways, the data is not re-read by these kernels
-template <typename V>
+// CLEAR (svoxt_compact_rows_clear): what was read is left zeroed -- the padded gradient scratch is then ready for the
+// next backward's atomics and that backward needs no fill of its own (the pad columns are never written by anyone)
+template <typename V, bool CLEAR = false>
 __global__ void __launch_bounds__(kBlock)
-compact_rows_kernel(const V* __restrict__ src, int64_t n, int Kv, int stride_v, V* __restrict__ dst) {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const int64_t r = i / Kv;
-        const int c = (int)(i - r * Kv);
-        __builtin_nontemporal_store(__builtin_nontemporal_load(src + r * stride_v + c), dst + i);
+compact_rows_kernel(typename std::conditional<CLEAR, V, const V>::type* __restrict__ src, int64_t n, int Kv, int stride_v,
+                    V* __restrict__ dst) {
+    if constexpr (CLEAR) {
+        // n = rows * stride_v here: the threads cover the PADDED rows, so that the zeros go out as whole lines (zeroing
+        // 112 of a row's 128 bytes leaves every second line a partial write: 57 us against 27 + 14 for copy + fill, r03)
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+            const int64_t r = i / stride_v;
+            const int c = (int)(i - r * stride_v);
+            if (c < Kv) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + r * Kv + c);
+            __builtin_nontemporal_store(V{}, src + i);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+            const int64_t r = i / Kv;
+            const int c = (int)(i - r * Kv);
+            __builtin_nontemporal_store(__builtin_nontemporal_load(src + r * stride_v + c), dst + i);
+        }
     }
 }
 

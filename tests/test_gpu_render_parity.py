@@ -193,6 +193,49 @@ def test_two_kernel_backward_and_repeated_backward(gpu, name, monkeypatch):
     assert_grads_close(tree.features.grad.cpu().numpy(), want, abs_sum)
 
 
+@pytest.mark.parametrize("name", ["d5_sh9", "d5_sh4_world"])
+def test_kept_gradient_scratch_changes_nothing(gpu, name, monkeypatch):
+    """The padded gradient buffer kept between steps (svoxt_compact_rows_clear leaves it zeroed, the next backward
+    skips its fill: SVOXT_LISTS_GRAD_ZEROED): step after step the gradient of a backward that fills its own buffer;
+    another upstream gradient in between leaves nothing behind; a scratch left dirty (a call that failed between the
+    atomics and the compaction) is filled again; a buffer of another shape gets its own scratch."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd import synth
+    c = Case(**CASES[name])
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    side = int(round(c.Q ** 0.5))
+    g = synth.grad_output(c.Q, 4).to(gpu)
+    want, abs_sum = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.cpu().numpy(), want_abs=True)
+
+    def step(gg):
+        tree.features.grad = None
+        r(tree.features, c.rays_gpu(gpu), image_shape=(side, side)).backward(gg)
+        return tree.features.grad.clone()
+
+    monkeypatch.setattr(_C, "GRAD_SCRATCH", False)
+    _C.invalidate_caches()
+    plain = step(g)
+    assert not _C._GRAD_SCRATCH
+    assert_grads_close(plain.cpu().numpy(), want, abs_sum)
+    monkeypatch.setattr(_C, "GRAD_SCRATCH", True)
+    scale = plain.abs().max().item()
+    for it in range(3):
+        if it == 1:
+            step(5.0 * g + 1.0)                                  # something else through the same scratch
+        got = step(g)
+        assert len(_C._GRAD_SCRATCH) == 1
+        (buf, clean), = _C._GRAD_SCRATCH.values()
+        assert clean and buf.shape[1] % 16 == 0 and not buf.any().item()        # left zeroed, pad columns included
+        assert (got - plain).abs().max().item() <= 1e-6 * scale                  # float atomics' order aside
+    ent = next(iter(_C._GRAD_SCRATCH.values()))
+    ent[0].fill_(3.0)
+    ent[1] = False                                               # as a failed call leaves it
+    assert (step(g) - plain).abs().max().item() <= 1e-6 * scale
+    _C.invalidate_caches()
+    assert not _C._GRAD_SCRATCH
+
+
 @pytest.mark.parametrize("shape", [(64, 64), (40, 72), (60, 64)])      # last: H not a multiple of 8 -> hint ignored
 def test_image_tile_hint_changes_nothing_but_the_lane_assignment(gpu, shape):
     H, W = shape
