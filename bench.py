@@ -432,7 +432,11 @@ def main():
             limits["forward"]["shade_kernel_ms"] = shade_ms
         if atomic_requests:
             limits["backward"] = {
-                "bound": "rate at which the memory side takes 64-byte float-atomic requests (exp/atomic_bench.hip: 22 G/s)",
+                "bound": "floor: the rate at which the memory side takes 64-byte float-atomic requests (exp/atomic_bench.hip: 22 G/s)"
+                         + (".  Not what binds the per-tile backward today: 15 % fewer requests (rows carried across the reduce's "
+                            "16-record groups) made it 6 % SLOWER, shorter instruction paths in the same reduce 3 % faster -- its phases "
+                            "are serial per workgroup and latency-bound (DESIGN.md steps 39-41)"
+                            if "grad_fused" in (route_bwd or "") else ""),
                 "atomic_requests": atomic_requests, "merged_rows": merged_rows,
                 "floor_ms": round(atomic_requests / ATOMIC_REQUESTS_PER_S * 1e3, 4), "measured_ms": round(bwd_ms, 4)}
         res = {
