@@ -43,6 +43,7 @@ stats d8_sh9_800
 bench d8_sh9_800
 bench d8_sh9_800_fwd --forward-only
 bench d8_sh9_800_camera --route camera --no-plain
+stats d8_sh9_800_plain --route plain
 SVOXT_BWD_EXACT=0 bench d8_sh9_800_single_march --no-plain
 SVOXT_LIST_POOL=0 bench d8_sh9_800_dense_lists --no-plain
 # configs[0]: the reference's own CPU-runnable case
