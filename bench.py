@@ -87,7 +87,7 @@ def pmc_traffic(workload, forward_only, group):
     try:
         with open(path) as f:
             counters = json.load(f)["counters"]
-        ks = {"forward": ("fwd", "march", "shade"), "backward": ("bwd", "fused", "merge", "wide", "compact")}[group]
+        ks = {"forward": ("fwd", "roles", "march", "shade"), "backward": ("bwd", "fused", "merge", "wide", "compact")}[group]
         fetch = sum(counters[k]["FETCH_SIZE"] for k in ks if k in counters) * 1024.0
         write = sum(counters[k]["WRITE_SIZE"] for k in ks if k in counters) * 1024.0
         if fetch + write == 0:
@@ -494,6 +494,12 @@ def main():
                 "reference_equivalent_gbps": round(dom_ref / (dom_ms * 1e-3) / 1e9, 2),
                 "reference_equivalent_note": "SURVEY.md 8(d): the bytes the REFERENCE's algorithm moves for the same result "
                                              "(a tree march per pass, 8 B per gradient float) / this kernel group's time",
+                # both kernel groups (the dominant one is whichever took longer in this run: at the headline config the
+                # two are within 2 % of each other and take turns)
+                "groups": {g: {"ms": round(ms_, 4), "compulsory_bytes": b_, "achieved": round(b_ / (ms_ * 1e-3) / 1e9, 2),
+                               "frac": round(b_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                               "traffic": (pmc_traffic(args.workload, args.forward_only, g)[0] if world == 1 else None)}
+                           for g, ms_, b_ in (("forward", fwd_ms, fwd_bytes), ("backward", bwd_ms, bwd_bytes)) if ms_ > 0.02 and b_ > 0},
             },
             "limits": limits,
         }
