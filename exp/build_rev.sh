@@ -1,0 +1,12 @@
+#!/bin/bash
+# exp/build_rev.sh REV [extra hipcc flags]: the library as of git revision REV -> exp/libsvoxt_REV.so (for A/B runs with SVOXT_LIB)
+set -e
+rev=$1; shift
+root=$(cd $(dirname $0)/.. && pwd)
+tmp=$(mktemp -d)
+git -C $root archive $rev svox_t_amd/csrc include | tar -x -C $tmp
+cd $tmp/svox_t_amd/csrc
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math "$@" \
+    -o $root/exp/libsvoxt_$rev.so svoxt_kernels.hip svoxt_build.hip svoxt_motion.hip svoxt_order.hip 2>&1 | grep -v hip-link || true
+rm -rf $tmp
+echo $root/exp/libsvoxt_$rev.so

@@ -307,9 +307,12 @@ constexpr uint32_t kAccelIdx = 0x07ffffffu;      // row / node bits; as a row: e
 template <bool MARK = false>
 __device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float py, float pz,
                                              Leaf& lf, int32_t& idx, uint8_t* mark = nullptr) {
-    px = fmaxf(0.f, fminf(kClampHi, px));
-    py = fmaxf(0.f, fminf(kClampHi, py));
-    pz = fmaxf(0.f, fminf(kClampHi, pz));
+    // (r03) the clamp as ONE median-of-three per axis: for every non-NaN p the value of fmaxf(0, fminf(hi, p))
+    // (a zero may come out with the other sign: p * 2^22 truncates to the same 0 and f - floor(f) is +0 either
+    // way); a NaN position cannot reach this point (no finite t makes one, and t = NaN ends the march).
+    px = __builtin_amdgcn_fmed3f(px, 0.f, kClampHi);
+    py = __builtin_amdgcn_fmed3f(py, 0.f, kClampHi);
+    pz = __builtin_amdgcn_fmed3f(pz, 0.f, kClampHi);
     const float S = (float)(1 << kFixBits);
     const uint32_t ux = (uint32_t)(px * S);
     const uint32_t uy = (uint32_t)(py * S);
@@ -323,8 +326,7 @@ __device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float 
     uint32_t slot = 0xffffffffu;
     if (cell & kAccelLeaf) {
         k = (int)((cell >> 27) & 15u);
-        const uint32_t row = cell & kAccelIdx;
-        idx = row == kAccelIdx ? 0x7fffffff : (int32_t)row;
+        idx = (int32_t)(cell & kAccelIdx);          // (an empty leaf's all-ones is no row of the table: M < 2^27 - 1 with a grid)
     } else {
         // below the grid: (child word, data word) pairs, so that reaching a leaf costs no
         // further dependent load for its data word
@@ -364,7 +366,8 @@ __device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float 
     const float sc = __int_as_float((127 + k) << 23);   // 2^k
     const float fx = px * sc, fy = py * sc, fz = pz * sc;
     lf.slot = slot;
-    lf.lx = fx - floorf(fx); lf.ly = fy - floorf(fy); lf.lz = fz - floorf(fz);
+    // f - floorf(f) for 0 <= f < 2^22 is exact and below 1: v_fract_f32 (= min(f - floor(f), 1 - 2^-24)) is that value
+    lf.lx = __builtin_amdgcn_fractf(fx); lf.ly = __builtin_amdgcn_fractf(fy); lf.lz = __builtin_amdgcn_fractf(fz);
     lf.cube_sz = sc;
     lf.levels = k;
 }
@@ -404,7 +407,9 @@ __device__ __forceinline__ void march_step(const TreeDev& tr, const Ray& r, floa
     // `*data_idx_ptr >= features.size(0)` compares int32 with int64 (:269); a
     // negative index is therefore "valid" for the reference (and reads out of
     // bounds).  Treat it as empty instead of faulting.
-    s.valid = s.idx >= 0 && (int64_t)s.idx < tr.M;
+    // (one unsigned compare: a negative index is a large unsigned one, and a table of 2^31 rows or more holds
+    // every non-negative int32)
+    s.valid = (uint32_t)s.idx < (tr.M > 0x7fffffffLL ? 0x80000000u : (uint32_t)tr.M);
     // _dda_unit on the leaf-local point (:273).  The point lies inside its leaf
     // (local coordinates in [0, 1)), so on every axis one of t1 = -c*inv and
     // t2 = t1 + inv is <= 0: the entry distance max(0, min...) is 0 and
@@ -598,6 +603,26 @@ __device__ __forceinline__ void rotated_sh_basis(const TreeDev& tr, int32_t idx,
     const float y = m[d] * vdir[0] + m[d + 1] * vdir[1] + m[d + 2] * vdir[2];
     const float z = m[2 * d] * vdir[0] + m[2 * d + 1] * vdir[1] + m[2 * d + 2] * vdir[2];
     precalc_basis<BD>(FMT_SH, BD, tr, x, y, z, basis);
+}
+
+// -(sum_i basis[i] * row[i]) for exp(-sum) (rt_kernel.cu:293-300), the products rounded one by one and added in
+// index order like the reference's `tmp += basis_fn[i] * tree_val[off + i]` from tmp = 0.  Two things about the
+// instruction stream (r03 ISA of the shade rounds): each product goes through an opaque register, which keeps the
+// compiler from pairing them into v_pk_mul_f32 -- the rows' channels start at odd floats, so every pair cost two
+// v_mov to line its operands up (4 packed multiplies + 8 moves where 8 multiplies do); and the sum starts from
+// the first product instead of 0 + product -- the same float unless the product is -0, and then the sums differ
+// in the sign of a zero at most, which exp() of the negated sum does not see (e^-0 = e^+0 = 1).
+template <int BD>
+__device__ __forceinline__ float neg_sh_dot(const float* __restrict__ basis, const float* __restrict__ row) {
+    float tmp = basis[0] * row[0];
+    asm("" : "+v"(tmp));
+#pragma unroll
+    for (int i = 1; i < BD; ++i) {
+        float pr = basis[i] * row[i];
+        asm("" : "+v"(pr));
+        tmp += pr;
+    }
+    return -tmp;
 }
 
 // The reference's `w / (1.0 + expf(-x))` family is evaluated in double

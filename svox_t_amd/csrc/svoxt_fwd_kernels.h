@@ -114,10 +114,7 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
             if constexpr (XF) rotated_sh_basis<BD>(tr, idx, vd, basis);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                float tmp = 0.f;
-#pragma unroll
-                for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
-                ex[c] = pexpf(-tmp);
+                ex[c] = pexpf(neg_sh_dot<BD>(basis, row + c * BD));
                 acc[c] = (float)((double)acc[c] + (double)weight / (1.0 + (double)ex[c]));
             }
         } else {
@@ -337,16 +334,25 @@ __device__ __forceinline__ void march_rec_tile(const TreeDev& tr, const RaysDev&
     // lane mask merged with scalar instructions at every branch: r02, 87 of the loop's 186
     // instructions per crossing were such mask arithmetic): "nothing pending" is sigma = -inf,
     // "stop marching" is t = +inf.
+    // MASK: what is in flight is the mask WORD of the crossing's row, and its bit is taken where the sample is
+    // looked at -- behind the next crossing's cell, which was requested after it.  (Taken where the word is
+    // requested, as r02 had it, the wavefront waits for the word before it can ask for the next cell: a second
+    // trip to memory in the chain of every crossing that has a leaf with data.)  "Nothing pending" is word 0.
     const float kNone = -__builtin_inff();
     float p_sigma = kNone, p_dt = 0.f, p_t = 0.f;
     int32_t p_idx = 0;
+    uint32_t p_word = 0u;
+    auto pending = [&]() -> bool {
+        if constexpr (MASK) return ((p_word >> (p_idx & 31)) & 1u) != 0u;
+        else return p_sigma > opt.sigma_thresh;
+    };
     while (t < r.tmax) {
         Sample s;
         march_step<N2, ACC>(tr, r, opt.step_size, t, s);
         const float t_cur = t;
         t = march_advance(t, s.delta_t);
         bool keep = true;
-        if (p_sigma > opt.sigma_thresh) {
+        if (pending()) {
             bool room = nrec < S;
             if (room && (nrec & 7) == 0) {
                 cur_block = rec_block_begin(L, ltab, tid >> 6, nrec >> 3);
@@ -367,15 +373,16 @@ __device__ __forceinline__ void march_rec_tile(const TreeDev& tr, const RaysDev&
             }
         }
         p_sigma = kNone;
+        p_word = 0u;
         if (keep && s.valid) {
-            if constexpr (MASK) p_sigma = ((sigma_mask[s.idx >> 5] >> (s.idx & 31)) & 1u) ? __builtin_inff() : kNone;
+            if constexpr (MASK) p_word = sigma_mask[s.idx >> 5];
             else p_sigma = sig_col[(int64_t)s.idx * K];
             p_idx = s.idx;
             p_dt = s.delta_t;
             p_t = t_cur;
         }
     }
-    if (p_sigma > opt.sigma_thresh) {    // the last crossing's sample
+    if (pending()) {    // the last crossing's sample
         bool room = nrec < S;
         if (room && (nrec & 7) == 0) {
             cur_block = rec_block_begin(L, ltab, tid >> 6, nrec >> 3);
@@ -463,10 +470,7 @@ __device__ __forceinline__ void shade_tile_body(const TreeDev& tr, const RaysDev
                     float ex[C];
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
-                        float tmp = 0.f;
-#pragma unroll
-                        for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
-                        ex[c] = pexpf(-tmp);
+                        ex[c] = pexpf(neg_sh_dot<BD>(basis, row + c * BD));
                     }
                     tv.y = ex[0]; tv.z = ex[1]; tv.w = ex[2];
                 } else {
