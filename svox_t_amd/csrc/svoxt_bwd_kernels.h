@@ -825,6 +825,7 @@ __global__ void __launch_bounds__(512, 4)
 grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                   RecLists L, const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
                   float* __restrict__ grad, int gstride, unsigned long long* __restrict__ counters = nullptr) {
+    if (tile_never_recorded(L, blockIdx.x)) return;          // (r03: before anything else is requested or cleared)
     float4* __restrict__ terms = L.terms;
     // P list positions per round, formed by wavefronts W - P .. W - 1 (pw = the wavefront's position in the round);
     // wavefront 0 only runs along the rays.  (r03: with P = W wavefront 0 also formed the terms of a position
@@ -1197,6 +1198,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                  RecLists L, const uint4* __restrict__ aux, float* __restrict__ grad, int gstride,
                  unsigned long long* __restrict__ counters = nullptr) {
     static_assert(K == 8 || K == 16 || K == 32, "row widths with an instance");
+    if (tile_never_recorded(L, blockIdx.x)) return;          // (r03: before anything else is requested)
     constexpr int C = K - 1, W = 8, NT = 64 * W, T = 1024, R = 1024, RPP = R / (64 * W);
     constexpr int KG = K | 1;                                // odd stride: conflict-free gradient rows
     constexpr int SPW = 64 / K;                              // distinct rows a wavefront reduces at a time

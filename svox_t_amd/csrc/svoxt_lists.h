@@ -119,6 +119,17 @@ __device__ __forceinline__ int64_t rec_block_u(const RecLists& L, int32_t tabreg
     if (L.tab == nullptr) return tile * (int64_t)(L.S >> 3) + b;
     return (int64_t)__builtin_amdgcn_readlane(tabreg, __builtin_amdgcn_readfirstlane(b));
 }
+// Pooled lists: a tile none of whose rays recorded a sample never took its first block -- entry 0 of its table is
+// still the -1 lists_begin left.  ONE scalar load (the address is the workgroup's) answers that before a kernel
+// that works per tile has requested anything else: on an 800 x 800 view of the depth-8 shell two tiles in three
+// are empty, and what their workgroups cost is what a per-tile kernel gets back (see fwd_roles_kernel).
+__device__ __forceinline__ bool tile_never_recorded(const RecLists& L, int64_t tile) {
+    if (L.tab == nullptr) return false;
+    const int32_t* p = L.tab + tile * (int64_t)(L.S >> 3);
+    int32_t b0;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b0) : "s"(p) : "memory");
+    return b0 == -1;
+}
 // The pool is cut into kSubPools equal parts with a counter each (64 bytes apart), chosen by the tile:
 // one counter for every hand-out was a single hot address -- 40 000 returning atomics per forward
 // of the headline workload, 0.25 -> 0.31 ms (r02).
