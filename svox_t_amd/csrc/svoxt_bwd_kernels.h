@@ -249,7 +249,9 @@ __device__ __forceinline__ void sample_advance(float att, float total_color, flo
 // contiguous bytes per wavefront and list position).  Sweep 2 is scalar work per listed sample --
 // sigma gather, attenuation, accum -= weight * total_color -- and one atomic on the sigma column.
 // Per-contribution values are the reference's; only where the additions happen differs.
-template <int FMT, int C, int BD, bool N2, bool REPLAY, bool XF = false, bool GATHER = false, bool ONEPASS = false>
+// LOBES (FMT_SH instances): the basis values are those of opt.format = SG or ASG with BD lobes (precalc_lobes).
+template <int FMT, int C, int BD, bool N2, bool REPLAY, bool XF = false, bool GATHER = false, bool ONEPASS = false,
+          bool LOBES = false>
 __global__ void __launch_bounds__(kBlock, (GATHER && !XF && C == 3) ? 4 : 1)
 render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                   float* __restrict__ grad, int gstride, RecLists L,
@@ -292,7 +294,8 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     if (alive) {
         if constexpr (FMT == FMT_SH) {
             load_vdir(rays, q, vd);
-            precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
+            if constexpr (LOBES) precalc_lobes<BD>(opt.format, tr, vd[0], vd[1], vd[2], basis);
+            else precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
         }
 #pragma unroll
         for (int j = 0; j <= C; ++j) g[j] = grad_out[q * (C + 1) + j];

@@ -32,11 +32,13 @@ __device__ __forceinline__ uint32_t leaf_slot(const TreeDev& tr, const Ray& r, f
 // list overflowed (aux[q].x bit 31) do anything; they pick up the compositing state the shade
 // kernel left in `out` (colour sums, transmittance in the alpha slot) and march on from
 // aux[q].y, then finalise the pixel and the recorded final transmittance.
-template <int FMT, int C, int BD, bool N2, bool REC, bool XF = false, bool RESUME = false>
+// LOBES (FMT_SH instances): the basis values are those of opt.format = SG or ASG with BD lobes (precalc_lobes).
+template <int FMT, int C, int BD, bool N2, bool REC, bool XF = false, bool RESUME = false, bool LOBES = false>
 __global__ void __launch_bounds__(kBlock)
 render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
                   RecLists L, uint4* __restrict__ aux) {
     static_assert(!XF || FMT == FMT_SH, "view rotations only matter for view-dependent formats");
+    static_assert(!LOBES || (FMT == FMT_SH && !XF), "lobes stand in for an SH basis");
     static_assert(!(RESUME && REC), "the tail launch does not record");
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     __shared__ uint2 rstage[REC ? kRecBlock * kBlock : 1];
@@ -72,7 +74,8 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
     float vd[3] = {0.f, 0.f, 0.f};
     if constexpr (FMT == FMT_SH) {
         load_vdir(rays, q, vd);
-        if constexpr (!XF) precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
+        if constexpr (LOBES) precalc_lobes<BD>(opt.format, tr, vd[0], vd[1], vd[2], basis);
+        else if constexpr (!XF) precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
     }
     float acc[C];
 #pragma unroll

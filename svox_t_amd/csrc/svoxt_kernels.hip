@@ -289,6 +289,23 @@ bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
             case 16: SVOXT_FWD(FMT_SH, 3, 16)
             case 25: SVOXT_FWD(FMT_SH, 3, 25)
         }
+    } else if constexpr (!REC) {
+        // SG / ASG payloads with 1 / 4 / 9 / 16 / 25 lobes and three channels (r03; they used to take the generic
+        // kernels): a ray's basis values are formed once (precalc_lobes) and used like an SH basis
+#define SVOXT_FWD_LOBES(BB)                                                                                     \
+    hipLaunchKernelGGL((render_fwd_kernel<FMT_SH, 3, BB, N2, false, false, false, true>), dim3(nb), dim3(kBlock), \
+                       0, st, tr, rays, opt, out, L, aux);                                                      \
+    return true;
+        if ((opt.format == FMT_SG || opt.format == FMT_ASG) && C == 3 && tr.K == 3 * opt.basis_dim + 1) {
+            switch (opt.basis_dim) {
+                case 1: SVOXT_FWD_LOBES(1)
+                case 4: SVOXT_FWD_LOBES(4)
+                case 9: SVOXT_FWD_LOBES(9)
+                case 16: SVOXT_FWD_LOBES(16)
+                case 25: SVOXT_FWD_LOBES(25)
+            }
+        }
+#undef SVOXT_FWD_LOBES
     }
 #undef SVOXT_FWD
     return false;
@@ -589,6 +606,21 @@ bool launch_bwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt,
             case 16: SVOXT_BWD(FMT_SH, 3, 16)
             case 25: SVOXT_BWD(FMT_SH, 3, 25)
         }
+    } else if constexpr (!REPLAY) {
+#define SVOXT_BWD_LOBES(BB)                                                                                        \
+    hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, N2, false, false, false, false, true>), dim3(nb), dim3(kBlock), \
+                       0, st, tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out);                            \
+    return true;
+        if ((opt.format == FMT_SG || opt.format == FMT_ASG) && C == 3 && tr.K == 3 * opt.basis_dim + 1) {
+            switch (opt.basis_dim) {
+                case 1: SVOXT_BWD_LOBES(1)
+                case 4: SVOXT_BWD_LOBES(4)
+                case 9: SVOXT_BWD_LOBES(9)
+                case 16: SVOXT_BWD_LOBES(16)
+                case 25: SVOXT_BWD_LOBES(25)
+            }
+        }
+#undef SVOXT_BWD_LOBES
     }
 #undef SVOXT_BWD
 #undef SVOXT_BWD1

@@ -159,6 +159,38 @@ def test_asg_format(gpu):
     np.testing.assert_allclose(O.basis(O.FORMAT_ASG, B, cs.vdirs.numpy()[:200], extra=lobes.numpy()), ref, rtol=2e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("kind,B", [("SG", 9), ("ASG", 4), ("SG", 25), ("ASG", 16), ("SG", 1)])
+def test_sg_asg_with_sh_sized_lobe_counts_take_the_register_kernels(gpu, kind, B):
+    """SG / ASG payloads with 1 / 4 / 9 / 16 / 25 lobes and three channels are served by the kernels that keep a ray's
+    basis values in registers (render_fwd_kernel / render_bwd_kernel<..., LOBES>, r03; other lobe counts stay with the
+    generic kernels: the two tests above): forward bit-exact against the oracle, gradient within its tolerance,
+    and a gradient that is not trivially zero."""
+    g = torch.Generator().manual_seed(40 + B)
+    if kind == "SG":
+        lobes = torch.cat([torch.rand(B, 1, generator=g) * 4 + 0.5,
+                           torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)], -1).contiguous()
+        fmt = O.FORMAT_SG
+    else:
+        frames = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0]
+        lobes = torch.cat([torch.rand(B, 2, generator=g) * 3 + 0.3, frames.reshape(B, 9)], -1).contiguous()
+        fmt = O.FORMAT_ASG
+    cs = Case(depth=4, K=3 * B + 1, data_format=f"{kind}{B}", width=40, height=40)
+    assert (cs.format, cs.basis_dim) == (fmt, B)
+    t = svox.N3Tree.from_arrays(cs.st.child, cs.st.data, cs.st.parent_depth, cs.features,
+                                data_format=f"{kind}{B}", extra_data=lobes, device=gpu)
+    rs = svox.VolumeRenderer(t)
+    f = t.features
+    out = rs(f, cs.rays_gpu(gpu))
+    ot = O.Tree(cs.features.numpy(), cs.st.data, cs.st.child, extra=lobes.numpy())
+    opt = O.make_options(format=fmt, basis_dim=B)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O.volume_render(ot, *cs.rays_np(), opt))
+    gout = synth.grad_output(cs.Q, 4)
+    out.backward(gout.to(gpu))
+    want, absum = O.volume_render_backward(ot, *cs.rays_np(), opt, gout.numpy(), want_abs=True)
+    assert_grads_close(f.grad.cpu().numpy(), want, absum)
+    assert np.abs(want[:, :-1]).max() > 0
+
+
 @pytest.mark.parametrize("Q", [0, 1, 63, 257])
 def test_ragged_and_empty_ray_batches(gpu, Q):
     c = Case(depth=4, K=4, data_format="RGBA", width=32, height=32)
