@@ -22,6 +22,8 @@ if kind == "SG":
 else:
     fr = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0]
     lobes = torch.cat([torch.rand(B, 2, generator=g) * 3 + 0.3, fr.reshape(B, 9)], -1).contiguous()
+if kind == "SH":                 # (for comparison: an SH payload of the same width)
+    lobes = None
 tree = svox.N3Tree.from_arrays(st.child, st.data, st.parent_depth, feats, data_format=f"{kind}{B}", extra_data=lobes, device=dev)
 r = svox.VolumeRenderer(tree)
 o, d, v = synth.pinhole_rays(W, H, c2w=synth.camera_pose(azimuth_deg=30.0))

@@ -1001,7 +1001,12 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
     # on shuffled rays it loses to the one-kernel backward (2.4 vs 1.65 ms)
     tiled = cr.image_width > 0 and cr.image_width % 8 == 0 and cr.image_height % 8 == 0
     coherent = tiled or bool(getattr(rays, "coherent", False))      # or sorted by svoxt_ray_order
-    gather = lists is not None and K <= 32 and grad_output.shape[1] == 4 and ct.N == 2 and \
+    # rows wider than 32 floats (SH16: 49, SH25: 76): per tile only as ONE kernel over the hand-over the recording
+    # forward left (lists.terms_state 2 / 3), exact arithmetic, no view rotations
+    wide_sh = K > 32 and lists is not None and co.format == FORMAT_SH and co.basis_dim in (16, 25) and \
+        K == 3 * co.basis_dim + 1 and lists.terms is not None and lists.terms_state in (2, 3) and \
+        BWD_EXACT and BWD_FUSED and BWD_TERMS and ct.xform is None
+    gather = lists is not None and (K <= 32 or wide_sh) and grad_output.shape[1] == 4 and ct.N == 2 and \
         (BWD_GATHER == 2 or (BWD_GATHER == 1 and coherent))
     with torch.cuda.device(dev):
         kept = _grad_scratch(dev, M, stride) if (GRAD_SCRATCH and lists is not None and stride != K and M > 0) else None

@@ -834,14 +834,20 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     // wavefront 0 only runs along the rays.  (r03: with P = W wavefront 0 also formed the terms of a position
     // and was every round's critical path -- its own terms, then the barrier, then the advance of the
     // round while the others already waited at the next barrier: 5 100 cycles per round of sweep 2.)
-    constexpr int C = 3, W = 8, P = W - 1, NT = 64 * W, T = 1024, R = 1024;
-    static_assert(P * 64 <= R && P >= 1 && P <= W && R <= T, "a round must fit the record arrays, a pass the hash table");
+    // (r03) Rows wider than 32 floats -- SH16: 49, SH25: 76 -- take this kernel too when the forward left the
+    // hand-over (TERMS 2 / 3): then neither sweep touches a feature row, the row's width only shows in the reduce
+    // (ceil(K / 16) rounds of 16 columns) and in the 64 rays' basis values in LDS (SH25: a pass holds 896 records
+    // -- one pair of rounds, the least a pass can be -- instead of 1024 so that two workgroups still share a CU's LDS).  800 x 800 / depth 8, forward+backward:
+    // SH16 2.02 -> see profiles/r03_lobes_timing.txt (per ray: 49 float atomics per sample).
+    constexpr int C = 3, W = 8, P = W - 1, NT = 64 * W, T = 1024, R = (FMT == FMT_SH && BD > 16) ? 896 : 1024;
+    static_assert(2 * P * 64 <= R && P >= 1 && P <= W && R <= T, "a pair of rounds must fit the record arrays, a pass the hash table");
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
     constexpr int NB = (FMT == FMT_SH) ? BD : 0;
     constexpr int BDS = (FMT == FMT_SH) ? (BD | 1) : 1;
-    constexpr int HALF = K < 16 ? K : 16;                    // columns 0-15 / 16-K: see grad_merge_kernel
+    constexpr int HALF = K < 16 ? K : 16;                    // columns 0-15 / 16-31 / ...: see grad_merge_kernel
+    constexpr int NH = (K + HALF - 1) / HALF;                // rounds of columns in the reduce
     constexpr int KS = HALF | 1;                             // staging row: one round of columns
-    static_assert(K <= 32, "sizes");
+    static_assert(K <= 32 || (EXACT && TERMS >= 2), "wide rows: only with the forward's hand-over (no row in registers)");
     __shared__ int32_t keys[T];
     __shared__ int32_t cnt[T];
     __shared__ uint16_t order[R];

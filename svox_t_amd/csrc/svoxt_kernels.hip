@@ -560,13 +560,32 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
         return false;
     }
     if (opt.format == FMT_RGBA) { SVOXT_GATHER(FMT_RGBA, 0) }
+    // SH16 / SH25 (rows of 49 / 76 floats, r03): the one-kernel per-tile form only, and only over the hand-over a
+    // recording forward left (terms_state 2 / 3): the kernel then never holds a feature row
+#define SVOXT_GATHER_WIDE(BB)                                                                                 \
+    {                                                                                                         \
+        if (!fused || g_bwd_counters != nullptr || fwd_out != nullptr || L.terms == nullptr ||                \
+            (terms_state != 2 && terms_state != 3)) return false;                                             \
+        hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
+                           tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out, (float4*)nullptr);        \
+        if (terms_state == 2)                                                                                 \
+            hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 2>), dim3(nb), dim3(512), 0, st,   \
+                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                      \
+        else                                                                                                  \
+            hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 3>), dim3(nb), dim3(512), 0, st,   \
+                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                      \
+        return true;                                                                                          \
+    }
     if (opt.format == FMT_SH) {
         switch (opt.basis_dim) {
             case 1: SVOXT_GATHER(FMT_SH, 1)
             case 4: SVOXT_GATHER(FMT_SH, 4)
             case 9: SVOXT_GATHER(FMT_SH, 9)
+            case 16: SVOXT_GATHER_WIDE(16)
+            case 25: SVOXT_GATHER_WIDE(25)
         }
     }
+#undef SVOXT_GATHER_WIDE
 #undef SVOXT_GATHER
 #undef SVOXT_GATHER_XF
     return false;
@@ -690,7 +709,8 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
             // coef_bytes < 0 (and no coef): the per-tile route if it can run fused, which needs no buffer
             const bool have_coef = lists->coef != nullptr &&
                                    lists->coef_bytes >= (int64_t)lists->max_samples * rays->Q * 16;
-            if (n2 && tree->K <= 32 && (have_coef || lists->coef_bytes < 0))
+            // (rows wider than 32 floats: SH16 / SH25 over the forward's hand-over, one kernel -- launch_bwd_gather decides)
+            if (n2 && (tree->K <= 32 || !have_coef) && (have_coef || lists->coef_bytes < 0))
                 // (ll.terms: the exact one-kernel form's hand-over buffer; terms_state 2 = the forward filled it)
                 done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, ll, laux,
                                          fwd_out, have_coef ? reinterpret_cast<float4*>(lists->coef) : nullptr, false, st,

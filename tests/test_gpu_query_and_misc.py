@@ -336,6 +336,23 @@ def test_config3_backward_full_size(cfg3, gpu):
     assert_grads_close(tree.features.grad.cpu().numpy(), 2 * want, 2 * absum)
 
 
+def test_sh25_backward_full_size(gpu):
+    """The headline geometry with rows of 76 floats (SH25): grad_fused_kernel over the forward's hand-over with
+    ceil(76 / 16) rounds of columns in its reduce and passes of 896 records -- dense tiles, whose first pair of
+    rounds fills 896 slots, are what a first version with 768 overran (r03; only full size has them)."""
+    c = Case(depth=8, K=76, data_format="SH25", width=800, height=800)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    out = r(tree.features, c.rays_gpu(gpu), image_shape=(800, 800))
+    gout = synth.grad_output(c.Q, 4)
+    out.backward(gout.to(gpu))
+    assert _C.LAST_ROUTE["backward"].startswith("grad_fused_kernel<EXACT>"), _C.LAST_ROUTE
+    got = tree.features.grad.cpu().numpy()
+    want, absum, tight = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), gout.numpy(), want_abs="both")
+    assert_grads_close(got, want, tight)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts()))
+
+
 def test_config3_backward_relative_error_both_routes(cfg3, gpu, monkeypatch, capsys):
     """What "1e-5 relative" holds for at full size, route by route.
 

@@ -193,6 +193,39 @@ def test_two_kernel_backward_and_repeated_backward(gpu, name, monkeypatch):
     assert_grads_close(tree.features.grad.cpu().numpy(), want, abs_sum)
 
 
+@pytest.mark.parametrize("fmt,K,depth,side", [("SH16", 49, 5, 64), ("SH25", 76, 5, 56), ("SH16", 49, 6, 96), ("SH25", 76, 6, 96)])
+def test_wide_sh_rows_take_the_per_tile_backward(gpu, fmt, K, depth, side, monkeypatch):
+    """SH16 / SH25 (rows of 49 / 76 floats) on image batches: grad_fused_kernel over the hand-over the recording
+    forward left (r03; per ray these rows cost 49 / 76 float atomics per sample) -- exact arithmetic: held to the
+    tight scale like the SH9 route; the same through the kept gradient scratch (stride 64 / 80 floats), and with
+    lists of 8 samples so that rays overflow into the tail-only launch."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd import synth
+    c = Case(depth=depth, K=K, data_format=fmt, width=side, height=side)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    g = synth.grad_output(c.Q, 4)
+    want, abs_sum, tight = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.numpy(), want_abs="both")
+    fwd_want = O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts())
+    for cap in (None, 8):
+        if cap is not None:
+            monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", cap)
+        for rep in range(2):                                   # (the second step runs over the kept scratch)
+            tree.features.grad = None
+            out = r(tree.features, c.rays_gpu(gpu), image_shape=(side, side))
+            np.testing.assert_array_equal(out.detach().cpu().numpy(), fwd_want)
+            out.backward(g.to(gpu))
+            assert _C.LAST_ROUTE["backward"].startswith("grad_fused_kernel<EXACT>"), _C.LAST_ROUTE
+            got = tree.features.grad.cpu().numpy()
+            assert_grads_close(got, want, tight)
+            assert np.all(got[abs_sum == 0] == 0)
+    # not declared an image: the per-ray backward, as before
+    tree.features.grad = None
+    r(tree.features, c.rays_gpu(gpu)).backward(g.to(gpu))
+    assert _C.LAST_ROUTE["backward"].startswith("render_bwd_kernel"), _C.LAST_ROUTE
+    assert_grads_close(tree.features.grad.cpu().numpy(), want, tight)
+
+
 @pytest.mark.parametrize("name", ["d5_sh9", "d5_sh4_world"])
 def test_kept_gradient_scratch_changes_nothing(gpu, name, monkeypatch):
     """The padded gradient buffer kept between steps (svoxt_compact_rows_clear leaves it zeroed, the next backward
