@@ -440,6 +440,7 @@ bool launch_fwd_roles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
                 case 1: SVOXT_ROLES(FMT_SH, 1)
                 case 4: SVOXT_ROLES(FMT_SH, 4)
                 case 9: SVOXT_ROLES(FMT_SH, 9)
+                case 16: SVOXT_ROLES(FMT_SH, 16)      // (r03: 0.833 -> 0.805 ms forward+backward; SH25, at 129 registers, loses: 1.139 -> 1.194)
             }
         }
 #undef SVOXT_ROLES
