@@ -20,14 +20,13 @@ def build():
         src = src.replace(old, new)
 
     # per-tile stamps, no shared counters (20 000 atomics on one address cost more than the kernel)
-    sub("template <int FMT, int BD, int ACC, bool WTERMS>\n__global__ void __launch_bounds__(512)\nfwd_roles_kernel(",
-        "__device__ unsigned long long g_rt[3 * 16384];\ntemplate <int FMT, int BD, int ACC, bool WTERMS>\n__global__ void __launch_bounds__(512)\nfwd_roles_kernel(")
-    sub("        march_rec_tile<true, false, ACC, true>(tr, rays, opt, L, aux, sigma_mask, tile, rstage, ltab);\n",
+    sub("constexpr int kRolePolls = 20000;\n", "constexpr int kRolePolls = 20000;\n__device__ unsigned long long g_rt[3 * 16384];\n")
+    sub("        const uint32_t ax = march_rec_tile<true, false, ACC, true>(tr, rays, opt, L, aux, sigma_mask, tile, rstage, ltab);\n",
         "        if ((threadIdx.x & 63) == 0 && tile < 16384) g_rt[tile] = wall_clock64();\n"
-        "        march_rec_tile<true, false, ACC, true>(tr, rays, opt, L, aux, sigma_mask, tile, rstage, ltab);\n")
-    sub("            __hip_atomic_store(queue + pos, (int32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n",
-        "            __hip_atomic_store(queue + pos, (int32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
-        "            if (tile < 16384) g_rt[16384 + tile] = wall_clock64();\n")
+        "        const uint32_t ax = march_rec_tile<true, false, ACC, true>(tr, rays, opt, L, aux, sigma_mask, tile, rstage, ltab);\n")
+    sub("        __hip_atomic_store(queue + pos, (int32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n",
+        "        __hip_atomic_store(queue + pos, (int32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+        "            if ((tile & 0xffff) < 16384) g_rt[16384 + (tile & 0xffff)] = wall_clock64();\n")
     sub("    if (threadIdx.x == 0) tile_state[tile] = kTileShaded;        // (read by the fallback launch: after this kernel)\n",
         "    if (threadIdx.x == 0) { tile_state[tile] = kTileShaded; if (tile < 16384) g_rt[2 * 16384 + tile] = wall_clock64(); }\n")
     if os.environ.get("RT_NOSHADE"):
@@ -83,14 +82,17 @@ def run():
     ms, me, se = (buf[i * 16384:i * 16384 + T].astype(np.float64) / 100.0 for i in range(3))    # us (100 MHz)
     t0 = ms.min()
     ms, me = ms - t0, me - t0
+    shaded = se > 0                        # (r03: a tile without samples is finished by its march and never shaded)
+    print(f"tiles shaded by a shading workgroup: {int(shaded.sum())} of {T}")
     print(_C.LAST_ROUTE["forward"])
     print(f"march starts: 50 % by {np.percentile(ms, 50):6.1f} us, 90 % by {np.percentile(ms, 90):6.1f}, last {ms.max():6.1f}")
     print(f"march ends  : 50 % by {np.percentile(me, 50):6.1f} us, 90 % by {np.percentile(me, 90):6.1f}, 99 % by {np.percentile(me, 99):6.1f}, last {me.max():6.1f}")
     dur = me - ms
     print(f"march duration: median {np.median(dur):6.1f} us, 99 % {np.percentile(dur, 99):6.1f}, longest {dur.max():6.1f} (started at {ms[dur.argmax()]:.1f})")
     if se.max() > 0:
-        se = se - t0
+        se, me = se[shaded] - t0, me[shaded]
         lag = se - me
+        print(f"marches of the shaded tiles end: 50 % by {np.percentile(me, 50):6.1f} us, 90 % by {np.percentile(me, 90):6.1f}, last {me.max():6.1f}")
         print(f"shade ends  : 50 % by {np.percentile(se, 50):6.1f} us, 90 % by {np.percentile(se, 90):6.1f}, last {se.max():6.1f}")
         print(f"march end -> shade end of the same tile: median {np.median(lag):6.1f} us, 90 % {np.percentile(lag, 90):6.1f}, max {lag.max():6.1f}; "
               f"the last-shaded tile's march ended at {me[se.argmax()]:.1f}")
