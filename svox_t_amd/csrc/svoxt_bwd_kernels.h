@@ -565,6 +565,7 @@ __global__ void __launch_bounds__(64 * W)
 grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, RecLists L,
                   const float4* __restrict__ coef, const uint4* __restrict__ aux,
                   float* __restrict__ grad, int gstride) {
+    if (tile_never_recorded(L, blockIdx.x)) return;          // (r03: see grad_fused_kernel)
     const int S = L.S;
     const int32_t tabreg = rec_tab_reg(L, blockIdx.x, threadIdx.x & 63);
     // W wavefronts share one tile (64 rays) and its LDS: the phases below are latency

@@ -145,6 +145,7 @@ opacity_merge_kernel(RaysDev rays, RecLists L, const uint4* __restrict__ aux,
     constexpr int NT = 64 * W;
     constexpr int kGroup = 2, kRound = kGroup * W, RPP = T / (64 * kRound);
     static_assert((T & (T - 1)) == 0 && RPP >= 1, "a pass of RPP rounds must fit the table");
+    if (tile_never_recorded(L, blockIdx.x)) return;          // (r03: see grad_fused_kernel)
     __shared__ int32_t keys[T];
     __shared__ float vals[T];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
