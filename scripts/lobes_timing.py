@@ -50,3 +50,5 @@ for name, fn in (("forward", fwd), ("forward+backward", both)):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
     print(f"{kind}{B} (K = {K}) 800x800 depth-8 {name}: {ms:.3f} ms = {W * H / ms / 1e3:.1f} Mrays/s", flush=True)
+import svox_t_amd.csrc as _C
+print("   routes:", _C.LAST_ROUTE.get("forward"), "|", _C.LAST_ROUTE.get("backward"), flush=True)
