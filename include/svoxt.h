@@ -219,7 +219,12 @@ int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
  * sigma_thresh == stop_thresh == 0 (the reference's backward ignores both) and
  * one of the specialised payloads (svoxt_can_record returns 1; with tree->xform
  * set: SH payloads on N = 2 trees); the lists are valid for the tree, features'
- * sign of sigma, rays and options they were recorded with. */
+ * sign of sigma, rays and options they were recorded with.
+ * svoxt_can_record returns 2 (r03) for SG / ASG payloads with 1 / 4 / 9 / 16 / 25 lobes and three channels on
+ * N = 2 trees: their lists are recorded only TOGETHER WITH the exact per-tile backward's hand-over (lists.terms
+ * given; svoxt_fwd_fills_terms says 3) and serve that backward alone (svoxt_volume_render_bwd_replay with
+ * coef_bytes < 0, terms_state 3, fwd_out NULL); any other combination is SVOXT_ERR_UNSUPPORTED -- call the
+ * marching svoxt_volume_render_bwd instead. */
 /* svoxt_sample_lists.flags (ABI v16): how the kernels that write and read these lists work.
  *   SVOXT_LISTS_NATIVE_MATH      opt-in TOLERANCE mode for RGBA-style rows of 8 / 16 / 32 floats (= the `flags`
  *                                value SVOXT_FWD_FAST_SIGMOID of the scratch forwards): the stepping -- which

@@ -897,8 +897,14 @@ def _volume_render(tree, rays, opt, record):
     lists = None
     wide = co.format == FORMAT_RGBA and ct.K in (8, 16, 32)
     split = (FWD_SPLIT != "0") if FWD_SPLIT != "" else wide
-    will_record = bool(record and BWD_LIST_SAMPLES > 0 and cr.Q > 0 and
-                       _lib.svoxt_can_record(ctypes.byref(ct), ctypes.byref(co)))
+    can_rec = _lib.svoxt_can_record(ctypes.byref(ct), ctypes.byref(co)) if (record and BWD_LIST_SAMPLES > 0 and cr.Q > 0) else 0
+    will_record = bool(can_rec)
+    if can_rec == 2:
+        # SG / ASG: lists serve the exact per-tile backward alone -- recorded when that is the backward that will run
+        # (the conditions of _volume_render_backward), else the backward marches by itself as before
+        tiled = cr.image_width > 0 and cr.image_width % 8 == 0 and cr.image_height % 8 == 0
+        coherent = tiled or bool(getattr(rays, "coherent", False))
+        will_record = bool(BWD_EXACT and BWD_TERMS and BWD_FUSED and (BWD_GATHER == 2 or (BWD_GATHER == 1 and coherent)))
     lflags = _list_flags(native=NATIVE_MATH and wide)
     fills = _lib.svoxt_fwd_fills_terms(ctypes.byref(ct), ctypes.byref(co), lflags) \
         if (will_record and BWD_EXACT and BWD_TERMS and BWD_FUSED and BWD_GATHER) else 0
@@ -1003,11 +1009,15 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
     coherent = tiled or bool(getattr(rays, "coherent", False))      # or sorted by svoxt_ray_order
     # rows wider than 32 floats (SH16: 49, SH25: 76): per tile only as ONE kernel over the hand-over the recording
     # forward left (lists.terms_state 2 / 3), exact arithmetic, no view rotations
-    wide_sh = K > 32 and lists is not None and co.format == FORMAT_SH and co.basis_dim in (16, 25) and \
+    wide_sh = K > 32 and lists is not None and co.format in (FORMAT_SH, FORMAT_SG, FORMAT_ASG) and co.basis_dim in (16, 25) and \
         K == 3 * co.basis_dim + 1 and lists.terms is not None and lists.terms_state in (2, 3) and \
         BWD_EXACT and BWD_FUSED and BWD_TERMS and ct.xform is None
     gather = lists is not None and (K <= 32 or wide_sh) and grad_output.shape[1] == 4 and ct.N == 2 and \
         (BWD_GATHER == 2 or (BWD_GATHER == 1 and coherent))
+    if lists is not None and co.format in (FORMAT_SG, FORMAT_ASG) and not (
+            gather and BWD_FUSED and BWD_EXACT and ct.xform is None and lists.terms is not None and lists.terms_state == 3):
+        lists = None              # SG / ASG lists serve the exact per-tile backward only: march instead
+        gather = False
     with torch.cuda.device(dev):
         kept = _grad_scratch(dev, M, stride) if (GRAD_SCRATCH and lists is not None and stride != K and M > 0) else None
         buf = kept[0] if kept is not None else torch.empty((M, stride), dtype=torch.float32, device=dev)

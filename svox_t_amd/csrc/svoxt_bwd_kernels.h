@@ -824,7 +824,8 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
 // an exponential.
 // Two workgroups per CU (77 KB of LDS each) need at most 128 registers: said to the compiler,
 // because one branch too many costs exactly that (r02: 116 -> 130 registers, 0.38 -> 0.55 ms).
-template <int FMT, int BD, bool EXACT, bool COUNT = false, int TERMS = 0>
+// LOBES (FMT_SH instances over the forward's hand-over): the 64 rays' basis values are those of opt.format = SG or ASG.
+template <int FMT, int BD, bool EXACT, bool COUNT = false, int TERMS = 0, bool LOBES = false>
 __global__ void __launch_bounds__(512, 4)
 grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                   RecLists L, const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
@@ -849,6 +850,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     constexpr int NH = (K + HALF - 1) / HALF;                // rounds of columns in the reduce
     constexpr int KS = HALF | 1;                             // staging row: one round of columns
     static_assert(K <= 32 || (EXACT && TERMS >= 2), "wide rows: only with the forward's hand-over (no row in registers)");
+    static_assert(!LOBES || (FMT == FMT_SH && EXACT && TERMS >= 2), "lobes: only over the forward's hand-over");
     __shared__ int32_t keys[T];
     __shared__ int32_t cnt[T];
     __shared__ uint16_t order[R];
@@ -901,13 +903,14 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     if (from_tensors) {
         float dx, dy, dz;
         r.delta_scale = dir_to_tree(tr, dsrc, dx, dy, dz);   // setup_ray's, from the direction already at hand
-        if constexpr (FMT == FMT_SH) precalc_basis<BD>(FMT_SH, BD, tr, vsrc[0], vsrc[1], vsrc[2], basis);
+        if constexpr (FMT == FMT_SH && !LOBES) precalc_basis<BD>(FMT_SH, BD, tr, vsrc[0], vsrc[1], vsrc[2], basis);
     } else if (nrec > 0) {
         setup_ray(tr, rays, opt, q, r);                      // for delta_scale (a ray with samples hits the cube)
         if constexpr (FMT == FMT_SH) {
             float vd[3];
             load_vdir(rays, q, vd);
-            precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
+            if constexpr (!LOBES) precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
+            else { vsrc[0] = vd[0]; vsrc[1] = vd[1]; vsrc[2] = vd[2]; }
         }
     }
     if (wave == 0) {
@@ -918,8 +921,14 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 for (int c = 0; c < C; ++c) accum += g[c] * o[c];
             }
         }
+        if constexpr (LOBES) {
+            // (the lobes one at a time straight into LDS: 25 unrolled exponentials at this kernel's 128 registers spill 106)
+#pragma unroll 1
+            for (int i = 0; i < NB; ++i) bases[lane * BDS + i] = lobe_value(opt.format, tr, vsrc[0], vsrc[1], vsrc[2], i, NB);
+        } else {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) bases[lane * BDS + i] = basis[i];
+            for (int i = 0; i < NB; ++i) bases[lane * BDS + i] = basis[i];
+        }
 #pragma unroll
         for (int c = 0; c < C; ++c) gl[lane * 3 + c] = g[c];
     }

@@ -578,25 +578,22 @@ __device__ __forceinline__ void precalc_basis(int format, int basis_dim_rt, cons
 // that keep a ray's basis values in registers (r03: `render_fwd_kernel` / `render_bwd_kernel<..., LOBES>` -- what they
 // do with the values per sample is what they do with an SH basis).  Same operations in the same order as
 // precalc_basis (dot3 = u0 v0 + u1 v1 + u2 v2), written with scalars and unrolled so that `out` is registers.
+// one lobe's value (i < bd): the loop bodies of maybe_precalc_basis for SG / ASG
+__device__ __forceinline__ float lobe_value(int format, const TreeDev& tr, float x, float y, float z, int i, int bd) {
+    const float* lobe = tr.extra + (int64_t)i * tr.extra_cols;
+    if (format == FMT_SG) {
+        const float d = x * lobe[1] + y * lobe[2] + z * lobe[3];
+        return pexpf(lobe[0] * (d - 1.f)) / (float)bd;
+    }
+    const float S = x * lobe[8] + y * lobe[9] + z * lobe[10];
+    const float dot_x = x * lobe[2] + y * lobe[3] + z * lobe[4];
+    const float dot_y = x * lobe[5] + y * lobe[6] + z * lobe[7];
+    return S * pexpf(-lobe[0] * dot_x * dot_x - lobe[1] * dot_y * dot_y) / (float)bd;
+}
 template <int BD>
 __device__ __forceinline__ void precalc_lobes(int format, const TreeDev& tr, float x, float y, float z, float* out) {
-    if (format == FMT_SG) {
 #pragma unroll
-        for (int i = 0; i < BD; ++i) {
-            const float* lobe = tr.extra + (int64_t)i * tr.extra_cols;
-            const float d = x * lobe[1] + y * lobe[2] + z * lobe[3];
-            out[i] = pexpf(lobe[0] * (d - 1.f)) / (float)BD;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < BD; ++i) {
-            const float* lobe = tr.extra + (int64_t)i * tr.extra_cols;
-            const float S = x * lobe[8] + y * lobe[9] + z * lobe[10];
-            const float dot_x = x * lobe[2] + y * lobe[3] + z * lobe[4];
-            const float dot_y = x * lobe[5] + y * lobe[6] + z * lobe[7];
-            out[i] = S * pexpf(-lobe[0] * dot_x * dot_x - lobe[1] * dot_y * dot_y) / (float)BD;
-        }
-    }
+    for (int i = 0; i < BD; ++i) out[i] = lobe_value(format, tr, x, y, z, i, BD);
 }
 
 // Per-leaf view-direction rotation (rt_kernel.cu:283-291, :387-395): the basis

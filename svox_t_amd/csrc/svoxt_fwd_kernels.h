@@ -422,7 +422,8 @@ march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
 // tile inside the launch that marched it (fwd_roles_kernel).
 constexpr int kShadeP = 7;                       // list positions per round: one per wavefront but the first
 typedef float shade_v4f __attribute__((ext_vector_type(4)));
-template <int FMT, int BD, bool XF, bool STOP, bool WTERMS, bool COH>
+// LOBES (FMT_SH instances): the basis values are those of opt.format = SG or ASG with BD lobes (precalc_lobes).
+template <int FMT, int BD, bool XF, bool STOP, bool WTERMS, bool COH, bool LOBES = false>
 __device__ __forceinline__ void shade_tile_body(const TreeDev& tr, const RaysDev& rays, const Opts& opt, const RecLists& L,
                                                 uint4* __restrict__ aux, float* __restrict__ out, int64_t tile,
                                                 shade_v4f (*terms)[kShadeP][64] /* [2]: (att, e_0, e_1, e_2) of a list position, per ray */) {
@@ -453,7 +454,8 @@ __device__ __forceinline__ void shade_tile_body(const TreeDev& tr, const RaysDev
         delta_scale = r.delta_scale;
         if constexpr (FMT == FMT_SH) {
             load_vdir(rays, q, vd);
-            if constexpr (!XF) precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
+            if constexpr (LOBES) precalc_lobes<BD>(opt.format, tr, vd[0], vd[1], vd[2], basis);
+            else if constexpr (!XF) precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
         }
     }
     float light = 1.f, acc[C] = {0.f, 0.f, 0.f};
@@ -534,14 +536,15 @@ __device__ __forceinline__ void shade_tile_body(const TreeDev& tr, const RaysDev
 
 // tile_state (optional): tiles whose entry is kTileShaded were shaded inside fwd_roles_kernel -- nothing to do
 constexpr int32_t kTileShaded = 0x200;
-template <int FMT, int BD, bool XF, bool STOP, bool WTERMS = false>
+template <int FMT, int BD, bool XF, bool STOP, bool WTERMS = false, bool LOBES = false>
 __global__ void __launch_bounds__(512)
 shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
                   uint4* __restrict__ aux, float* __restrict__ out, const int32_t* __restrict__ tile_state = nullptr) {
+    static_assert(!LOBES || (FMT == FMT_SH && !XF), "lobes stand in for an SH basis");
     __shared__ shade_v4f terms[2][kShadeP][64];
     const int64_t tile = (int64_t)blockIdx.x + rays.tile0;
     if (tile_state != nullptr && tile_state[tile] == kTileShaded) return;       // (uniform: one tile per workgroup)
-    shade_tile_body<FMT, BD, XF, STOP, WTERMS, false>(tr, rays, opt, L, aux, out, tile, terms);
+    shade_tile_body<FMT, BD, XF, STOP, WTERMS, false, LOBES>(tr, rays, opt, L, aux, out, tile, terms);
 }
 
 // ---------------------------------------------------------------------------

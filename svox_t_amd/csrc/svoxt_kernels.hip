@@ -268,6 +268,70 @@ bool xform_special(const svoxt_tree* t, const svoxt_options* o) {
            (o->basis_dim == 1 || o->basis_dim == 4 || o->basis_dim == 9 || o->basis_dim == 16 || o->basis_dim == 25);
 }
 
+// SG / ASG payloads with an SH-sized lobe count and three channels (r03): a ray's basis values are formed once
+// (precalc_lobes) and used like an SH basis by the <LOBES> instances of the FMT_SH kernels.
+static inline bool lobes_payload(const Opts& opt, int K) {
+    return (opt.format == FMT_SG || opt.format == FMT_ASG) && K == 3 * opt.basis_dim + 1 &&
+           (opt.basis_dim == 1 || opt.basis_dim == 4 || opt.basis_dim == 9 || opt.basis_dim == 16 || opt.basis_dim == 25);
+}
+
+// ... with sample lists: the recording forward as march + tile shade + tail launch, leaving the backward's hand-over
+// (position-major: terms_state 3), and the per-tile backward over it -- the exact one-kernel form only.
+template <bool N2>
+bool launch_lobes_fwd_record(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out, RecLists L, uint4* aux,
+                             hipStream_t st, const uint32_t* sigma_mask) {
+    if (L.terms == nullptr || !lobes_payload(opt, tr.K)) return false;
+    const unsigned nb = nblocks(rays.Q);
+    const bool acc = N2 && tr.accel != nullptr;
+    if (sigma_mask != nullptr) {
+        if (acc) hipLaunchKernelGGL((march_rec_kernel<N2, false, 1, true>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, L, aux, sigma_mask);
+        else hipLaunchKernelGGL((march_rec_kernel<N2, false, 0, true>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, L, aux, sigma_mask);
+    } else {
+        if (acc) hipLaunchKernelGGL((march_rec_kernel<N2, false, 1>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, L, aux, (const uint32_t*)nullptr);
+        else hipLaunchKernelGGL((march_rec_kernel<N2, false, 0>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, L, aux, (const uint32_t*)nullptr);
+    }
+#define SVOXT_LOBES_FWD(BB)                                                                                         \
+    {                                                                                                               \
+        hipLaunchKernelGGL((shade_tile_kernel<FMT_SH, BB, false, false, true, true>), dim3(nb), dim3(512), 0, st,   \
+                           tr, rays, opt, L, aux, out, (const int32_t*)nullptr);                                    \
+        hipLaunchKernelGGL((render_fwd_kernel<FMT_SH, 3, BB, N2, false, false, true, true>), dim3(nb), dim3(kBlock), \
+                           0, st, tr, rays, opt, out, L, aux);                                                      \
+        return true;                                                                                                \
+    }
+    switch (opt.basis_dim) {
+        case 1: SVOXT_LOBES_FWD(1)
+        case 4: SVOXT_LOBES_FWD(4)
+        case 9: SVOXT_LOBES_FWD(9)
+        case 16: SVOXT_LOBES_FWD(16)
+        case 25: SVOXT_LOBES_FWD(25)
+    }
+#undef SVOXT_LOBES_FWD
+    return false;
+}
+
+bool launch_lobes_bwd_tiles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, const float* grad_out, float* grad,
+                            int gstride, RecLists L, const uint4* aux, hipStream_t st, int terms_state) {
+    if (L.terms == nullptr || terms_state != 3 || !lobes_payload(opt, tr.K) || g_bwd_counters != nullptr) return false;
+    const unsigned nb = nblocks(rays.Q);
+#define SVOXT_LOBES_BWD(BB)                                                                                         \
+    {                                                                                                               \
+        hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, true, false, true, false, true>), dim3(nb), dim3(kBlock), \
+                           0, st, tr, rays, opt, grad_out, grad, gstride, L, aux, (const float*)nullptr, (float4*)nullptr); \
+        hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 3, true>), dim3(nb), dim3(512), 0, st,       \
+                           tr, rays, opt, grad_out, L, aux, (const float*)nullptr, grad, gstride);                  \
+        return true;                                                                                                \
+    }
+    switch (opt.basis_dim) {
+        case 1: SVOXT_LOBES_BWD(1)
+        case 4: SVOXT_LOBES_BWD(4)
+        case 9: SVOXT_LOBES_BWD(9)
+        case 16: SVOXT_LOBES_BWD(16)
+        case 25: SVOXT_LOBES_BWD(25)
+    }
+#undef SVOXT_LOBES_BWD
+    return false;
+}
+
 template <bool N2, bool REC>
 bool launch_fwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C, float* out,
                         RecLists L, uint4* aux, hipStream_t st) {
@@ -708,6 +772,13 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
             const RecLists l1 = wide ? lists_dev(lists, rays->Q, 4) : ll;
             const uint4* laux = reinterpret_cast<const uint4*>(lists->aux);
             // coef_bytes < 0 (and no coef): the per-tile route if it can run fused, which needs no buffer
+            if (lobes_payload(od, tree->K)) {
+                // SG / ASG: the one-kernel per-tile backward over the forward's hand-over, or nothing
+                if (n2 && lists->coef_bytes < 0)
+                    done = launch_lobes_bwd_tiles(tr, rd, od, grad_out, grad_features, gs, ll, laux, st, lists->terms_state);
+                if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: SG / ASG sample lists serve the per-tile backward only (N = 2, lists.terms filled by the forward: terms_state 3, coef_bytes < 0)", fn);
+                return check_launch(fn);
+            }
             const bool have_coef = lists->coef != nullptr &&
                                    lists->coef_bytes >= (int64_t)lists->max_samples * rays->Q * 16;
             // (rows wider than 32 floats: SH16 / SH25 over the forward's hand-over, one kernel -- launch_bwd_gather decides)
@@ -823,6 +894,18 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
     const int32_t lflags = flags | (lists != nullptr ? lists->flags : 0) | (scratch != nullptr ? scratch->flags : 0);
     const bool fast = (lflags & SVOXT_LISTS_NATIVE_MATH) != 0;
     const bool want_terms = lists != nullptr && lists->terms != nullptr && C == 3;
+    if (lists != nullptr && lobes_payload(od, tree->K)) {
+        // SG / ASG with sample lists: only as march + tile shade that leaves the backward's hand-over (svoxt_can_record)
+        if (!want_terms || !full_comp(opt) || uses_xform(tree, opt) || tree->weight_accum != nullptr)
+            return fail(SVOXT_ERR_UNSUPPORTED, "%s: SG / ASG payloads record sample lists only with lists.terms (the exact per-tile backward's hand-over), all components, no transformation_matrices, no weight accumulation", fn);
+        const uint32_t* smask = (tree->sigma_mask != nullptr && tree->sigma_mask_thresh == opt->sigma_thresh)
+                                    ? reinterpret_cast<const uint32_t*>(tree->sigma_mask) : nullptr;
+        uint4* aux = reinterpret_cast<uint4*>(lists->aux);
+        done = n2 ? launch_lobes_fwd_record<true>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, st, smask)
+                  : launch_lobes_fwd_record<false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, st, smask);
+        if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no recording kernel for this SG / ASG payload", fn);
+        return check_launch(fn);
+    }
     if (fwd_split_enabled(tree, opt, want_terms, lflags) && full_comp(opt) && fwd_split_payload(tree, opt, C) &&
         (!uses_xform(tree, opt) || xform_special(tree, opt))) {
         const bool xf = uses_xform(tree, opt);
@@ -938,6 +1021,7 @@ int svoxt_fwd_fills_terms(const svoxt_tree* tree, const svoxt_options* opt, int3
     if (uses_xform(tree, opt)) return 0;
     const int C = svoxt_out_data_dim(opt, tree->K) - 1;
     if (C != 3) return 0;
+    if (lobes_payload(to_dev(opt), tree->K)) return 3;
     // 3: the two-kernel forward (tile shade kernel, position-major); 2: the one-kernel forward (lane-major lines)
     return (fwd_split_enabled(tree, opt, true, list_flags) && full_comp(opt) && fwd_split_payload(tree, opt, C)) ? 3 : 2;
 }
@@ -951,6 +1035,9 @@ int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt) {
     if (opt->format == SVOXT_FORMAT_SH && C == 3 && tree->K == 3 * opt->basis_dim + 1)
         return (opt->basis_dim == 1 || opt->basis_dim == 4 || opt->basis_dim == 9 || opt->basis_dim == 16 ||
                 opt->basis_dim == 25) ? 1 : 0;
+    // SG / ASG (r03): 2 = lists can be recorded, but only together with the exact per-tile backward's hand-over
+    // (lists.terms; svoxt_fwd_fills_terms says 3) on N = 2 trees without weight accumulation -- they serve that backward alone
+    if (C == 3 && lobes_payload(to_dev(opt), tree->K) && tree->N == 2 && tree->weight_accum == nullptr) return 2;
     return 0;
 }
 

@@ -124,6 +124,15 @@ def test_validation_codes_without_touching_the_gpu():
     assert b"xform_dim" in lib.svoxt_last_error()
     t.xform, t.xform_dim = None, 0
     assert lib.svoxt_can_record(ctypes.byref(t), ctypes.byref(o)) == 1
+    # SG / ASG payloads with an SH-sized lobe count: lists only together with the per-tile backward's hand-over (2)
+    o2 = _C._COptions(format=2, basis_dim=4, min_comp=0, max_comp=3)
+    t2 = _C._CTree(features=p, M=1, K=13, N=2, data=p, child=p, n_internal=1, offset=p, scaling=p, extra=p, extra_rows=4, extra_cols=4)
+    assert lib.svoxt_can_record(ctypes.byref(t2), ctypes.byref(o2)) == 2
+    assert lib.svoxt_fwd_fills_terms(ctypes.byref(t2), ctypes.byref(o2), 0) == 3
+    t2.N = 3
+    assert lib.svoxt_can_record(ctypes.byref(t2), ctypes.byref(o2)) == 0
+    t2.N, o2.basis_dim, o2.max_comp, t2.K, t2.extra_rows = 2, 6, 5, 19, 6     # six lobes: the generic kernels, no lists
+    assert lib.svoxt_can_record(ctypes.byref(t2), ctypes.byref(o2)) == 0
     # the table-editing entry points validate before launching
     assert lib.svoxt_refine(None, 3, 2, 1, 2, None, None, None, None, None) == 1
     assert b"capacity" in lib.svoxt_last_error()

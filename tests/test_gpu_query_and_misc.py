@@ -160,7 +160,7 @@ def test_asg_format(gpu):
 
 
 @pytest.mark.parametrize("kind,B", [("SG", 9), ("ASG", 4), ("SG", 25), ("ASG", 16), ("SG", 1)])
-def test_sg_asg_with_sh_sized_lobe_counts_take_the_register_kernels(gpu, kind, B):
+def test_sg_asg_with_sh_sized_lobe_counts_take_the_register_kernels(gpu, kind, B, monkeypatch):
     """SG / ASG payloads with 1 / 4 / 9 / 16 / 25 lobes and three channels are served by the kernels that keep a ray's
     basis values in registers (render_fwd_kernel / render_bwd_kernel<..., LOBES>, r03; other lobe counts stay with the
     generic kernels: the two tests above): forward bit-exact against the oracle, gradient within its tolerance,
@@ -186,9 +186,28 @@ def test_sg_asg_with_sh_sized_lobe_counts_take_the_register_kernels(gpu, kind, B
     np.testing.assert_array_equal(out.detach().cpu().numpy(), O.volume_render(ot, *cs.rays_np(), opt))
     gout = synth.grad_output(cs.Q, 4)
     out.backward(gout.to(gpu))
-    want, absum = O.volume_render_backward(ot, *cs.rays_np(), opt, gout.numpy(), want_abs=True)
+    assert _C.LAST_ROUTE["backward"].startswith("render_bwd_kernel (marches"), _C.LAST_ROUTE
+    want, absum, tight = O.volume_render_backward(ot, *cs.rays_np(), opt, gout.numpy(), want_abs="both")
     assert_grads_close(f.grad.cpu().numpy(), want, absum)
     assert np.abs(want[:, :-1]).max() > 0
+    # declared an image: sample lists with the backward's hand-over (march + tile shade), then the per-tile backward
+    # over them (grad_fused_kernel<..., LOBES>) -- the exact route: held to the tight scale; also with lists of 8
+    # samples, whose overflowing rays go through the tail launches
+    for cap in (None, 8):
+        if cap is not None:
+            monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", cap)
+        f.grad = None
+        out = rs(f, cs.rays_gpu(gpu), image_shape=(40, 40))
+        np.testing.assert_array_equal(out.detach().cpu().numpy(), O.volume_render(ot, *cs.rays_np(), opt))
+        out.backward(gout.to(gpu))
+        assert "shade_tile_kernel" in _C.LAST_ROUTE["forward"] and _C.LAST_ROUTE["backward"].startswith("grad_fused_kernel<EXACT>"), _C.LAST_ROUTE
+        assert_grads_close(f.grad.cpu().numpy(), want, tight)
+    # the knobs that take the per-tile backward away take the lists away with it
+    monkeypatch.setattr(_C, "BWD_GATHER", 0)
+    f.grad = None
+    rs(f, cs.rays_gpu(gpu), image_shape=(40, 40)).backward(gout.to(gpu))
+    assert _C.LAST_ROUTE["backward"].startswith("render_bwd_kernel (marches"), _C.LAST_ROUTE
+    assert_grads_close(f.grad.cpu().numpy(), want, tight)
 
 
 @pytest.mark.parametrize("Q", [0, 1, 63, 257])
