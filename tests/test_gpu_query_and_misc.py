@@ -609,6 +609,43 @@ def test_render_persp_generates_the_reference_rays_in_kernel(gpu, width, height,
                                   O.opacity_render(c.oracle_tree(), o, d, v, opt))
 
 
+@pytest.mark.parametrize("fmt,K", [("SH16", 49), ("SG9", 28), ("ASG16", 49)])
+def test_render_persp_with_the_payloads_added_in_r03(gpu, fmt, K):
+    """The camera route (rays generated in the kernels) through what round 3 added: SH16's rows of 49 floats and
+    SG / ASG lobes in the recording forward and in grad_fused_kernel, whose camera branch forms the view direction
+    itself (the lobes' basis values come from it).  Image bit-exact against the oracle on its own camera rays,
+    gradient on the tight scale."""
+    width = height = 64
+    c = Case(depth=5, K=K, data_format=fmt, width=8, height=8)
+    B = c.basis_dim
+    extra, lobes = None, None
+    g = torch.Generator().manual_seed(11)
+    if fmt.startswith("SG"):
+        lobes = torch.cat([torch.rand(B, 1, generator=g) * 4 + 0.5,
+                           torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1)], -1).contiguous()
+    elif fmt.startswith("ASG"):
+        fr = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0]
+        lobes = torch.cat([torch.rand(B, 2, generator=g) * 3 + 0.3, fr.reshape(B, 9)], -1).contiguous()
+    tree = svox.N3Tree.from_arrays(c.st.child, c.st.data, c.st.parent_depth, c.features, data_format=fmt,
+                                   extra_data=lobes, device=gpu)
+    ot = O.Tree(c.features.numpy(), c.st.data, c.st.child, extra=None if lobes is None else lobes.numpy())
+    opt = O.make_options(format=c.format, basis_dim=B)
+    fx = 1111.111 * width / 800.0
+    pose = synth.camera_pose(azimuth_deg=40.0, elevation_deg=20.0).astype(np.float32)
+    r = svox.VolumeRenderer(tree)
+    feats = tree.features.detach().clone().requires_grad_(True)
+    img = r.render_persp(feats, torch.from_numpy(pose).to(gpu), width=width, height=height, fx=fx)
+    o, d, v = O.camera_rays(pose, fx, fx, width, height)
+    want = O.volume_render(ot, o, d, v, opt)
+    assert (want[:, 3] > 0.05).mean() > 0.05
+    np.testing.assert_array_equal(img.detach().reshape(-1, 4).cpu().numpy(), want)
+    gout = torch.randn(height, width, 4, generator=g)
+    img.backward(gout.to(gpu))
+    assert _C.LAST_ROUTE["backward"].startswith("grad_fused_kernel<EXACT>"), _C.LAST_ROUTE
+    wg, wabs, tight = O.volume_render_backward(ot, o, d, v, opt, gout.reshape(-1, 4).numpy(), want_abs="both")
+    assert_grads_close(feats.grad.cpu().numpy(), wg, tight)
+
+
 def test_torch_ray_generator_matches_the_oracle_camera(gpu):
     """renderer.pinhole_rays (a torch utility for callers that want the ray tensors)
     == the oracle's cam2world_ray / maybe_world2ndc restatement."""

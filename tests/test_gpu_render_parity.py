@@ -226,6 +226,28 @@ def test_wide_sh_rows_take_the_per_tile_backward(gpu, fmt, K, depth, side, monke
     assert_grads_close(tree.features.grad.cpu().numpy(), want, tight)
 
 
+def test_wide_sh_rows_in_ray_order(gpu):
+    """SH16 on a shuffled batch that is no image, rendered in svoxt_ray_order's order (sort_rays=True): the lists are
+    walked per tile of that order -- grad_fused_kernel over the forward's hand-over, rays.order in both kernels -- and
+    every ray's pixel and every gradient entry is what the oracle says."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd import synth
+    c = Case(depth=5, K=49, data_format="SH16", width=72, height=64)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    o, d, v = c.rays_np()
+    shuffle = np.random.default_rng(3).permutation(len(o))[: len(o) - 21]            # (a ragged last tile)
+    o, d, v = o[shuffle].copy(), d[shuffle].copy(), v[shuffle].copy()
+    rays = svox.Rays(*(torch.from_numpy(x).to(gpu) for x in (o, d, v)))
+    g = synth.grad_output(len(o), 4, seed=5)
+    out = r(tree.features, rays, sort_rays=True)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O.volume_render(c.oracle_tree(), o, d, v, c.oracle_opts()))
+    out.backward(g.to(gpu))
+    assert _C.LAST_ROUTE["backward"].startswith("grad_fused_kernel<EXACT>"), _C.LAST_ROUTE
+    want, abs_sum, tight = O.volume_render_backward(c.oracle_tree(), o, d, v, c.oracle_opts(), g.numpy(), want_abs="both")
+    assert_grads_close(tree.features.grad.cpu().numpy(), want, tight)
+
+
 @pytest.mark.parametrize("name", ["d5_sh9", "d5_sh4_world"])
 def test_kept_gradient_scratch_changes_nothing(gpu, name, monkeypatch):
     """The padded gradient buffer kept between steps (svoxt_compact_rows_clear leaves it zeroed, the next backward
