@@ -688,6 +688,9 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
 // takes its exponentials with v_exp_f32 (nexpf) and the quotient with the hardware reciprocal,
 // acc = fma(w, rcp(1 + e), acc) -- a dozen instructions per channel and sample where the bit-exact
 // replica of expf and the double-precision divide are about fifty (r02 PMC: this kernel 100 % VALU-bound).
+#ifndef SVOXT_CHAN_SWIZZLE
+#define SVOXT_CHAN_SWIZZLE 1
+#endif
 template <int K, bool STOP, bool FAST>
 __global__ void __launch_bounds__(256)
 shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
@@ -698,7 +701,15 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
     const int c = lane & (K - 1);
     const int sig_lane = lane | (K - 1);                         // the sigma lane of this lane's ray
     // t: the launch thread of march_rec_kernel that holds this ray (tile t >> 6, lane t & 63)
-    const int64_t t = (int64_t)rays.tile0 * 64 + ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + (lane / K);
+    // (r03) Workgroup b runs on XCD b mod 8, and a tile's 64 rays are 64 / RPW wavefronts = 8 consecutive workgroups
+    // for K = 32: left alone, the rays of ONE tile -- which share their feature rows -- are shaded on all eight XCDs,
+    // each behind its own L2.  Within every 64 workgroups the two 3-bit fields of the index change places: XCD x then
+    // takes workgroups 8x .. 8x + 7 of the group -- one tile (K = 32), whole tiles for the narrower rows -- and
+    // neighbouring tiles still go to different XCDs.  (A contiguous eighth of the image per XCD: 1.00 -> 1.37 ms --
+    // the image's middle rows hold most of the samples.)
+    const unsigned b0 = blockIdx.x;
+    const unsigned wg = (SVOXT_CHAN_SWIZZLE && (b0 | 63u) < gridDim.x) ? (b0 & ~63u) | ((b0 & 7u) << 3) | ((b0 >> 3) & 7u) : b0;
+    const int64_t t = (int64_t)rays.tile0 * 64 + ((int64_t)wg * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + (lane / K);
     const int64_t q = ray_of_thread(rays, t);
     const bool inb = q < rays.Q;
     uint4 a = make_uint4(0u, 0u, 0u, 0u);
