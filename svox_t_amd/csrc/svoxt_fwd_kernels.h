@@ -707,8 +707,13 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
     // takes workgroups 8x .. 8x + 7 of the group -- one tile (K = 32), whole tiles for the narrower rows -- and
     // neighbouring tiles still go to different XCDs.  (A contiguous eighth of the image per XCD: 1.00 -> 1.37 ms --
     // the image's middle rows hold most of the samples.)
+    constexpr unsigned kRun = 8u * SVOXT_CHAN_SWIZZLE;           // consecutive workgroups (of the ray order) one XCD takes
     const unsigned b0 = blockIdx.x;
-    const unsigned wg = (SVOXT_CHAN_SWIZZLE && (b0 | 63u) < gridDim.x) ? (b0 & ~63u) | ((b0 & 7u) << 3) | ((b0 >> 3) & 7u) : b0;
+    unsigned wg = b0;
+    if (kRun != 0u && (b0 | (8u * kRun - 1u)) < gridDim.x) {
+        const unsigned base = b0 & ~(8u * kRun - 1u), x = b0 & 7u, m = (b0 >> 3) & (kRun - 1u);
+        wg = base + x * kRun + m;
+    }
     const int64_t t = (int64_t)rays.tile0 * 64 + ((int64_t)wg * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + (lane / K);
     const int64_t q = ray_of_thread(rays, t);
     const bool inb = q < rays.Q;
