@@ -226,6 +226,29 @@ def test_wide_sh_rows_take_the_per_tile_backward(gpu, fmt, K, depth, side, monke
     assert_grads_close(tree.features.grad.cpu().numpy(), want, tight)
 
 
+@pytest.mark.parametrize("knob,val", [("FWD_SPLIT", "0"), ("FWD_OVERLAP", False), ("LIST_POOL", False), ("SIGMA_MASK", False),
+                                      ("GRAD_SCRATCH", False)])
+def test_wide_sh_rows_under_the_forwards_other_arrangements(gpu, knob, val, monkeypatch):
+    """SH16's per-tile backward over whatever the recording forward was: one kernel (hand-over in lane-major lines,
+    terms_state 2), two launches, dense lists, no sigma bitmask, no kept gradient scratch -- same image bits, same
+    gradient on the tight scale."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd import synth
+    monkeypatch.setattr(_C, knob, val)
+    _C.invalidate_caches()
+    c = Case(depth=5, K=49, data_format="SH16", width=64, height=64)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    g = synth.grad_output(c.Q, 4)
+    out = r(tree.features, c.rays_gpu(gpu), image_shape=(64, 64))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts()))
+    out.backward(g.to(gpu))
+    assert _C.LAST_ROUTE["backward"].startswith("grad_fused_kernel<EXACT>"), _C.LAST_ROUTE
+    assert ("fwd_roles_kernel" in _C.LAST_ROUTE["forward"]) == (knob == "GRAD_SCRATCH"), _C.LAST_ROUTE
+    want, abs_sum, tight = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.numpy(), want_abs="both")
+    assert_grads_close(tree.features.grad.cpu().numpy(), want, tight)
+
+
 def test_wide_sh_rows_in_ray_order(gpu):
     """SH16 on a shuffled batch that is no image, rendered in svoxt_ray_order's order (sort_rays=True): the lists are
     walked per tile of that order -- grad_fused_kernel over the forward's hand-over, rays.order in both kernels -- and
