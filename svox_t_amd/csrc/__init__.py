@@ -916,7 +916,8 @@ def _volume_render(tree, rays, opt, record):
     # march and shade of a 3-channel payload as ONE launch (fwd_roles_kernel): the conditions of the library's launch_fwd_roles
     roles = bool(FWD_OVERLAP and LIST_POOL and ct.sigma_mask and ct.N == 2 and ct.xform is None and ct.weight_accum is None
                  and cr.Q > 0 and ((co.format == FORMAT_RGBA and ct.K == 4) or
-                                   (co.format == FORMAT_SH and co.basis_dim in (1, 4, 9, 16) and ct.K == 3 * co.basis_dim + 1)))
+                                   (co.format in (FORMAT_SH, FORMAT_SG, FORMAT_ASG) and co.basis_dim in (1, 4, 9, 16)
+                                    and ct.K == 3 * co.basis_dim + 1 and (co.format == FORMAT_SH or ct.accel))))
     LAST_ROUTE["forward"] = (("march_rec_kernel + shade_chan_kernel (two-kernel forward, channels on lanes"
                               + (", native exp / rcp)" if NATIVE_MATH else ")") if wide else
                               "fwd_roles_kernel (march + shade_tile in one launch)" if roles else

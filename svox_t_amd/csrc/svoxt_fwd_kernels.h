@@ -617,7 +617,7 @@ __device__ __forceinline__ int32_t pop_tile(int32_t* __restrict__ tile_state, in
     return tile;
 }
 
-template <int FMT, int BD, int ACC, bool WTERMS>
+template <int FMT, int BD, int ACC, bool WTERMS, bool LOBES = false>
 __global__ void __launch_bounds__(512)
 fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux, float* __restrict__ out,
                  const uint32_t* __restrict__ sigma_mask, int32_t* __restrict__ tile_state, int n_march, int ntiles) {
@@ -668,8 +668,8 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
     const int64_t tile = s_tile;
     if (tile < 0 || tile >= ntiles) return;                      // nothing arrived: left to the fallback launch; or tile | kTileEmpty: finished by its march
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    shade_tile_body<FMT, BD, false, false, WTERMS, true>(tr, rays, opt, L, aux, out, tile,
-                                                          reinterpret_cast<shade_v4f (*)[kShadeP][64]>(lds));
+    shade_tile_body<FMT, BD, false, false, WTERMS, true, LOBES>(tr, rays, opt, L, aux, out, tile,
+                                                                 reinterpret_cast<shade_v4f (*)[kShadeP][64]>(lds));
     if (threadIdx.x == 0) tile_state[tile] = kTileShaded;        // (read by the fallback launch: after this kernel)
 }
 

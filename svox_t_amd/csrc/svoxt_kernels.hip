@@ -279,10 +279,34 @@ static inline bool lobes_payload(const Opts& opt, int K) {
 // (position-major: terms_state 3), and the per-tile backward over it -- the exact one-kernel form only.
 template <bool N2>
 bool launch_lobes_fwd_record(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out, RecLists L, uint4* aux,
-                             hipStream_t st, const uint32_t* sigma_mask) {
+                             hipStream_t st, const uint32_t* sigma_mask, int32_t* tile_state) {
     if (L.terms == nullptr || !lobes_payload(opt, tr.K)) return false;
     const unsigned nb = nblocks(rays.Q);
     const bool acc = N2 && tr.accel != nullptr;
+    if constexpr (N2) {
+        // march and shade in one launch (fwd_roles_kernel<..., LOBES>) where SH takes it too: up to 16 lobes, grid at hand
+        if (tile_state != nullptr && sigma_mask != nullptr && acc && opt.basis_dim <= 16 && nb < (1u << 30)) {
+            const int n_march = (int)(((nb + 7) / 8 + 7) / 8 * 8);
+            const unsigned grid = (unsigned)n_march + (unsigned)n_march * 8;
+#define SVOXT_LOBES_ROLES(BB)                                                                                       \
+    {                                                                                                               \
+        hipLaunchKernelGGL((fwd_roles_kernel<FMT_SH, BB, 1, true, true>), dim3(grid), dim3(512), 0, st,             \
+                           tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb);                   \
+        hipLaunchKernelGGL((shade_tile_kernel<FMT_SH, BB, false, false, true, true>), dim3(nb), dim3(512), 0, st,   \
+                           tr, rays, opt, L, aux, out, (const int32_t*)tile_state);                                 \
+        hipLaunchKernelGGL((render_fwd_kernel<FMT_SH, 3, BB, true, false, false, true, true>), dim3(nb), dim3(kBlock), \
+                           0, st, tr, rays, opt, out, L, aux);                                                      \
+        return true;                                                                                                \
+    }
+            switch (opt.basis_dim) {
+                case 1: SVOXT_LOBES_ROLES(1)
+                case 4: SVOXT_LOBES_ROLES(4)
+                case 9: SVOXT_LOBES_ROLES(9)
+                case 16: SVOXT_LOBES_ROLES(16)
+            }
+#undef SVOXT_LOBES_ROLES
+        }
+    }
     if (sigma_mask != nullptr) {
         if (acc) hipLaunchKernelGGL((march_rec_kernel<N2, false, 1, true>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, L, aux, sigma_mask);
         else hipLaunchKernelGGL((march_rec_kernel<N2, false, 0, true>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, L, aux, sigma_mask);
@@ -901,8 +925,10 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
         const uint32_t* smask = (tree->sigma_mask != nullptr && tree->sigma_mask_thresh == opt->sigma_thresh)
                                     ? reinterpret_cast<const uint32_t*>(tree->sigma_mask) : nullptr;
         uint4* aux = reinterpret_cast<uint4*>(lists->aux);
-        done = n2 ? launch_lobes_fwd_record<true>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, st, smask)
-                  : launch_lobes_fwd_record<false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, st, smask);
+        int32_t* states = (lists->blocktab != nullptr && !(lflags & SVOXT_LISTS_FWD_NO_OVERLAP))
+                              ? reinterpret_cast<int32_t*>(lists->tile_state) : nullptr;
+        done = n2 ? launch_lobes_fwd_record<true>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, st, smask, states)
+                  : launch_lobes_fwd_record<false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, st, smask, nullptr);
         if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no recording kernel for this SG / ASG payload", fn);
         return check_launch(fn);
     }
