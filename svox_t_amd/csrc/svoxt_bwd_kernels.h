@@ -252,7 +252,7 @@ __device__ __forceinline__ void sample_advance(float att, float total_color, flo
 // LOBES (FMT_SH instances): the basis values are those of opt.format = SG or ASG with BD lobes (precalc_lobes).
 template <int FMT, int C, int BD, bool N2, bool REPLAY, bool XF = false, bool GATHER = false, bool ONEPASS = false,
           bool LOBES = false>
-__global__ void __launch_bounds__(kBlock, (GATHER && !XF && C == 3) ? 4 : 1)
+__global__ void __launch_bounds__(kBlock, (GATHER && !XF && C == 3 && BD <= 9) ? 4 : 1)
 render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                   float* __restrict__ grad, int gstride, RecLists L,
                   const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
