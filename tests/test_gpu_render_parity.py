@@ -249,6 +249,43 @@ def test_wide_sh_rows_under_the_forwards_other_arrangements(gpu, knob, val, monk
     assert_grads_close(tree.features.grad.cpu().numpy(), want, tight)
 
 
+@pytest.mark.parametrize("fmt,K", [("SH9", 28), ("SH16", 49), ("RGBA", 4), ("RGBA", 16), ("SG9", 28)])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_views_through_the_image_routes(gpu, fmt, K, seed):
+    """Seeded views around (and partly off) the cube -- azimuth, elevation, distance, image size with ragged last
+    tiles, feature seed -- through the routes an image takes (one-launch forward with tiles finished by their march,
+    per-tile backward that leaves empty tiles at once): pixels bit-exact, gradient on the tight scale, for every
+    payload family with a fast kernel."""
+    import svox_t_amd.csrc as _C
+    from svox_t_amd import synth
+    rng = np.random.default_rng(100 * seed + K)
+    W, H = int(rng.integers(5, 12)) * 8, int(rng.integers(5, 12)) * 8
+    c = Case(depth=5, K=K, data_format=fmt, width=W, height=H, seed=seed)
+    pose = synth.camera_pose(azimuth_deg=float(rng.uniform(0, 360)), elevation_deg=float(rng.uniform(-60, 60)),
+                             radius=float(rng.uniform(1.1, 2.6)), center=np.array([0.5, 0.5, 0.5]) + rng.uniform(-0.25, 0.25, 3))
+    o, d, v = (t.numpy() for t in synth.pinhole_rays(W, H, c2w=pose))
+    lobes = None
+    if fmt.startswith("SG"):
+        g = torch.Generator().manual_seed(seed)
+        lobes = torch.cat([torch.rand(c.basis_dim, 1, generator=g) * 4 + 0.5,
+                           torch.nn.functional.normalize(torch.randn(c.basis_dim, 3, generator=g), dim=-1)], -1).contiguous()
+    tree = svox.N3Tree.from_arrays(c.st.child, c.st.data, c.st.parent_depth, c.features, data_format=fmt,
+                                   extra_data=lobes, device=gpu)
+    ot = O.Tree(c.features.numpy(), c.st.data, c.st.child, offset=tree.offset.cpu().numpy(), scaling=tree.invradius.cpu().numpy(),
+                extra=None if lobes is None else lobes.numpy())
+    opt = O.make_options(format=c.format, basis_dim=c.basis_dim)
+    r = svox.VolumeRenderer(tree)
+    rays = svox.Rays(*(torch.from_numpy(a).to(gpu) for a in (o, d, v)))
+    out = r(tree.features, rays, image_shape=(H, W))
+    want = O.volume_render(ot, o, d, v, opt)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
+    g = synth.grad_output(W * H, want.shape[1], seed=seed)
+    out.backward(g.to(gpu))
+    gw, ab, tight = O.volume_render_backward(ot, o, d, v, opt, g.numpy(), want_abs="both")
+    assert_grads_close(tree.features.grad.cpu().numpy(), gw, tight)
+    assert np.all(tree.features.grad.cpu().numpy()[ab == 0] == 0)
+
+
 def test_wide_sh_rows_in_ray_order(gpu):
     """SH16 on a shuffled batch that is no image, rendered in svoxt_ray_order's order (sort_rays=True): the lists are
     walked per tile of that order -- grad_fused_kernel over the forward's hand-over, rays.order in both kernels -- and
