@@ -703,12 +703,12 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
     // t: the launch thread of march_rec_kernel that holds this ray (tile t >> 6, lane t & 63)
     // (r03) Workgroup b runs on XCD b mod 8, and a tile's 64 rays are 64 / RPW wavefronts = 8 consecutive workgroups
     // for K = 32: left alone, the rays of ONE tile -- which share their feature rows -- are shaded on all eight XCDs,
-    // each behind its own L2.  Within every 64 workgroups the two 3-bit fields of the index change places: XCD x then
-    // takes workgroups 8x .. 8x + 7 of the group -- one tile (K = 32), whole tiles for the narrower rows -- and
-    // neighbouring tiles still go to different XCDs.  (A contiguous eighth of the image per XCD: 1.00 -> 1.37 ms --
+    // each behind its own L2.  Within every 8 tiles' worth of workgroups the XCD field and the field of the workgroup
+    // within its tile change places (K = 32: the two 3-bit fields of every 64 workgroups): XCD x then takes tile x of the
+    // group, whole, and neighbouring tiles still go to different XCDs.  (A contiguous eighth of the image per XCD: 1.00 -> 1.37 ms --
     // the image's middle rows hold most of the samples.  Two / four tiles in a row per XCD, SVOXT_CHAN_SWIZZLE = 2 / 4:
     // the kernel's fetches 751 -> 719 / 704 MB, its time 0.669 -> 0.685 / 0.72 ms native: one tile it is.)
-    constexpr unsigned kRun = 8u * SVOXT_CHAN_SWIZZLE;           // consecutive workgroups (of the ray order) one XCD takes
+    constexpr unsigned kRun = (unsigned)(K / 4) * SVOXT_CHAN_SWIZZLE;   // consecutive workgroups one XCD takes: a tile's (64 rays / (4 wavefronts x 64 / K rays))
     const unsigned b0 = blockIdx.x;
     unsigned wg = b0;
     if (kRun != 0u && (b0 | (8u * kRun - 1u)) < gridDim.x) {
