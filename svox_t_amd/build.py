@@ -21,8 +21,9 @@ LIB_PATH = os.path.join(CSRC, LIB_NAME)
 # registers" (a private array that ends up in scratch memory is a round trip per access -- DESIGN.md
 # step 13 -- and the one place an out-of-range private index could fault)
 RESOURCES_PATH = os.path.join(CSRC, "libsvoxt_hip.resources.txt")
-SOURCES = ["svoxt_kernels.hip", "svoxt_build.hip", "svoxt_motion.hip", "svoxt_order.hip"]
-HEADERS = ["svoxt_device.h", "svoxt_host.h", "svoxt_lists.h", "svoxt_fwd_kernels.h", "svoxt_bwd_kernels.h",
+OBJ_DIR = os.path.join(CSRC, "build")          # object files (git-ignored)
+SOURCES = ["svoxt_kernels.hip", "svoxt_bwd.hip", "svoxt_build.hip", "svoxt_motion.hip", "svoxt_order.hip"]
+HEADERS = ["svoxt_device.h", "svoxt_host.h", "svoxt_launch.h", "svoxt_lists.h", "svoxt_fwd_kernels.h", "svoxt_bwd_kernels.h",
            "svoxt_misc_kernels.h", "svoxt_tile_reduce.inc", os.path.join("..", "..", "include", "svoxt.h")]
 
 # -ffp-contract=off is part of the numerical contract (svoxt_device.h): the
@@ -46,23 +47,40 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-o", LIB_PATH + ".tmp"] + \
-        [os.path.join(CSRC, s) for s in SOURCES]
+def _compile(src: str, verbose: bool):
+    """One translation unit -> object file (device code for gfx950 embedded); returns (returncode, cmd, stderr)."""
+    obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+    cmd = [_hipcc()] + [f for f in HIPCC_FLAGS if f != "-shared"] + \
+        ["-Rpass-analysis=kernel-resource-usage", "-c", "-o", obj, os.path.join(CSRC, src)]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)
+    return res.returncode, cmd, res.stderr, obj
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB_PATH
+    # the translation units are independent (no relocatable device code): compiled side by side, then linked
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        results = list(pool.map(lambda s: _compile(s, verbose), SOURCES))
     remarks, other = [], []
-    for line in res.stderr.splitlines():
-        (remarks if "-Rpass-analysis=kernel-resource-usage" in line else other).append(line)
+    for _, _, err, _ in results:
+        for line in err.splitlines():
+            (remarks if "-Rpass-analysis=kernel-resource-usage" in line else other).append(line)
     # the remarks come with source excerpts ("  123 | code", "      | ^"): keep warnings and errors only
     noise = [ln for ln in other if not (ln.lstrip()[:1].isdigit() or ln.lstrip().startswith("|"))]
-    if res.returncode != 0 or any("warning:" in ln or "error:" in ln for ln in noise):
+    failed = [r for r in results if r[0] != 0]
+    if failed or any("warning:" in ln or "error:" in ln for ln in noise):
         print("\n".join(noise), file=sys.stderr)
-    if res.returncode != 0:
-        raise subprocess.CalledProcessError(res.returncode, cmd)
+    if failed:
+        raise subprocess.CalledProcessError(failed[0][0], failed[0][1])
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp"] + [r[3] for r in results]
+    if verbose:
+        print(" ".join(link), file=sys.stderr)
+    subprocess.run(link, cwd=CSRC, check=True)
     with open(RESOURCES_PATH + ".tmp", "w") as f:
         f.write("\n".join(ln.split("remark: ", 1)[-1].replace(" [-Rpass-analysis=kernel-resource-usage]", "")
                           for ln in remarks) + "\n")

@@ -16,17 +16,13 @@
 //   svoxt_fwd_kernels.h   render_fwd_kernel (trace_ray; optionally records each ray's composited samples),
 //                         render_fwd_generic_kernel, sigma_mask_kernel, march_rec_kernel + shade_tile_kernel /
 //                         shade_chan_kernel + tail_chan_kernel (the forward as two kernels)
-//   svoxt_bwd_kernels.h   render_bwd_kernel (trace_ray_backward: replays recorded samples or marches, stages
-//                         gradient rows in LDS, flushes them as shaped atomics; <GATHER>: list walk of the
-//                         two-kernel backward / tail-only launch; <ONEPASS>: one sigmoid pass for wide rows),
-//                         grad_merge_kernel, grad_fused_kernel (list walk + per-tile merge as one kernel: the
-//                         backward of an image), grad_wide_kernel (the same for RGBA rows of 8 / 16 / 32 floats),
-//                         render_bwd_generic_kernel, render_bwd_generic_staged_kernel
 //   svoxt_misc_kernels.h  opacity_fwd_kernel (+ opacity_walk_kernel, opacity_merge_kernel: backward from lists),
 //                         depth_kernel, count_fwd_kernel, count_touched_kernel, query_fwd_kernel, query_bwd_kernel,
 //                         leaves_count / scan / scatter kernels, compact_rows_kernel, accel_build_kernel,
 //                         accel_nodes_kernel
-// Other translation units of the library: svoxt_build.hip (octree from a point
+// Other translation units of the library: svoxt_bwd.hip (the backward: svoxt_bwd_kernels.h -- render_bwd_kernel,
+// grad_merge_kernel, grad_fused_kernel, grad_wide_kernel, the generic fallbacks -- and its launch logic; its own
+// unit so that the two halves compile side by side), svoxt_build.hip (octree from a point
 // cloud, construct_tree), svoxt_motion.hip (motion variants, point skinning), svoxt_order.hip
 // (coherent order for ray batches that are not images).
 // The design rationale and the measurements behind each choice are in DESIGN.md 5.
@@ -45,9 +41,8 @@
 
 #pragma clang fp contract(off)
 
-#include "svoxt_lists.h"
+#include "svoxt_launch.h"
 #include "svoxt_fwd_kernels.h"
-#include "svoxt_bwd_kernels.h"
 #include "svoxt_misc_kernels.h"
 
 
@@ -59,7 +54,6 @@ using namespace svoxt;
 
 namespace {
 thread_local char g_err[512] = "";
-int64_t* g_bwd_counters = nullptr;      // svoxt_set_bwd_counters (instrumentation)
 }
 
 namespace svoxt {
@@ -73,10 +67,6 @@ int check_launch(const char* what) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(SVOXT_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     return SVOXT_OK;
-}
-
-static int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
-    return set_error(code, fmt, a, b);
 }
 
 int check_tree(const svoxt_tree* t, const char* fn) {
@@ -173,52 +163,6 @@ Opts to_dev(const svoxt_options* o) {
 
 namespace {
 
-inline unsigned nblocks(int64_t Q) { return (unsigned)((Q + kBlock - 1) / kBlock); }
-
-// sample lists: rec[tile][block of 8][lane][8], 8 bytes per record (rec_index)
-inline int64_t rec_rays(int64_t Q) { return (Q + 63) / 64 * 64; }
-// the kernels' view of caller-owned lists / of a dense workspace region
-inline RecLists lists_dev(const svoxt_sample_lists* l, int64_t Q, int term_bytes = 16) {
-    RecLists L;
-    L.rec = reinterpret_cast<uint2*>(l->rec);
-    L.tab = reinterpret_cast<int32_t*>(l->blocktab);
-    L.pool_next = reinterpret_cast<int32_t*>(l->pool_next);
-    L.pool_blocks = l->blocktab != nullptr ? l->pool_blocks : rec_rays(Q) / 64 * (l->max_samples / kRecBlock);
-    L.S = l->max_samples;
-    // term_bytes (16; 8 / 4 for the backwards of wide rows) per record slot, 16-byte aligned, or not at all
-    const bool have_terms = l->terms != nullptr && ((uintptr_t)l->terms & 15u) == 0 &&
-                            l->terms_bytes >= L.pool_blocks * (int64_t)(64 * kRecBlock) * term_bytes;
-    L.terms = have_terms ? reinterpret_cast<float4*>(l->terms) : nullptr;
-    return L;
-}
-inline RecLists dense_lists(void* rec, int64_t S, int64_t Q) {
-    RecLists L;
-    L.rec = reinterpret_cast<uint2*>(rec);
-    L.tab = nullptr;
-    L.pool_next = nullptr;
-    L.pool_blocks = rec_rays(Q) / 64 * (S / kRecBlock);
-    L.S = (int)S;
-    L.terms = nullptr;
-    return L;
-}
-inline int64_t rec_capacity(int64_t bytes, int64_t Q) {       // records per ray that fit: a multiple of 8, at most 4096
-    if (bytes <= 0 || Q <= 0) return 0;
-    int64_t S = bytes / (8 * rec_rays(Q)) / kRecBlock * kRecBlock;
-    return S > 4096 ? 4096 : S;
-}
-
-// Specialised payloads: (format, C, BD) with all components selected.
-struct Payload { int fmt, C, BD; };
-
-// transformation_matrices only matter for view-dependent formats (for RGBA the
-// reference's per-sample basis re-evaluation is a no-op, rt_kernel.cu:181-183)
-bool uses_xform(const svoxt_tree* t, const svoxt_options* o) {
-    return t->xform != nullptr && o->format != SVOXT_FORMAT_RGBA;
-}
-
-bool full_comp(const svoxt_options* o) {
-    return o->format == SVOXT_FORMAT_RGBA || (o->min_comp == 0 && o->max_comp == o->basis_dim - 1);
-}
 
 // specialised kernels with per-leaf view rotations: SH payloads on N = 2 trees
 template <bool REC>
@@ -239,40 +183,6 @@ bool launch_fwd_xform(const TreeDev& tr, const RaysDev& rays, const Opts& opt, i
     }
 #undef SVOXT_FWD_XF
     return false;
-}
-
-template <bool REPLAY>
-bool launch_bwd_xform(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
-                      const float* grad_out, float* grad, int gstride, RecLists L, const uint4* aux,
-                      const float* fwd_out, hipStream_t st) {
-    if (opt.format != FMT_SH || C != 3) return false;
-    const unsigned nb = nblocks(rays.Q);
-#define SVOXT_BWD_XF(BB)                                                                                      \
-    hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, REPLAY, true>), dim3(nb), dim3(kBlock), 0, st, \
-                       tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out);                         \
-    return true;
-    switch (opt.basis_dim) {
-        case 1: SVOXT_BWD_XF(1)
-        case 4: SVOXT_BWD_XF(4)
-        case 9: SVOXT_BWD_XF(9)
-        case 16: SVOXT_BWD_XF(16)
-        case 25: SVOXT_BWD_XF(25)
-    }
-#undef SVOXT_BWD_XF
-    return false;
-}
-
-// can the specialised kernels serve this tree / options pair with its view rotations?
-bool xform_special(const svoxt_tree* t, const svoxt_options* o) {
-    return t->N == 2 && o->format == SVOXT_FORMAT_SH && t->K == 3 * o->basis_dim + 1 &&
-           (o->basis_dim == 1 || o->basis_dim == 4 || o->basis_dim == 9 || o->basis_dim == 16 || o->basis_dim == 25);
-}
-
-// SG / ASG payloads with an SH-sized lobe count and three channels (r03): a ray's basis values are formed once
-// (precalc_lobes) and used like an SH basis by the <LOBES> instances of the FMT_SH kernels.
-static inline bool lobes_payload(const Opts& opt, int K) {
-    return (opt.format == FMT_SG || opt.format == FMT_ASG) && K == 3 * opt.basis_dim + 1 &&
-           (opt.basis_dim == 1 || opt.basis_dim == 4 || opt.basis_dim == 9 || opt.basis_dim == 16 || opt.basis_dim == 25);
 }
 
 // ... with sample lists: the recording forward as march + tile shade + tail launch, leaving the backward's hand-over
@@ -330,29 +240,6 @@ bool launch_lobes_fwd_record(const TreeDev& tr, const RaysDev& rays, const Opts&
         case 25: SVOXT_LOBES_FWD(25)
     }
 #undef SVOXT_LOBES_FWD
-    return false;
-}
-
-bool launch_lobes_bwd_tiles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, const float* grad_out, float* grad,
-                            int gstride, RecLists L, const uint4* aux, hipStream_t st, int terms_state) {
-    if (L.terms == nullptr || terms_state != 3 || !lobes_payload(opt, tr.K) || g_bwd_counters != nullptr) return false;
-    const unsigned nb = nblocks(rays.Q);
-#define SVOXT_LOBES_BWD(BB)                                                                                         \
-    {                                                                                                               \
-        hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, true, false, true, false, true>), dim3(nb), dim3(kBlock), \
-                           0, st, tr, rays, opt, grad_out, grad, gstride, L, aux, (const float*)nullptr, (float4*)nullptr); \
-        hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 3, true>), dim3(nb), dim3(512), 0, st,       \
-                           tr, rays, opt, grad_out, L, aux, (const float*)nullptr, grad, gstride);                  \
-        return true;                                                                                                \
-    }
-    switch (opt.basis_dim) {
-        case 1: SVOXT_LOBES_BWD(1)
-        case 4: SVOXT_LOBES_BWD(4)
-        case 9: SVOXT_LOBES_BWD(9)
-        case 16: SVOXT_LOBES_BWD(16)
-        case 25: SVOXT_LOBES_BWD(25)
-    }
-#undef SVOXT_LOBES_BWD
     return false;
 }
 
@@ -557,284 +444,6 @@ bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
         else hipLaunchKernelGGL((march_rec_kernel<N2, STOP, 0>), dim3(nb), dim3(kBlock), 0, st, tr, rays, opt, L, aux, (const uint32_t*)nullptr);
     }
     return launch_shade<N2, STOP>(tr, rays, opt, out, L, aux, xf, fast, nb, st);
-}
-
-// two-kernel backward: SH 1/4/9 (also with view rotations) and RGBA with 3 channels
-// (K <= 32) on N = 2 trees
-bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
-                       const float* grad_out, float* grad, int gstride, RecLists L, const uint4* aux,
-                       const float* fwd_out, float4* coef, bool xf, hipStream_t st, int terms_state = 0,
-                       bool native = false) {
-    const unsigned nb = nblocks(rays.Q);
-    if (C > 3) {
-        // RGBA-style rows of 8 / 16 / 32 floats: the exact per-tile form only (one kernel, a float per
-        // list slot in L.terms); tails of overflowed rays first, as for the 3-channel fused kernel
-        if (opt.format != FMT_RGBA || coef != nullptr || xf || fwd_out != nullptr || L.terms == nullptr) return false;
-#define SVOXT_WIDE(KK)                                                                                        \
-    {                                                                                                         \
-        hipLaunchKernelGGL((render_bwd_kernel<FMT_RGBA, KK - 1, 0, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
-                           tr, rays, opt, grad_out, grad, gstride, L, aux, (const float*)nullptr, (float4*)nullptr); \
-        unsigned long long* ctr = reinterpret_cast<unsigned long long*>(g_bwd_counters);                      \
-        if (ctr != nullptr)                                                                                   \
-            hipLaunchKernelGGL((grad_wide_kernel<KK, false, true>), dim3(nb), dim3(512), 0, st, tr, rays, opt, grad_out, L, aux, \
-                               grad, gstride, ctr);                                                           \
-        else if (native)                                                                                      \
-            hipLaunchKernelGGL((grad_wide_kernel<KK, true>), dim3(nb), dim3(512), 0, st, tr, rays, opt, grad_out, L, aux, \
-                               grad, gstride, (unsigned long long*)nullptr);                                  \
-        else                                                                                                  \
-            hipLaunchKernelGGL((grad_wide_kernel<KK, false>), dim3(nb), dim3(512), 0, st, tr, rays, opt, grad_out, L, aux, \
-                               grad, gstride, (unsigned long long*)nullptr);                                  \
-        return true;                                                                                          \
-    }
-        if (C == 7 && tr.K == 8) SVOXT_WIDE(8)
-        if (C == 15 && tr.K == 16) SVOXT_WIDE(16)
-        if (C == 31 && tr.K == 32) SVOXT_WIDE(32)
-#undef SVOXT_WIDE
-        return false;
-    }
-    if (C != 3) return false;
-    // a caller that hands over a coef buffer asks for the two-kernel form; without one (coef_bytes < 0)
-    // the per-tile route runs if it can run as ONE kernel.  (The choice is the caller's alone: the
-    // Python layer reads SVOXT_BWD_FUSED, the library reads no environment for this.)
-    const bool fused = coef == nullptr && !xf;
-    if (!fused && coef == nullptr) return false;            // the two-kernel form needs its buffer
-    // four wavefronts per tile and tables of 1024 (measured: one wavefront per tile 0.41 ms,
-    // two 0.33, four 0.30 before step 15; tables of 512 / 256 cost more passes than they buy)
-#define SVOXT_GATHER(F, BB)                                                                                   \
-    if (fused) {   /* tails of overflowed rays (a tail-only launch), then list walk and merge in one kernel */ \
-        hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
-                           tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out, (float4*)nullptr);   \
-        unsigned long long* ctr = reinterpret_cast<unsigned long long*>(g_bwd_counters);                      \
-        if (fwd_out != nullptr && ctr == nullptr)                                                             \
-            hipLaunchKernelGGL((grad_fused_kernel<F, BB, false>), dim3(nb), dim3(512), 0, st,                 \
-                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                 \
-        else if (ctr == nullptr && L.terms != nullptr && terms_state == 2)                                    \
-            hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 2>), dim3(nb), dim3(512), 0, st,        \
-                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                      \
-        else if (ctr == nullptr && L.terms != nullptr && terms_state == 3)                                    \
-            hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 3>), dim3(nb), dim3(512), 0, st,        \
-                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                      \
-        else if (ctr == nullptr && L.terms != nullptr)                                                        \
-            hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 1>), dim3(nb), dim3(512), 0, st,        \
-                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                      \
-        else if (ctr == nullptr)                                                                              \
-            hipLaunchKernelGGL((grad_fused_kernel<F, BB, true>), dim3(nb), dim3(512), 0, st,                  \
-                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                 \
-        else if (fwd_out != nullptr)                                                                          \
-            hipLaunchKernelGGL((grad_fused_kernel<F, BB, false, true>), dim3(nb), dim3(512), 0, st,           \
-                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, ctr);            \
-        else                                                                                                  \
-            hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, true>), dim3(nb), dim3(512), 0, st,            \
-                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, ctr);            \
-        return true;                                                                                          \
-    }                                                                                                         \
-    hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
-                       tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out, coef);                   \
-    hipLaunchKernelGGL((grad_merge_kernel<F, BB, 1024, 1024, 4>), dim3(nb), dim3(256), 0, st, tr, rays,      \
-                       grad_out, L, coef, aux, grad, gstride);                                                \
-    return true;
-#define SVOXT_GATHER_XF(BB)                                                                                       \
-    hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, true, true, true>), dim3(nb), dim3(kBlock), 0, st, \
-                       tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out, coef);                       \
-    hipLaunchKernelGGL((grad_merge_kernel<FMT_SH, BB, 1024, 512, 4, true>), dim3(nb), dim3(256), 0, st, tr, rays, \
-                       grad_out, L, coef, aux, grad, gstride);                                                    \
-    return true;
-    if (xf) {
-        if (opt.format != FMT_SH) return false;
-        switch (opt.basis_dim) {
-            case 1: SVOXT_GATHER_XF(1)
-            case 4: SVOXT_GATHER_XF(4)
-            case 9: SVOXT_GATHER_XF(9)
-        }
-        return false;
-    }
-    if (opt.format == FMT_RGBA) { SVOXT_GATHER(FMT_RGBA, 0) }
-    // SH16 / SH25 (rows of 49 / 76 floats, r03): the one-kernel per-tile form only, and only over the hand-over a
-    // recording forward left (terms_state 2 / 3): the kernel then never holds a feature row
-#define SVOXT_GATHER_WIDE(BB)                                                                                 \
-    {                                                                                                         \
-        if (!fused || g_bwd_counters != nullptr || fwd_out != nullptr || L.terms == nullptr ||                \
-            (terms_state != 2 && terms_state != 3)) return false;                                             \
-        hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
-                           tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out, (float4*)nullptr);        \
-        if (terms_state == 2)                                                                                 \
-            hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 2>), dim3(nb), dim3(512), 0, st,   \
-                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                      \
-        else                                                                                                  \
-            hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 3>), dim3(nb), dim3(512), 0, st,   \
-                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                      \
-        return true;                                                                                          \
-    }
-    if (opt.format == FMT_SH) {
-        switch (opt.basis_dim) {
-            case 1: SVOXT_GATHER(FMT_SH, 1)
-            case 4: SVOXT_GATHER(FMT_SH, 4)
-            case 9: SVOXT_GATHER(FMT_SH, 9)
-            case 16: SVOXT_GATHER_WIDE(16)
-            case 25: SVOXT_GATHER_WIDE(25)
-        }
-    }
-#undef SVOXT_GATHER_WIDE
-#undef SVOXT_GATHER
-#undef SVOXT_GATHER_XF
-    return false;
-}
-
-template <bool N2, bool REPLAY>
-bool launch_bwd_special(const TreeDev& tr, const RaysDev& rays, const Opts& opt, int C,
-                        const float* grad_out, float* grad, int gstride, RecLists L, const uint4* aux,
-                        const float* fwd_out, hipStream_t st) {
-    const unsigned nb = nblocks(rays.Q);
-#define SVOXT_BWD(F, CC, BB)                                                                      \
-    hipLaunchKernelGGL((render_bwd_kernel<F, CC, BB, N2, REPLAY>), dim3(nb), dim3(kBlock), 0, st, \
-                       tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out);             \
-    return true;
-#define SVOXT_BWD1(CC)                                                                                          \
-    hipLaunchKernelGGL((render_bwd_kernel<FMT_RGBA, CC, 0, N2, true, false, false, true>), dim3(nb), dim3(kBlock), \
-                       0, st, tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out);                         \
-    return true;
-    if (opt.format == FMT_RGBA) {
-        if (C == 3) { SVOXT_BWD(FMT_RGBA, 3, 0) }
-        if constexpr (REPLAY) {
-            // lists + a float per slot + the exact form asked for: one sigmoid pass instead of two
-            if (L.terms != nullptr && fwd_out == nullptr) {
-                if (C == 7) { SVOXT_BWD1(7) }
-                if (C == 15) { SVOXT_BWD1(15) }
-                if (C == 31) { SVOXT_BWD1(31) }
-            }
-        }
-        if (C == 7) { SVOXT_BWD(FMT_RGBA, 7, 0) }
-        if (C == 15) { SVOXT_BWD(FMT_RGBA, 15, 0) }
-        if (C == 31) { SVOXT_BWD(FMT_RGBA, 31, 0) }
-    } else if (opt.format == FMT_SH && C == 3) {
-        switch (opt.basis_dim) {
-            case 1: SVOXT_BWD(FMT_SH, 3, 1)
-            case 4: SVOXT_BWD(FMT_SH, 3, 4)
-            case 9: SVOXT_BWD(FMT_SH, 3, 9)
-            case 16: SVOXT_BWD(FMT_SH, 3, 16)
-            case 25: SVOXT_BWD(FMT_SH, 3, 25)
-        }
-    } else if constexpr (!REPLAY) {
-#define SVOXT_BWD_LOBES(BB)                                                                                        \
-    hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, N2, false, false, false, false, true>), dim3(nb), dim3(kBlock), \
-                       0, st, tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out);                            \
-    return true;
-        if ((opt.format == FMT_SG || opt.format == FMT_ASG) && C == 3 && tr.K == 3 * opt.basis_dim + 1) {
-            switch (opt.basis_dim) {
-                case 1: SVOXT_BWD_LOBES(1)
-                case 4: SVOXT_BWD_LOBES(4)
-                case 9: SVOXT_BWD_LOBES(9)
-                case 16: SVOXT_BWD_LOBES(16)
-                case 25: SVOXT_BWD_LOBES(25)
-            }
-        }
-#undef SVOXT_BWD_LOBES
-    }
-#undef SVOXT_BWD
-#undef SVOXT_BWD1
-    return false;
-}
-
-int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
-               const float* grad_out, int32_t grad_cols, float* grad_features, int32_t grad_stride,
-               void* workspace, int64_t workspace_bytes, const svoxt_sample_lists* lists,
-               const float* fwd_out, void* stream, const char* fn) {
-    int rc;
-    if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) ||
-        (rc = check_opts(opt, tree, fn, grad_cols > 1)))
-        return rc;
-    if (grad_features == nullptr && tree->M > 0) return fail(SVOXT_ERR_INVALID, "%s: grad_features is NULL", fn);
-    if (rays->Q > 0 && grad_out == nullptr) return fail(SVOXT_ERR_INVALID, "%s: grad_out is NULL", fn);
-    const int C = grad_cols - 1;
-    if (C < 0) return fail(SVOXT_ERR_INVALID, "%s: grad_cols must be >= 1", fn);
-    if (C > 0) {
-        const int want = svoxt_out_data_dim(opt, tree->K);
-        if (want != grad_cols) return fail(SVOXT_ERR_INVALID, "%s: grad_out columns do not match get_out_data_dim", fn);
-    }
-    const int gs = grad_stride > 0 ? grad_stride : tree->K;
-    if (gs < tree->K) return fail(SVOXT_ERR_INVALID, "%s: grad_stride smaller than data_dim", fn);
-    hipStream_t st = (hipStream_t)stream;
-    // (SVOXT_LISTS_GRAD_ZEROED: the caller's buffer is the scratch svoxt_compact_rows_clear left zeroed)
-    if (tree->M > 0 && !(lists != nullptr && (lists->flags & SVOXT_LISTS_GRAD_ZEROED))) {
-        const hipError_t e = hipMemsetAsync(grad_features, 0, sizeof(float) * (size_t)tree->M * gs, st);
-        if (e != hipSuccess) return fail(SVOXT_ERR_HIP, "%s: hipMemsetAsync: %s", fn, hipGetErrorString(e));
-    }
-    if (rays->Q == 0 || tree->M == 0) return SVOXT_OK;
-    const TreeDev tr = to_dev(tree);
-    const RaysDev rd = to_dev(rays);
-    const Opts od = to_dev(opt);
-    const bool n2 = tree->N == 2;
-    bool done = false;
-    const bool xf = uses_xform(tree, opt);
-    if (xf && lists != nullptr && !(full_comp(opt) && xform_special(tree, opt)))
-        return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists with transformation_matrices need an SH payload on an N = 2 tree", fn);
-    if (C > 0 && full_comp(opt) && xf && xform_special(tree, opt)) {
-        const int64_t S = workspace != nullptr ? rec_capacity(workspace_bytes, rays->Q) : 0;
-        if (lists != nullptr) {
-            const int64_t need = (int64_t)lists->max_samples * rays->Q * 32;
-            if (lists->coef != nullptr && tree->K <= 32 && lists->coef_bytes >= need)
-                done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, lists_dev(lists, rays->Q),
-                                         reinterpret_cast<const uint4*>(lists->aux), fwd_out,
-                                         reinterpret_cast<float4*>(lists->coef), true, st);
-            if (!done)
-                done = launch_bwd_xform<true>(tr, rd, od, C, grad_out, grad_features, gs, lists_dev(lists, rays->Q),
-                                              reinterpret_cast<const uint4*>(lists->aux), fwd_out, st);
-        }
-        else
-            done = launch_bwd_xform<false>(tr, rd, od, C, grad_out, grad_features, gs,
-                                           dense_lists(S > 0 ? workspace : nullptr, S, rays->Q), nullptr, nullptr, st);
-    } else if (C > 0 && full_comp(opt) && !xf)
-    {
-        // per-ray sample lists: S entries of 8 bytes per ray, laid out rec[k][q]
-        const int64_t S = workspace != nullptr ? rec_capacity(workspace_bytes, rays->Q) : 0;
-        const RecLists wl = dense_lists(S > 0 ? workspace : nullptr, S, rays->Q);
-        if (lists != nullptr) {
-            // hand-over per list slot: 16 bytes for 3-channel payloads; RGBA rows of 8 / 16 / 32 floats: 8 for the
-            // per-tile kernel (grad_wide_kernel), 4 for the per-ray one (render_bwd_kernel<ONEPASS>)
-            const bool wide = opt->format == SVOXT_FORMAT_RGBA && C > 3;
-            const RecLists ll = lists_dev(lists, rays->Q, wide ? 8 : 16);
-            const RecLists l1 = wide ? lists_dev(lists, rays->Q, 4) : ll;
-            const uint4* laux = reinterpret_cast<const uint4*>(lists->aux);
-            // coef_bytes < 0 (and no coef): the per-tile route if it can run fused, which needs no buffer
-            if (lobes_payload(od, tree->K)) {
-                // SG / ASG: the one-kernel per-tile backward over the forward's hand-over, or nothing
-                if (n2 && lists->coef_bytes < 0)
-                    done = launch_lobes_bwd_tiles(tr, rd, od, grad_out, grad_features, gs, ll, laux, st, lists->terms_state);
-                if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: SG / ASG sample lists serve the per-tile backward only (N = 2, lists.terms filled by the forward: terms_state 3, coef_bytes < 0)", fn);
-                return check_launch(fn);
-            }
-            const bool have_coef = lists->coef != nullptr &&
-                                   lists->coef_bytes >= (int64_t)lists->max_samples * rays->Q * 16;
-            // (rows wider than 32 floats: SH16 / SH25 over the forward's hand-over, one kernel -- launch_bwd_gather decides)
-            if (n2 && (tree->K <= 32 || !have_coef) && (have_coef || lists->coef_bytes < 0))
-                // (ll.terms: the exact one-kernel form's hand-over buffer; terms_state 2 = the forward filled it)
-                done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, ll, laux,
-                                         fwd_out, have_coef ? reinterpret_cast<float4*>(lists->coef) : nullptr, false, st,
-                                         (lists->terms_state == 2 || lists->terms_state == 3) ? lists->terms_state : 1,
-                                         (lists->flags & SVOXT_LISTS_NATIVE_MATH) != 0);
-            if (!done) done = n2 ? launch_bwd_special<true, true>(tr, rd, od, C, grad_out, grad_features, gs, l1, laux, fwd_out, st)
-                      : launch_bwd_special<false, true>(tr, rd, od, C, grad_out, grad_features, gs, l1, laux, fwd_out, st);
-            if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no specialised kernel for this payload", fn);
-        } else {
-            done = n2 ? launch_bwd_special<true, false>(tr, rd, od, C, grad_out, grad_features, gs, wl, nullptr, nullptr, st)
-                      : launch_bwd_special<false, false>(tr, rd, od, C, grad_out, grad_features, gs, wl, nullptr, nullptr, st);
-        }
-    } else if (lists != nullptr) {
-        return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists need a specialised payload", fn);
-    }
-    if (!done) {
-        const unsigned nb = nblocks(rays->Q);
-        const size_t lds = (size_t)(kBlock / 64) * 64 * (tree->K | 1) * sizeof(float) + kBlock * sizeof(int32_t);
-        if (C > 0 && lds <= 65536) {      // shaped atomics through LDS staging (default dynamic-LDS limit: 64 KiB)
-            if (n2) hipLaunchKernelGGL((render_bwd_generic_staged_kernel<true>), dim3(nb), dim3(kBlock), lds, st, tr, rd, od, C, grad_out, grad_features, gs);
-            else hipLaunchKernelGGL((render_bwd_generic_staged_kernel<false>), dim3(nb), dim3(kBlock), lds, st, tr, rd, od, C, grad_out, grad_features, gs);
-        } else {
-            // C == 0 (opacity: one value per sample, nothing to shape) or rows too wide to stage
-            if (n2) hipLaunchKernelGGL((render_bwd_generic_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, grad_out, grad_features, gs);
-            else hipLaunchKernelGGL((render_bwd_generic_kernel<false>), dim3(nb), dim3(kBlock), 0, st, tr, rd, od, C, grad_out, grad_features, gs);
-        }
-    }
-    return check_launch(fn);
 }
 
 }  // namespace
@@ -1235,11 +844,6 @@ int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
     if (tree->N == 2) hipLaunchKernelGGL((count_fwd_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, to_dev(rays), to_dev(opt), c);
     else hipLaunchKernelGGL((count_fwd_kernel<false>), dim3(nb), dim3(kBlock), 0, st, tr, to_dev(rays), to_dev(opt), c);
     return check_launch(fn);
-}
-
-int svoxt_set_bwd_counters(int64_t* counters) {
-    g_bwd_counters = counters;
-    return SVOXT_OK;
 }
 
 int svoxt_count_touched(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
