@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 16
+#define SVOXT_ABI_VERSION 17
 
 enum {
     SVOXT_OK = 0,
@@ -252,6 +252,16 @@ int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
  *                                again -- a fill of M * grad_stride floats per step less.  The caller answers for the
  *                                zeros (a scratch a failed call may have left half written must be filled again). */
 #define SVOXT_LISTS_GRAD_ZEROED 16
+/* Test and measurement switches of the one-launch forward (fwd_roles_kernel; ABI v17), all result-neutral: its shading
+ * workgroups drop every third tile they take / give up after one poll / treat what they load for every fifth tile as a
+ * stale read would look -- the fallback launch must then deliver the same pixels, lists and hand-over -- and
+ * SVOXT_LISTS_FWD_AGENT_FENCE: the march -> shade hand-over with an agent-scope release before the queue entry is
+ * stored and an agent-scope acquire before the first load (the microarchitecture guide's valid form in full; the
+ * default rests on same-XCD queues, acknowledged stores and sc1 loads, checked by a per-tile checksum). */
+#define SVOXT_LISTS_TEST_DROP 256
+#define SVOXT_LISTS_TEST_NOPOLL 512
+#define SVOXT_LISTS_TEST_STALE 1024
+#define SVOXT_LISTS_FWD_AGENT_FENCE 2048
 typedef struct svoxt_sample_lists {
     void*   rec;           /* device, 64-byte aligned, max_samples * ceil(Q / 64) * 64 * 8 bytes: record k of the
                               ray handled by launch thread t lives at rec[t / 64][k / 8][t % 64][k % 8] (8 bytes
@@ -299,11 +309,11 @@ typedef struct svoxt_sample_lists {
     void*   pool_next;
     int32_t terms_state;   /* see terms */
     int32_t flags;         /* 0 or an OR of SVOXT_LISTS_* (above) */
-    void*   tile_state;    /* optional (pooled lists only): device int32 [9 * ceil(Q / 64) + 512], scratch.  Given, the two-kernel
+    void*   tile_state;    /* optional (pooled lists only): device int32 [17 * ceil(Q / 64) + 514], 8-byte aligned, scratch.  Given, the two-kernel
                               forward of 3-channel payloads (N = 2, no view rotations, sigma bitmask at hand) runs its march
                               and its shade as ONE launch: tiles are shaded in the order their marches finish, beside the
-                              marches still running (per-tile states, then per-XCD ready queues and their counters:
-                              fwd_roles_kernel).  Cleared by the
+                              marches still running (per-tile states, then per-XCD ready queues of 64-bit entries -- tile id and a
+                              checksum of the tile's lists -- and their counters: fwd_roles_kernel).  Cleared by the
                               forward together with the block table (one fill when it lies right behind pool_next's
                               counters).  Same lists, terms and pixels bit for bit.  NULL: two launches. */
 } svoxt_sample_lists;
@@ -417,6 +427,15 @@ int svoxt_count_touched(const svoxt_tree* tree, const svoxt_rays* rays, const sv
  * the number of (tile, window of 16 list positions, feature row) groups they belong to.  Process-wide;
  * meant for bench.py. */
 int svoxt_set_bwd_counters(int64_t* counters);
+
+/* Instrumentation (ABI v17): words [32] (device int64, caller-zeroed) or NULL.  While set, the one-kernel
+ * per-tile backwards run their CHECKED instances: every index into an LDS array, the lists' block pool
+ * and the feature / gradient tables is compared with its extent before it is used; a violation adds one
+ * to words[2 + site] (sites: svoxt_bwd_kernels.h, grad_fused_kernel / grad_wide_kernel) and the index is
+ * clamped, so the checked run cannot itself leave its arrays; words[31] counts the tiles the checked
+ * instances worked on (0: the route taken has no checked instance).  Results are those of the production
+ * instances.  Process-wide; meant for tests (the memory fault of round 3). */
+int svoxt_set_bwd_check(int64_t* words);
 
 /* Acceleration grid (no counterpart in the reference).  A 2^g x 2^g x 2^g table
  * that caches, per cell, where the root->leaf descent of common.cuh:63-100

@@ -43,7 +43,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -98,6 +98,7 @@ class _CLists(ctypes.Structure):         # struct svoxt_sample_lists
 
 # svoxt_sample_lists.flags (include/svoxt.h)
 LISTS_NATIVE_MATH, LISTS_FWD_ONE_KERNEL, LISTS_FWD_TWO_KERNELS, LISTS_FWD_NO_OVERLAP, LISTS_GRAD_ZEROED = 1, 2, 4, 8, 16
+LISTS_TEST_DROP, LISTS_TEST_NOPOLL, LISTS_TEST_STALE, LISTS_FWD_AGENT_FENCE = 256, 512, 1024, 2048
 
 
 _P = ctypes.POINTER
@@ -135,6 +136,7 @@ EXPORTS = {
     "svoxt_count_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
     "svoxt_count_touched": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp, _vp]),
     "svoxt_set_bwd_counters": (ctypes.c_int, [_vp]),
+    "svoxt_set_bwd_check": (ctypes.c_int, [_vp]),
     "svoxt_ray_order_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "svoxt_ray_order": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, ctypes.c_int64, _vp]),
     "svoxt_gather_rays": (ctypes.c_int, [_P(_CRays), _vp, _vp, _vp, _vp, _vp]),
@@ -210,6 +212,7 @@ FWD_OVERLAP = _env_flag("SVOXT_FWD_OVERLAP", "1")
 # --- not environment switches: routes the tests exercise by assignment
 BWD_TERMS = True     # False: no hand-over between the sweeps of the exact backwards (every row gathered twice)
 BWD_FUSED = True     # False: list walk and per-tile merge of an image's backward as two kernels (the form view rotations take)
+ROLES_FLAGS = 0      # OR of LISTS_TEST_* / LISTS_FWD_AGENT_FENCE: test and measurement switches of the one-launch forward
 
 
 def _list_flags(native: bool = False) -> int:
@@ -220,7 +223,7 @@ def _list_flags(native: bool = False) -> int:
         f |= LISTS_FWD_TWO_KERNELS
     if not FWD_OVERLAP:
         f |= LISTS_FWD_NO_OVERLAP
-    return f
+    return f | ROLES_FLAGS
 
 
 # ---------------------------------------------------------------------------
@@ -646,7 +649,7 @@ class SampleLists:
             self.pool_blocks = (_pool_blocks_for(tiles, S) + 31) // 32 * 32      # 32 equal parts, a counter each
             nt = tiles * (S // 8)
             # table, then the 32 counters, then the tile states, ready queues and their counters (march and shade in one launch): one fill
-            both = torch.empty((nt + 32 * 16 + 9 * tiles + 512,), dtype=torch.int32, device=device)
+            both = torch.empty((nt + 32 * 16 + 17 * tiles + 514,), dtype=torch.int32, device=device)
             self.blocktab, self.pool_next, self.tile_state = both[:nt], both[nt:nt + 32 * 16], both[nt + 32 * 16:]
         else:
             # rec[tile][block][lane][8]: every ray owns S slots
@@ -1292,6 +1295,26 @@ class bwd_counters:
 
     def read(self):
         return tuple(int(v) for v in self.buf.cpu().tolist())
+
+
+class bwd_check:
+    """`with bwd_check(dev) as c: ...backward...; c.read()` -> ({site: violations}, tiles worked on): the per-tile
+    backwards run inside take their CHECKED instances -- every LDS / pool / table index compared with its extent
+    (svoxt_set_bwd_check; the sites are listed at grad_fused_kernel / grad_wide_kernel)."""
+
+    def __init__(self, device):
+        self.buf = torch.zeros((32,), dtype=torch.int64, device=device)
+
+    def __enter__(self):
+        _call("svoxt_set_bwd_check", _ptr(self.buf))
+        return self
+
+    def __exit__(self, *exc):
+        _call("svoxt_set_bwd_check", None)
+
+    def read(self):
+        w = [int(v) for v in self.buf.cpu().tolist()]
+        return {site: n for site, n in enumerate(w[2:31]) if n}, w[31]
 
 
 def motion_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions):

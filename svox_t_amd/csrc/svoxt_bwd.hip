@@ -18,6 +18,7 @@ using namespace svoxt;
 
 namespace {
 int64_t* g_bwd_counters = nullptr;      // svoxt_set_bwd_counters (instrumentation)
+int64_t* g_bwd_check = nullptr;         // svoxt_set_bwd_check (instrumentation): the per-tile backwards run their CHECK instances
 
 // specialised kernels with per-leaf view rotations: SH payloads on N = 2 trees
 template <bool REPLAY>
@@ -80,7 +81,13 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
         hipLaunchKernelGGL((render_bwd_kernel<FMT_RGBA, KK - 1, 0, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
                            tr, rays, opt, grad_out, grad, gstride, L, aux, (const float*)nullptr, (float4*)nullptr); \
         unsigned long long* ctr = reinterpret_cast<unsigned long long*>(g_bwd_counters);                      \
-        if (ctr != nullptr)                                                                                   \
+        unsigned long long* chkw = reinterpret_cast<unsigned long long*>(g_bwd_check);                        \
+        if (chkw != nullptr && !native)                                                                       \
+            hipLaunchKernelGGL((grad_wide_kernel<KK, false, false, true>), dim3(nb), dim3(512), 0, st, tr, rays, opt, grad_out, L, aux, \
+                               grad, gstride, chkw);                                                          \
+        else if (chkw != nullptr)                                                                             \
+            return false;                                                                                     \
+        else if (ctr != nullptr)                                                                              \
             hipLaunchKernelGGL((grad_wide_kernel<KK, false, true>), dim3(nb), dim3(512), 0, st, tr, rays, opt, grad_out, L, aux, \
                                grad, gstride, ctr);                                                           \
         else if (native)                                                                                      \
@@ -110,6 +117,25 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
         hipLaunchKernelGGL((render_bwd_kernel<F, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
                            tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out, (float4*)nullptr);   \
         unsigned long long* ctr = reinterpret_cast<unsigned long long*>(g_bwd_counters);                      \
+        unsigned long long* chkw = reinterpret_cast<unsigned long long*>(g_bwd_check);                        \
+        if (chkw != nullptr) {   /* the checked instance of the route that would run */                       \
+            if (fwd_out != nullptr)                                                                           \
+                hipLaunchKernelGGL((grad_fused_kernel<F, BB, false, false, 0, false, true>), dim3(nb), dim3(512), 0, st, \
+                                   tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);            \
+            else if (L.terms != nullptr && terms_state == 2)                                                  \
+                hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 2, false, true>), dim3(nb), dim3(512), 0, st, \
+                                   tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);            \
+            else if (L.terms != nullptr && terms_state == 3)                                                  \
+                hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 3, false, true>), dim3(nb), dim3(512), 0, st, \
+                                   tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);            \
+            else if (L.terms != nullptr)                                                                      \
+                hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 1, false, true>), dim3(nb), dim3(512), 0, st, \
+                                   tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);            \
+            else                                                                                              \
+                hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 0, false, true>), dim3(nb), dim3(512), 0, st, \
+                                   tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);            \
+            return true;                                                                                      \
+        }                                                                                                     \
         if (fwd_out != nullptr && ctr == nullptr)                                                             \
             hipLaunchKernelGGL((grad_fused_kernel<F, BB, false>), dim3(nb), dim3(512), 0, st,                 \
                                tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                 \
@@ -162,7 +188,14 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
             (terms_state != 2 && terms_state != 3)) return false;                                             \
         hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, true, false, true>), dim3(nb), dim3(kBlock), 0, st, \
                            tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out, (float4*)nullptr);        \
-        if (terms_state == 2)                                                                                 \
+        unsigned long long* chkw = reinterpret_cast<unsigned long long*>(g_bwd_check);                        \
+        if (chkw != nullptr && terms_state == 2)                                                              \
+            hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 2, false, true>), dim3(nb), dim3(512), 0, st, \
+                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);                \
+        else if (chkw != nullptr)                                                                             \
+            hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 3, false, true>), dim3(nb), dim3(512), 0, st, \
+                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);                \
+        else if (terms_state == 2)                                                                            \
             hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 2>), dim3(nb), dim3(512), 0, st,   \
                                tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                      \
         else                                                                                                  \
@@ -352,6 +385,11 @@ extern "C" {
 
 int svoxt_set_bwd_counters(int64_t* counters) {
     g_bwd_counters = counters;
+    return SVOXT_OK;
+}
+
+int svoxt_set_bwd_check(int64_t* words) {
+    g_bwd_check = words;
     return SVOXT_OK;
 }
 

@@ -825,12 +825,19 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
 // Two workgroups per CU (77 KB of LDS each) need at most 128 registers: said to the compiler,
 // because one branch too many costs exactly that (r02: 116 -> 130 registers, 0.38 -> 0.55 ms).
 // LOBES (FMT_SH instances over the forward's hand-over): the 64 rays' basis values are those of opt.format = SG or ASG.
-template <int FMT, int BD, bool EXACT, bool COUNT = false, int TERMS = 0, bool LOBES = false>
+// CHECK (instrumentation, svoxt_set_bwd_check; r04): every LDS / pool / table index against its extent, violations
+// counted per site in counters[kChkBase + site] (see chk()); the sites of this kernel: 0 sweep 1's hand-over slot,
+// 1 the chain's read of it, 2 a list block outside the pool, 3 a record's slot in a pass, 4 its table entry, 5 the
+// chain's slot, 6 a feature row outside the table; svoxt_tile_reduce.inc: 8 table entry of a record, 9 its place in
+// the sorted order, 10 sorted record number, 11 table entry of a sorted record, 12 the row a sum is sent to,
+// 13 records of the pass != sum of the table's counters.
+template <int FMT, int BD, bool EXACT, bool COUNT = false, int TERMS = 0, bool LOBES = false, bool CHECK = false>
 __global__ void __launch_bounds__(512, 4)
 grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                   RecLists L, const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
                   float* __restrict__ grad, int gstride, unsigned long long* __restrict__ counters = nullptr) {
     if (tile_never_recorded(L, blockIdx.x)) return;          // (r03: before anything else is requested or cleared)
+#define SVOXT_CHK(i, n, site) chk<CHECK>(i, n, counters, site)
     float4* __restrict__ terms = L.terms;
     // P list positions per round, formed by wavefronts W - P .. W - 1 (pw = the wavefront's position in the round);
     // wavefront 0 only runs along the rays.  (r03: with P = W wavefront 0 also formed the terms of a position
@@ -894,6 +901,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
     maxn = __builtin_amdgcn_readfirstlane(maxn);             // everything that decides barriers is scalar
     if (maxn == 0) return;                                   // the same in every wavefront of the workgroup
+    if constexpr (CHECK) { if (threadIdx.x == 0) atomicAdd(counters + kChkBase + 29, 1ull); }    // (tiles this instance worked on)
 
     Ray r;
     float basis[NB > 0 ? NB : 1];
@@ -948,7 +956,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         constexpr int D1 = 3;
         float4 tq0 = make_float4(0.f, 0.f, 0.f, 0.f), tq1 = tq0, tq2 = tq0;
         auto terms_at = [&](int k) {
-            const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
+            const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 2);
             return terms[TERMS == 2 ? terms_index(blk, lane, k) : terms_index_pm(blk, lane, k)];
         };
         if constexpr (TERMS >= 2) {
@@ -965,7 +973,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             // rec_block_u must be the same in all lanes.
             const float4 tv_cur = tq;
             if (pw >= 0 && rd < nr1 && k < nrec) {
-                const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
+                const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 2);
                 float att, ex[C];                             // exp(-x_c): sigmoid_d(x) = 1.0 / (1.0 + double(exp(-x)))
                 if constexpr (TERMS >= 2) {
                     const float4 tv = tv_cur;
@@ -973,7 +981,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 } else {
                     const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
                     float row[K];
-                    load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
+                    load_row<K>(tr.features + (int64_t)SVOXT_CHK((int32_t)e.x, tr.M, 6) * K, row);
                     att = pexpf<true>(-__uint_as_float(e.y) * row[K - 1] * r.delta_scale);
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
@@ -994,7 +1002,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 float total_color = 0.f;
 #pragma unroll
                 for (int c = 0; c < C; ++c) total_color += (float)(1.0 / (1.0 + (double)ex[c])) * g[c];
-                const int sl = ((rd & 1) * P + pw) * 64 + lane;
+                const int sl = SVOXT_CHK(((rd & 1) * P + pw) * 64 + lane, R, 0);
                 r_w[sl] = att; r_sg[sl] = total_color;
             }
             // (unconditional, at a clamped position, and behind the last use of the set it refills: no merge of old and
@@ -1005,7 +1013,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 float av[P], tv[P];
 #pragma unroll
                 for (int j = 0; j < P; ++j) {
-                    const int sl = (((rd - 1) & 1) * P + j) * 64 + lane;
+                    const int sl = SVOXT_CHK((((rd - 1) & 1) * P + j) * 64 + lane, R, 1);
                     av[j] = r_w[sl]; tv[j] = r_sg[sl];
                 }
 #pragma unroll
@@ -1050,7 +1058,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     float4 uq0 = make_float4(0.f, 0.f, 0.f, 0.f), uq1 = uq0;
     auto request = [&](int k, uint2& eq, float4& uq) {
         k = min(max(k, 0), maxn - 1);                             // (a position some ray of the tile has: its block exists)
-        const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
+        const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 2);
         eq = rec_get(L.rec + rec_index_in(blk, lane, k));
         uq = terms[TERMS == 2 ? terms_index(blk, lane, k) : terms_index_pm(blk, lane, k)];
     };
@@ -1083,8 +1091,8 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             unsigned long long mym = 0ull;
 #pragma unroll
             for (int j = 0; j < P; ++j) { if (j == pw) { myb = basep[j]; mym = maskp[j]; } }      // (pw is scalar)
-            const int slot = nslot + myb + (int)__popcll(mym & lane_lt);
-            const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
+            const int slot = SVOXT_CHK(nslot + myb + (int)__popcll(mym & lane_lt), R, 3);
+            const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 2);
             if constexpr (!PRE) e = rec_get(L.rec + rec_index_in(blk, lane, k));
             float att, tc, cf[C];
             if constexpr (EXACT && TERMS != 0) {
@@ -1105,16 +1113,17 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 }
             } else {
                 float row[K];
-                load_row<K>(tr.features + (int64_t)(int32_t)e.x * K, row);
+                load_row<K>(tr.features + (int64_t)SVOXT_CHK((int32_t)e.x, tr.M, 6) * K, row);
                 sample_terms<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, att, tc, cf);
             }
-            const int32_t idx = (int32_t)e.x;
+            const int32_t idx = SVOXT_CHK((int32_t)e.x, tr.M, 6);
             uint32_t h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
             while (true) {
                 const int32_t old = atomicCAS(keys + h, -1, idx);
                 if (old == -1 || old == idx) break;
                 h = (h + 1u) & (uint32_t)(T - 1);
             }
+            h = (uint32_t)SVOXT_CHK((int)h, T, 4);
             atomicAdd(cnt + h, 1);
             r_sl[slot] = (h << 6) | (uint32_t)lane;
             r_w[slot] = att; r_sg[slot] = tc; r_dt[slot] = __uint_as_float(e.y);
@@ -1132,6 +1141,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 #pragma unroll
             for (int j = 0; j < P; ++j) {
                 sl[j] = nslot + basep[j] + (int)__popcll(maskp[j] & lane_lt);
+                if (kb + j < nrec) sl[j] = SVOXT_CHK(sl[j], R, 5);
                 av[j] = 1.f; tv[j] = 0.f; dv[j] = 0.f;
                 if (kb + j < nrec) { av[j] = r_w[sl[j]]; tv[j] = r_sg[sl[j]]; dv[j] = r_dt[sl[j]]; }
             }
@@ -1177,6 +1187,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
         lds_barrier();
     }
+#undef SVOXT_CHK
 }
 
 // The backward of an image for RGBA-style rows of 8 / 16 / 32 floats (C = K - 1 = 7 / 15 / 31
@@ -1211,13 +1222,18 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 // (r03: every barrier of this kernel is lds_barrier() -- its phases hand over through LDS alone, the hand-over
 // between the sweeps through memory is written and read by the same lane -- so the gradient atomics and the
 // hand-over stores stay in flight across them.)
-template <int K, bool FAST = false, bool COUNT = false>
+// CHECK (svoxt_set_bwd_check; r04): as for grad_fused_kernel; the sites of this kernel: 16 a list block outside the
+// pool, 17 sweep 1's compacted position, 18 a compacted record's slot, 19 a feature row outside the table, 20 sweep
+// 2's table entry, 21 the list of occupied entries, 22 a record's place in the sorted order, 23 an occupied entry
+// read by the reduce, 24 a sorted record read by the reduce, 25 the row a sum is sent to.
+template <int K, bool FAST = false, bool COUNT = false, bool CHECK = false>
 __global__ void __launch_bounds__(512, FAST ? 8 : 6)
 grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                  RecLists L, const uint4* __restrict__ aux, float* __restrict__ grad, int gstride,
                  unsigned long long* __restrict__ counters = nullptr) {
     static_assert(K == 8 || K == 16 || K == 32, "row widths with an instance");
     if (tile_never_recorded(L, blockIdx.x)) return;          // (r03: before anything else is requested)
+#define SVOXT_CHK(i, n, site) chk<CHECK>(i, n, counters, site)
     constexpr int C = K - 1, W = 8, NT = 64 * W, T = 1024, R = 1024, RPP = R / (64 * W);
     constexpr int KG = K | 1;                                // odd stride: conflict-free gradient rows
     constexpr int SPW = 64 / K;                              // distinct rows a wavefront reduces at a time
@@ -1244,6 +1260,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
     for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
     maxn = __builtin_amdgcn_readfirstlane(maxn);             // everything that decides barriers is scalar
     if (maxn == 0) return;                                   // the same in every wavefront of the workgroup
+    if constexpr (CHECK) { if (threadIdx.x == 0) atomicAdd(counters + kChkBase + 29, 1ull); }    // (tiles this instance worked on)
 
     float ds = 0.f, g_sig = 0.f;
     if (nrec > 0) {
@@ -1272,7 +1289,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                 const int k = k0 + rd * W + wave;
                 have[rd] = k < nrec;
                 e[rd] = make_uint2(0u, 0u);
-                if (have[rd]) e[rd] = rec_get(L.rec + rec_index_in(rec_block_u(L, tabreg, blockIdx.x, k >> 3), lane, k));
+                if (have[rd]) e[rd] = rec_get(L.rec + rec_index_in(SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 16), lane, k));
             }
 #pragma unroll
             for (int rd = 0; rd < RPP; ++rd) {
@@ -1285,7 +1302,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                         const int slot = (rd * W + wave) * 64 + lane;
                         r_sl[slot] = e[rd].x;
                         r_dt[slot] = __uint_as_float(e[rd].y);
-                        order[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)slot;
+                        order[SVOXT_CHK(base + (int)__popcll(m & ((1ull << lane) - 1ull)), R, 17)] = (uint16_t)slot;
                     }
                 }
             }
@@ -1300,7 +1317,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
         for (int p0 = wave * (64 / G); p0 < nb1; p0 += NT / G) {      // (scalar bounds: every lane takes part in the shuffles)
             const int p = p0 + (lane / G);
             const bool on = p < nb1;
-            const int slot = on ? (int)order[p] : 0;
+            const int slot = on ? SVOXT_CHK((int)order[SVOXT_CHK(p, R, 17)], R, 18) : 0;
             const int ray = slot & 63;
             float row[8];
             if constexpr (FAST) {
@@ -1309,7 +1326,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                 // lane with the float and the double sum), one float serves both passes' total_color
                 float part = 0.f;
                 if (on) {
-                    load_row<8>(tr.features + (int64_t)(int32_t)r_sl[slot] * K + 8 * gq, row);
+                    load_row<8>(tr.features + (int64_t)SVOXT_CHK((int32_t)r_sl[slot], tr.M, 19) * K + 8 * gq, row);
                     const float* __restrict__ gr = gl + ray * KG + 8 * gq;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -1327,7 +1344,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
             float a1[8];
             double a2[8];
             if (on) {
-                load_row<8>(tr.features + (int64_t)(int32_t)r_sl[slot] * K + 8 * gq, row);
+                load_row<8>(tr.features + (int64_t)SVOXT_CHK((int32_t)r_sl[slot], tr.M, 19) * K + 8 * gq, row);
                 const float* __restrict__ gr = gl + ray * KG + 8 * gq;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -1371,7 +1388,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
         for (int rd = 0; rd < RPP; ++rd) {
             const int k = k0 + rd * W + wave;
             if (k < nrec) {
-                const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
+                const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 16);
                 const int sl = (rd * W + wave) * 64 + lane;
                 tot2[terms_index_pm(blk, lane, k)] = make_float2(r_w[sl], r_sg[sl]);
             }
@@ -1425,7 +1442,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                 e[rd] = make_uint2(0u, 0u);
                 h[rd] = make_float2(0.f, 0.f);
                 if (have[rd]) {
-                    const int64_t blk = rec_block_u(L, tabreg, blockIdx.x, k >> 3);
+                    const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 16);
                     e[rd] = rec_get(L.rec + rec_index_in(blk, lane, k));
                     h[rd] = tot2[terms_index_pm(blk, lane, k)];
                 }
@@ -1433,13 +1450,14 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
 #pragma unroll
             for (int rd = 0; rd < RPP; ++rd) {
                 if (have[rd]) {
-                    const int32_t idx = (int32_t)e[rd].x;
+                    const int32_t idx = SVOXT_CHK((int32_t)e[rd].x, tr.M, 19);
                     uint32_t h32 = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));
                     while (true) {
                         const int32_t old = atomicCAS(keys + h32, -1, idx);
                         if (old == -1 || old == idx) break;
                         h32 = (h32 + 1u) & (uint32_t)(T - 1);
                     }
+                    h32 = (uint32_t)SVOXT_CHK((int)h32, T, 20);
                     atomicAdd(cnt + h32, 1);
                     const int slot = (rd * W + wave) * 64 + lane;
                     r_sl[slot] = (h32 << 6) | (uint32_t)lane;
@@ -1487,7 +1505,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
             for (int j2 = 0; j2 < PER; ++j2) {
                 cnt[lane * PER + j2] = run;
                 run += mine[j2];
-                if (mine[j2] > 0) slots[urun++] = (uint16_t)(lane * PER + j2);
+                if (mine[j2] > 0) slots[SVOXT_CHK(urun++, T, 21)] = (uint16_t)(lane * PER + j2);
             }
             if (lane == 63) { s_nb = incl; s_ns = uincl; }
         }
@@ -1495,7 +1513,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
         for (int rr = threadIdx.x; rr < R; rr += NT) {
             const uint32_t v = r_sl[rr];
             if (v != 0xffffffffu) {
-                const int pos = atomicAdd(cnt + (v >> 6), 1);
+                const int pos = SVOXT_CHK(atomicAdd(cnt + SVOXT_CHK((int)(v >> 6), T, 20), 1), R, 22);
                 r_t1[pos] = r_w[rr];                         // (r_dt was consumed by the chain above)
                 r_dt[pos] = r_sg[rr];
                 s_ray[pos] = (uint8_t)(v & 63u);
@@ -1503,7 +1521,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
         }
         lds_barrier();
         // ---- reduce: lane = column; after the scatter cnt[h] is where the records of entry h END
-        const int ns = __builtin_amdgcn_readfirstlane(s_ns);
+        const int ns = SVOXT_CHK(__builtin_amdgcn_readfirstlane(s_ns), T + 1, 21);
         if constexpr (COUNT) {
             if (threadIdx.x == 0 && ns > 0) {
                 atomicAdd(counters, (unsigned long long)ns * (K * 4 > 64 ? (K * 4) / 64 : 1));
@@ -1521,11 +1539,12 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                 const int i = i0 + u * W * SPW + sub;
                 idxs[u] = -1; ps[u] = 0; pes[u] = 0; xs[u] = 0.f;
                 if (i < ns) {
-                    const int h = (int)slots[i];
-                    idxs[u] = keys[h];
-                    pes[u] = cnt[h];
+                    const int h = SVOXT_CHK((int)slots[i], T, 23);
+                    idxs[u] = SVOXT_CHK(keys[h], tr.M, 25);
+                    pes[u] = SVOXT_CHK(cnt[h], R + 1, 24);
                     // the entry's records start where the previous occupied entry's end (table order = sorted order)
-                    if (i > 0) ps[u] = cnt[(int)slots[i - 1]];
+                    if (i > 0) ps[u] = SVOXT_CHK(cnt[SVOXT_CHK((int)slots[i - 1], T, 23)], R + 1, 24);
+                    if constexpr (CHECK) { if (ps[u] > pes[u]) { atomicAdd(counters + kChkBase + 24, 1ull); ps[u] = pes[u]; } }
                     xs[u] = tr.features[(int64_t)idxs[u] * K + col];
                 }
             }
@@ -1560,6 +1579,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
         for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
         lds_barrier();
     }
+#undef SVOXT_CHK
 }
 
 // Generic backward: any K / format / component range / channel count

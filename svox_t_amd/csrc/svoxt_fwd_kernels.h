@@ -310,12 +310,16 @@ sigma_mask_kernel(const float* __restrict__ features, int64_t M, int K, float th
 // The march of ONE tile by one wavefront (lane = threadIdx.x & 63); rstage / ltab: this wavefront's LDS
 // staging ([kRecBlock * 64] records) and block table ([kMaxRecBlocks]).
 // Returns what the lane left in aux[q].x (list length | overflow flag); 0 for a lane without a ray or without samples.
-template <bool N2, bool STOP, int ACC, bool MASK>
+// CSUM: *csum <- XOR of rec_hash over the records this lane wrote (tile_checksum_part folds the lanes; fwd_roles_kernel).
+template <bool N2, bool STOP, int ACC, bool MASK, bool CSUM = false>
 __device__ __forceinline__ uint32_t march_rec_tile(const TreeDev& tr, const RaysDev& rays, const Opts& opt, const RecLists& L,
                                                    uint4* __restrict__ aux, const uint32_t* __restrict__ sigma_mask,
-                                                   int64_t tile, uint2* __restrict__ rstage, int32_t* __restrict__ ltab) {
+                                                   int64_t tile, uint2* __restrict__ rstage, int32_t* __restrict__ ltab,
+                                                   uint32_t* csum = nullptr) {
     static_assert(!(MASK && STOP), "the stop rule needs sigma itself");
     const int lane = (int)(threadIdx.x & 63);
+    uint32_t cs = 0u;
+    if constexpr (CSUM) *csum = 0u;
     rec_tab_init(ltab);
     const int S = L.S;
     int64_t cur_block = 0;
@@ -364,6 +368,7 @@ __device__ __forceinline__ uint32_t march_rec_tile(const TreeDev& tr, const Rays
             }
             if (room) {
                 rec_stage_put(rstage, lane, L.rec, cur_block, nrec, (uint32_t)p_idx, p_dt);
+                if constexpr (CSUM) cs ^= rec_hash(nrec, (uint32_t)p_idx, __float_as_uint(p_dt));
                 ++nrec;
                 if constexpr (STOP) {
                     light *= pexpf(-p_dt * r.delta_scale * p_sigma);
@@ -394,6 +399,7 @@ __device__ __forceinline__ uint32_t march_rec_tile(const TreeDev& tr, const Rays
         }
         if (room) {
             rec_stage_put(rstage, lane, L.rec, cur_block, nrec, (uint32_t)p_idx, p_dt);
+            if constexpr (CSUM) cs ^= rec_hash(nrec, (uint32_t)p_idx, __float_as_uint(p_dt));
             ++nrec;
         } else {
             over = kRecOverflow;
@@ -402,6 +408,7 @@ __device__ __forceinline__ uint32_t march_rec_tile(const TreeDev& tr, const Rays
     }
     rec_stage_finish(rstage, lane, L.rec, cur_block, nrec);
     aux[q] = make_uint4((uint32_t)nrec | over, __float_as_uint(t_resume), __float_as_uint(1.f), 0u);
+    if constexpr (CSUM) *csum = cs;
     return (uint32_t)nrec | over;
 }
 
@@ -423,10 +430,15 @@ march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
 constexpr int kShadeP = 7;                       // list positions per round: one per wavefront but the first
 typedef float shade_v4f __attribute__((ext_vector_type(4)));
 // LOBES (FMT_SH instances): the basis values are those of opt.format = SG or ASG with BD lobes (precalc_lobes).
+// COH also: returns this wavefront's part of the tile's checksum (tile_checksum_part) over what it LOADED -- list
+// lengths, records -- for the caller to compare with the march's; what it loads is made harmless first (a block id
+// inside the pool, a row inside the table), so that a stale line costs a re-shade by the fallback launch, never a
+// fault; `stale_test`: (test only) treat the first record of every ray as if a stale line had been read.
 template <int FMT, int BD, bool XF, bool STOP, bool WTERMS, bool COH, bool LOBES = false>
-__device__ __forceinline__ void shade_tile_body(const TreeDev& tr, const RaysDev& rays, const Opts& opt, const RecLists& L,
-                                                uint4* __restrict__ aux, float* __restrict__ out, int64_t tile,
-                                                shade_v4f (*terms)[kShadeP][64] /* [2]: (att, e_0, e_1, e_2) of a list position, per ray */) {
+__device__ __forceinline__ uint32_t shade_tile_body(const TreeDev& tr, const RaysDev& rays, const Opts& opt, const RecLists& L,
+                                                    uint4* __restrict__ aux, float* __restrict__ out, int64_t tile,
+                                                    shade_v4f (*terms)[kShadeP][64] /* [2]: (att, e_0, e_1, e_2) of a list position, per ray */,
+                                                    bool stale_test = false) {
     constexpr int C = 3, W = 8, P = kShadeP;
     static_assert(P == W - 1, "one wavefront runs along the rays");
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
@@ -438,12 +450,14 @@ __device__ __forceinline__ void shade_tile_body(const TreeDev& tr, const RaysDev
     // (only the count lives through the rounds; wavefront 0 reads the entry again when it finalises the ray)
     uint32_t a_x = 0u;
     if (inb) a_x = COH ? aux_get_coherent(aux + q).x : aux[q].x;
-    const int nrec = (int)(a_x & ~kRecOverflow);
+    int nrec = (int)(a_x & ~kRecOverflow);
+    if constexpr (COH) nrec = min(nrec, L.S);        // (a stale count must not run the loops away)
     int maxn = nrec;
     for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
     maxn = __builtin_amdgcn_readfirstlane(maxn);     // what decides the barrier count is scalar
     const int nround = (maxn + P - 1) / P;           // the same in every wavefront of the workgroup
     const int32_t tabreg = rec_tab_reg<COH>(L, tile, lane);
+    uint32_t cs = 0u;                                // COH: XOR of rec_hash over the records this lane loaded
 
     float delta_scale = 0.f;
     float basis[NB];
@@ -465,8 +479,14 @@ __device__ __forceinline__ void shade_tile_body(const TreeDev& tr, const RaysDev
         if (wave > 0) {
             const int k = rd * P + (wave - 1);
             if (rd < nround && k < nrec) {
-                const int64_t blk = rec_block_u(L, tabreg, tile, k >> 3);
-                const uint2 e = COH ? rec_get_coherent(L.rec + rec_index_in(blk, lane, k)) : rec_get(L.rec + rec_index_in(blk, lane, k));
+                int64_t blk = rec_block_u(L, tabreg, tile, k >> 3);
+                if constexpr (COH) blk = min(max(blk, (int64_t)0), L.pool_blocks - 1);
+                uint2 e = COH ? rec_get_coherent(L.rec + rec_index_in(blk, lane, k)) : rec_get(L.rec + rec_index_in(blk, lane, k));
+                if constexpr (COH) {
+                    if (stale_test && k == 0) e.x ^= 1u;
+                    cs ^= rec_hash(k, e.x, e.y);
+                    e.x = min(e.x, (uint32_t)(tr.M - 1));
+                }
                 const int32_t idx = (int32_t)e.x;
                 float row[K];
                 load_row<K>(tr.features + (int64_t)idx * K, row);
@@ -511,15 +531,17 @@ __device__ __forceinline__ void shade_tile_body(const TreeDev& tr, const RaysDev
         lds_barrier();       // (the rounds hand over through LDS alone: the hand-over stores to memory stay in flight)
     }
     if (wave == 0 && inb) {
-        uint4 a = COH ? aux_get_coherent(aux + q) : aux[q];
+        // (the entry's other words stay as the march wrote them: only what the shade adds is stored -- a shade that
+        // read a stale list length must not write it back)
+        uint32_t* aw = reinterpret_cast<uint32_t*>(aux + q);
         float* o = out + q * (C + 1);
         if (stopped) {
             const float scale = (float)(1.0 / (1.0 - (double)light));
 #pragma unroll
             for (int j = 0; j < C; ++j) o[j] = acc[j] * scale;
             o[C] = 1.f - light;
-            a.x &= ~kRecOverflow;                    // nothing left for the tail launch
-        } else if (a.x & kRecOverflow) {             // state for render_fwd_kernel<..., RESUME>
+            aw[0] = a_x & ~kRecOverflow;             // nothing left for the tail launch
+        } else if (a_x & kRecOverflow) {             // state for render_fwd_kernel<..., RESUME>
 #pragma unroll
             for (int j = 0; j < C; ++j) o[j] = acc[j];
             o[C] = light;
@@ -529,11 +551,31 @@ __device__ __forceinline__ void shade_tile_body(const TreeDev& tr, const RaysDev
             for (int j = 0; j < C; ++j) o[j] = acc[j] + bg;
             o[C] = 1.f - light;
         }
-        a.z = __float_as_uint(light);                // the final transmittance, for the single-march backward
-        aux[q] = a;
+        aw[2] = __float_as_uint(light);              // the final transmittance, for the single-march backward
     }
+    if constexpr (COH) return tile_checksum_part(cs, wave == 1 ? a_x : 0u, lane);
+    else return 0u;
 }
 
+// (r04) A queue entry is 64 bits, written and read whole: the tile id (| kTileEmpty) below, the checksum of the tile's
+// lists as the march wrote them above (rec_hash / tile_checksum_part).  The shading workgroup folds what it LOADED the
+// same way; a tile whose checksum does not match is not marked shaded, so the fallback launch shades it again from
+// memory the kernel boundary has made visible: a stale read -- which this hand-over excludes by measured cache
+// behaviour, not by the memory model (below) -- costs a re-shade instead of wrong pixels, lists' hand-over and gradients.
+// Counters at words [ntiles_even + 256, + 264) of tile_state (value + 1: the fill leaves -1): tiles shaded in the launch,
+// checksum mismatches, workgroups whose poll ran out, tiles dropped by the test flag, tiles the fallback launch shaded.
+constexpr int kRolePolls = 20000;
+constexpr int64_t kTileEmpty = 1 << 30;          // queue entry tile | kTileEmpty: no ray of the tile has a sample and its pixels are written
+constexpr int kRoleXcds = 8;
+__host__ __device__ inline int64_t roles_even(int64_t tiles) { return (tiles + 1) & ~(int64_t)1; }   // (the 64-bit queue entries behind it stay aligned)
+__host__ __device__ inline int64_t roles_state_words(int64_t tiles) { return roles_even(tiles) + 16 * 32 + (int64_t)kRoleXcds * 2 * tiles; }
+__device__ __forceinline__ int my_xcc() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (kRoleXcds - 1)); }   // HW_REG_XCC_ID, bits 3:0
+enum { kRoleCtrShaded = 256, kRoleCtrMismatch = 257, kRoleCtrGaveUp = 258, kRoleCtrDropped = 259, kRoleCtrFallback = 260 };
+// test-only behaviour of the shading workgroups (svoxt_sample_lists.flags >> 8: SVOXT_LISTS_TEST_*) and the fence form
+enum { kRoleTestDrop = 1, kRoleTestNoPoll = 2, kRoleTestStale = 4, kRoleAgentFence = 8 };
+
+// The marching wavefront's side: every store of the wavefront (records, block table, aux) acknowledged by the L2
+// first, then a position from the queue's tail counter and the tile id into that entry.
 // tile_state (optional): tiles whose entry is kTileShaded were shaded inside fwd_roles_kernel -- nothing to do
 constexpr int32_t kTileShaded = 0x200;
 template <int FMT, int BD, bool XF, bool STOP, bool WTERMS = false, bool LOBES = false>
@@ -545,6 +587,8 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
     const int64_t tile = (int64_t)blockIdx.x + rays.tile0;
     if (tile_state != nullptr && tile_state[tile] == kTileShaded) return;       // (uniform: one tile per workgroup)
     shade_tile_body<FMT, BD, XF, STOP, WTERMS, false, LOBES>(tr, rays, opt, L, aux, out, tile, terms);
+    if (tile_state != nullptr && threadIdx.x == 0)                              // (fallback of fwd_roles_kernel: counted)
+        atomicAdd(const_cast<int32_t*>(tile_state) + roles_even(gridDim.x + rays.tile0) + kRoleCtrFallback, 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -578,54 +622,67 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
 // tile_state is shaded by the fallback launch that follows (shade_tile_kernel with tile_state) -- slower,
 // never wrong.  Same lists, terms and pixels bit for bit: the same device functions do the work.
 //
-// tile_state layout (int32, all -1 before the launch: lists_begin's fill): [0, T) per-tile state; then 16
-// counter slots of 32 words (a queue's tail at +0, its head at +16: 64 bytes apart; "next position" - 1, like
-// the block pool's counters); then 8 queues of T entries.
-constexpr int kRolePolls = 20000;
-constexpr int64_t kTileEmpty = 1 << 30;          // queue entry tile | kTileEmpty: no ray of the tile has a sample and its pixels are written
-constexpr int kRoleXcds = 8;
-__host__ __device__ inline int64_t roles_state_words(int64_t tiles) { return tiles + 16 * 32 + (int64_t)kRoleXcds * tiles; }
-__device__ __forceinline__ int my_xcc() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (kRoleXcds - 1)); }   // HW_REG_XCC_ID, bits 3:0
-
-// The marching wavefront's side: every store of the wavefront (records, block table, aux) acknowledged by the L2
-// first, then a position from the queue's tail counter and the tile id into that entry.
-__device__ __forceinline__ void publish_tile(int32_t* __restrict__ tile_state, int ntiles, int64_t tile) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
+// tile_state layout (int32, all -1 before the launch: lists_begin's fill): [0, T) per-tile state (T rounded up to
+// even); then 16 counter slots of 32 words (slot x < 8: queue x's tail at +0, its head at +16: 64 bytes apart; "next
+// position" - 1, like the block pool's counters; slot 8: the kRoleCtr* counters); then 8 queues of T 64-bit entries.
+// What makes the lists visible to the consumer (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup
+// visibility"): the wavefront's own stores are waited for -- asm volatile, which no compiler pass removes or moves: the
+// guide's "Compiler hazard" -- so they have reached the L2 of the XCD this wavefront runs on; the queue is that XCD's
+// (HW_REG_XCC_ID on both sides), so the consumer's CU sits behind the SAME L2, and every load of the handed-over bytes
+// on its side is a global_load ... sc1 (never served by its own vector cache).  That is the guide's "sc1 loads in place
+// of the acquire" with plain / nt producer stores, which the guide lists as valid only for sc1 (write-through) stores:
+// the difference is cross-XCD visibility, which this hand-over never needs.  It remains measured behaviour, not an
+// architectural guarantee -- hence the checksum.  agent_fence (test / measurement: SVOXT_LISTS_FWD_AGENT_FENCE) adds the
+// guide's valid form in full: release fence at agent scope (buffer_wbl2 sc1) before the entry is stored, acquire fence
+// (buffer_inv sc1) on the consumer before its first load.
+__device__ __forceinline__ void publish_tile(int32_t* __restrict__ tile_state, int ntiles, int64_t tile, uint32_t csum,
+                                             bool agent_fence) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (agent_fence) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if ((threadIdx.x & 63) == 0) {
         const int xcc = my_xcc();
-        int32_t* ctr = tile_state + ntiles + xcc * 32;
-        int32_t* queue = tile_state + ntiles + 16 * 32 + (int64_t)xcc * ntiles;
+        const int64_t base = roles_even(ntiles);
+        int32_t* ctr = tile_state + base + xcc * 32;
+        unsigned long long* queue = reinterpret_cast<unsigned long long*>(tile_state + base + 16 * 32) + (int64_t)xcc * ntiles;
         const int pos = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-        __hip_atomic_store(queue + pos, (int32_t)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(queue + pos, (unsigned long long)(uint32_t)tile | ((unsigned long long)csum << 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-// The shading workgroup's side (thread 0): the next tile of the queue of the XCD it runs on, or -1.
-__device__ __forceinline__ int32_t pop_tile(int32_t* __restrict__ tile_state, int ntiles) {
+// The shading workgroup's side (thread 0): the next entry of the queue of the XCD it runs on, or ~0 (nothing arrived).
+__device__ __forceinline__ unsigned long long pop_tile(int32_t* __restrict__ tile_state, int ntiles, int polls) {
     const int xcc = my_xcc();
-    int32_t* ctr = tile_state + ntiles + xcc * 32;
-    int32_t* queue = tile_state + ntiles + 16 * 32 + (int64_t)xcc * ntiles;
-    int32_t tile = -1;
+    const int64_t base = roles_even(ntiles);
+    int32_t* ctr = tile_state + base + xcc * 32;
+    unsigned long long* queue = reinterpret_cast<unsigned long long*>(tile_state + base + 16 * 32) + (int64_t)xcc * ntiles;
+    unsigned long long ent = ~0ull;
     const int idx = __hip_atomic_fetch_add(ctr + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     if (idx < ntiles) {
-        for (int p = 0; p < kRolePolls; ++p) {
-            tile = __hip_atomic_load(queue + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tile != -1) break;
+        for (int p = 0; p < polls; ++p) {
+            ent = __hip_atomic_load(queue + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ent != ~0ull) break;
             __builtin_amdgcn_s_sleep(16);
         }
     }
-    return tile;
+    return ent;
 }
 
 template <int FMT, int BD, int ACC, bool WTERMS, bool LOBES = false>
 __global__ void __launch_bounds__(512)
 fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux, float* __restrict__ out,
-                 const uint32_t* __restrict__ sigma_mask, int32_t* __restrict__ tile_state, int n_march, int ntiles) {
+                 const uint32_t* __restrict__ sigma_mask, int32_t* __restrict__ tile_state, int n_march, int ntiles,
+                 int tflags /* kRoleTest* | kRoleAgentFence: 0 in production */) {
     constexpr int kMarchBytes = 8 * (kRecBlock * 64 * (int)sizeof(uint2) + kMaxRecBlocks * (int)sizeof(int32_t));
     constexpr int kShadeBytes = 2 * kShadeP * 64 * (int)sizeof(shade_v4f);
     __shared__ __attribute__((aligned(16))) unsigned char lds[kMarchBytes > kShadeBytes ? kMarchBytes : kShadeBytes];
-    __shared__ int s_tile;
+    __shared__ unsigned long long s_ent;
+    __shared__ uint32_t s_part[8];
     const int wave = threadIdx.x >> 6;
+    const bool agent_fence = (tflags & kRoleAgentFence) != 0;
+    int32_t* const ctrs = tile_state + roles_even(ntiles);
     if ((int)blockIdx.x < n_march) {
         const int64_t tile = (int64_t)blockIdx.x * 8 + wave;
         if (tile >= ntiles) return;
@@ -634,7 +691,8 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
         // the kernel is as long as its longest march plus that tile's shade: the marching wavefronts' few
         // instructions per crossing go ahead of the shading wavefronts' many (issue priority 3 of 0..3)
         __builtin_amdgcn_s_setprio(3);
-        const uint32_t ax = march_rec_tile<true, false, ACC, true>(tr, rays, opt, L, aux, sigma_mask, tile, rstage, ltab);
+        uint32_t cs_lane;
+        const uint32_t ax = march_rec_tile<true, false, ACC, true, true>(tr, rays, opt, L, aux, sigma_mask, tile, rstage, ltab, &cs_lane);
         // Two tiles in three have no sample at all (800 x 800, depth-8 shell).  What the shade would leave for such a
         // tile -- the background in every pixel, by the operations shade_tile_body performs for a ray without records
         // (light = 1, acc = 0) -- the marching wavefront leaves itself, and the queue entry says so: the shading
@@ -654,7 +712,9 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
             }
             if ((threadIdx.x & 63) == 0) tile_state[tile] = kTileShaded;
         }
-        publish_tile(tile_state, ntiles, empty ? (tile | kTileEmpty) : tile);      // (the queue addresses are formed behind the march: nothing of them lives across it)
+        // (a lane without a ray, or whose ray misses the cube, returned ax = 0 and recorded nothing: it folds in as zero)
+        const uint32_t csum = empty ? 0u : tile_checksum_part(ax != 0u ? cs_lane : 0u, ax, (int)(threadIdx.x & 63));
+        publish_tile(tile_state, ntiles, empty ? (tile | kTileEmpty) : tile, csum, agent_fence);      // (the queue addresses are formed behind the march: nothing of them lives across it)
         return;
     }
     // is this shading workgroup one of those its XCD needs?  (see above; the same in every wavefront)
@@ -663,14 +723,36 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
     int mine = a < G ? 8 * ((G - a + 7) >> 3) : 0;
     if (((G - 1) & 7) == a) mine -= 8 * G - ntiles;              // the last march workgroup may be partial
     if (b >= mine) return;
-    if (threadIdx.x == 0) s_tile = pop_tile(tile_state, ntiles);
+    if (threadIdx.x == 0) s_ent = pop_tile(tile_state, ntiles, (tflags & kRoleTestNoPoll) ? 1 : kRolePolls);
     __syncthreads();
-    const int64_t tile = s_tile;
-    if (tile < 0 || tile >= ntiles) return;                      // nothing arrived: left to the fallback launch; or tile | kTileEmpty: finished by its march
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    shade_tile_body<FMT, BD, false, false, WTERMS, true, LOBES>(tr, rays, opt, L, aux, out, tile,
-                                                                 reinterpret_cast<shade_v4f (*)[kShadeP][64]>(lds));
-    if (threadIdx.x == 0) tile_state[tile] = kTileShaded;        // (read by the fallback launch: after this kernel)
+    const unsigned long long ent = s_ent;
+    if (ent == ~0ull) {                                          // nothing arrived: the tile this entry will name is left to the fallback launch
+        if (threadIdx.x == 0) atomicAdd(ctrs + kRoleCtrGaveUp, 1);
+        return;
+    }
+    const int64_t tile = (int64_t)(uint32_t)ent;
+    if (tile >= ntiles) return;                                  // tile | kTileEmpty: finished by its march
+    if ((tflags & kRoleTestDrop) && tile % 3 == 0) {             // (test: a consumer that takes its tile and does nothing)
+        if (threadIdx.x == 0) atomicAdd(ctrs + kRoleCtrDropped, 1);
+        return;
+    }
+    if (agent_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const uint32_t part = shade_tile_body<FMT, BD, false, false, WTERMS, true, LOBES>(
+        tr, rays, opt, L, aux, out, tile, reinterpret_cast<shade_v4f (*)[kShadeP][64]>(lds), (tflags & kRoleTestStale) && tile % 5 == 0);
+    // what this workgroup loaded, folded like the march folded what it wrote
+    if ((threadIdx.x & 63) == 0) s_part[wave] = part;
+    lds_barrier();
+    if (threadIdx.x == 0) {
+        uint32_t c = 0u;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) c ^= s_part[w];
+        if (c == (uint32_t)(ent >> 32)) {
+            tile_state[tile] = kTileShaded;                      // (read by the fallback launch: after this kernel)
+            atomicAdd(ctrs + kRoleCtrShaded, 1);
+        } else {
+            atomicAdd(ctrs + kRoleCtrMismatch, 1);               // stale (or, with the test flag, made to look so): the fallback launch shades it again
+        }
+    }
 }
 
 // The shade kernel for RGBA-style rows of K = 8, 16 or 32 floats (C = K - 1 feature channels and

@@ -189,7 +189,7 @@ bool launch_fwd_xform(const TreeDev& tr, const RaysDev& rays, const Opts& opt, i
 // (position-major: terms_state 3), and the per-tile backward over it -- the exact one-kernel form only.
 template <bool N2>
 bool launch_lobes_fwd_record(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out, RecLists L, uint4* aux,
-                             hipStream_t st, const uint32_t* sigma_mask, int32_t* tile_state) {
+                             hipStream_t st, const uint32_t* sigma_mask, int32_t* tile_state, int tflags = 0) {
     if (L.terms == nullptr || !lobes_payload(opt, tr.K)) return false;
     const unsigned nb = nblocks(rays.Q);
     const bool acc = N2 && tr.accel != nullptr;
@@ -201,7 +201,7 @@ bool launch_lobes_fwd_record(const TreeDev& tr, const RaysDev& rays, const Opts&
 #define SVOXT_LOBES_ROLES(BB)                                                                                       \
     {                                                                                                               \
         hipLaunchKernelGGL((fwd_roles_kernel<FMT_SH, BB, 1, true, true>), dim3(grid), dim3(512), 0, st,             \
-                           tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb);                   \
+                           tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags);           \
         hipLaunchKernelGGL((shade_tile_kernel<FMT_SH, BB, false, false, true, true>), dim3(nb), dim3(512), 0, st,   \
                            tr, rays, opt, L, aux, out, (const int32_t*)tile_state);                                 \
         hipLaunchKernelGGL((render_fwd_kernel<FMT_SH, 3, BB, true, false, false, true, true>), dim3(nb), dim3(kBlock), \
@@ -381,7 +381,7 @@ bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float
 // payloads of at most 28 floats on N = 2 trees, no view rotations, no stop rule, the sigma bitmask at hand.
 template <bool N2, bool STOP>
 bool launch_fwd_roles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out, RecLists L, uint4* aux,
-                      hipStream_t st, const uint32_t* sigma_mask, int32_t* tile_state) {
+                      hipStream_t st, const uint32_t* sigma_mask, int32_t* tile_state, int tflags) {
     if constexpr (!N2 || STOP) {
         return false;
     } else {
@@ -394,13 +394,13 @@ bool launch_fwd_roles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
 #define SVOXT_ROLES(F, BB)                                                                                        \
         {                                                                                                         \
             if (acc && wt) hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 1, true>), dim3(grid), dim3(512), 0, st,   \
-                                              tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb); \
+                                              tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags); \
             else if (acc) hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 1, false>), dim3(grid), dim3(512), 0, st,   \
-                                             tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb); \
+                                             tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags); \
             else if (wt) hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 0, true>), dim3(grid), dim3(512), 0, st,     \
-                                            tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb); \
+                                            tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags); \
             else hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 0, false>), dim3(grid), dim3(512), 0, st,            \
-                                    tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb);        \
+                                    tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags); \
             if (wt) hipLaunchKernelGGL((shade_tile_kernel<F, BB, false, false, true>), dim3(nb), dim3(512), 0, st, \
                                        tr, rays, opt, L, aux, out, (const int32_t*)tile_state);                   \
             else hipLaunchKernelGGL((shade_tile_kernel<F, BB, false, false, false>), dim3(nb), dim3(512), 0, st,  \
@@ -426,12 +426,12 @@ bool launch_fwd_roles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
 template <bool N2, bool STOP>
 bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out,
                       RecLists L, uint4* aux, bool xf, bool fast, hipStream_t st,
-                      const uint32_t* sigma_mask = nullptr, int32_t* tile_state = nullptr) {
+                      const uint32_t* sigma_mask = nullptr, int32_t* tile_state = nullptr, int tflags = 0) {
     const unsigned nb = nblocks(rays.Q);
     if (xf && !N2) return false;
     const bool acc = N2 && tr.accel != nullptr;
     if (tile_state != nullptr && sigma_mask != nullptr && !xf && !STOP &&
-        launch_fwd_roles<N2, STOP>(tr, rays, opt, out, L, aux, st, sigma_mask, tile_state))
+        launch_fwd_roles<N2, STOP>(tr, rays, opt, out, L, aux, st, sigma_mask, tile_state, tflags))
         return true;
     if constexpr (!STOP) {
         if (sigma_mask != nullptr) {
@@ -536,7 +536,7 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
         uint4* aux = reinterpret_cast<uint4*>(lists->aux);
         int32_t* states = (lists->blocktab != nullptr && !(lflags & SVOXT_LISTS_FWD_NO_OVERLAP))
                               ? reinterpret_cast<int32_t*>(lists->tile_state) : nullptr;
-        done = n2 ? launch_lobes_fwd_record<true>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, st, smask, states)
+        done = n2 ? launch_lobes_fwd_record<true>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, st, smask, states, (lflags >> 8) & 15)
                   : launch_lobes_fwd_record<false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, st, smask, nullptr);
         if (!done) return fail(SVOXT_ERR_UNSUPPORTED, "%s: no recording kernel for this SG / ASG payload", fn);
         return check_launch(fn);
@@ -553,7 +553,7 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
         };
         if (lists != nullptr) {
             uint4* aux = reinterpret_cast<uint4*>(lists->aux);
-            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, xf, fast, st, smask, states(lists))
+            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, xf, fast, st, smask, states(lists), (lflags >> 8) & 15)
                       : launch_fwd_split<false, false>(tr, rd, od, out, lists_dev(lists, rays->Q), aux, xf, fast, st, smask);
         } else if (scratch != nullptr && smask != nullptr && opt->stop_thresh == 0.f) {
             // With stop_thresh = 0 the stop rule ends a ray only once its transmittance is exactly 0; every
@@ -561,7 +561,7 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
             // outputs are the same without it, and the march needs no sigma value -- the bitmask will do.
             if ((rc = lists_begin(scratch, rays->Q, st, fn))) return rc;
             uint4* aux = reinterpret_cast<uint4*>(scratch->aux);
-            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, lists_dev(scratch, rays->Q), aux, xf, fast, st, smask, states(scratch))
+            done = n2 ? launch_fwd_split<true, false>(tr, rd, od, out, lists_dev(scratch, rays->Q), aux, xf, fast, st, smask, states(scratch), (lflags >> 8) & 15)
                       : launch_fwd_split<false, false>(tr, rd, od, out, lists_dev(scratch, rays->Q), aux, xf, fast, st, smask);
         } else if (scratch != nullptr) {      // caller-owned lists as scratch (dense or pooled): the stop rule applies
             if ((rc = lists_begin(scratch, rays->Q, st, fn))) return rc;

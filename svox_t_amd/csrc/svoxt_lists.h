@@ -223,6 +223,43 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// A checksum of a tile's lists as its march wrote them (r04): handed to the shading workgroup of fwd_roles_kernel with the
+// tile id, recomputed there from what that workgroup LOADED -- a stale line (the hand-over rests on measured cache
+// behaviour, not on the memory model: see fwd_roles_kernel) then shows as a mismatch and the tile is left to the
+// fallback launch instead of being shaded from wrong records.  XOR-linear, so that each wavefront of the consumer can
+// fold the records it loaded by itself: a record contributes rec_hash(k, row, delta_t) to its ray's word, the ray's
+// word (with its list length | overflow flag mixed in) is rotated by the ray's lane, all 64 are XORed.
+__device__ __forceinline__ uint32_t rec_hash(int k, uint32_t idx, uint32_t dt_bits) {
+    return __builtin_rotateleft32(idx, (uint32_t)k & 31u) ^ __builtin_rotateleft32(dt_bits, (uint32_t)(5 * k + 11) & 31u);
+}
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v ^= (uint32_t)__shfl_xor((int)v, off, 64);
+    return v;
+}
+// (the part of a tile's checksum that one wavefront holds: rays_xor = XOR of rec_hash over the records this lane
+// saw; ax = the ray's aux.x, given by ONE of the wavefronts that fold a tile, 0 by the others)
+__device__ __forceinline__ uint32_t tile_checksum_part(uint32_t rays_xor, uint32_t ax, int lane) {
+    return wave_xor(__builtin_rotateleft32(rays_xor ^ (ax * 0x9E3779B1u), (uint32_t)lane & 31u));
+}
+
+// CHECK instances of the per-tile backwards (svoxt_set_bwd_check; r04): every index into an LDS array, a private
+// array that is not unrolled away, the lists' block pool and the feature / gradient tables is compared with its
+// extent; a violation adds one to bad[site] and the index becomes 0, so that the checked run itself cannot leave its
+// arrays.  The production instances (CHECK = false) compile to the bare index: same code as without the call.
+constexpr int kChkBase = 2;              // words [0, 2) of the counter block are svoxt_set_bwd_counters'
+constexpr int kChkSites = 30;
+template <bool CHECK, typename I>
+__device__ __forceinline__ I chk(I i, int64_t n, unsigned long long* __restrict__ bad, int site) {
+    if constexpr (CHECK) {
+        if ((uint64_t)(int64_t)i >= (uint64_t)n) {
+            atomicAdd(bad + kChkBase + site, 1ull);
+            return (I)0;
+        }
+    }
+    return i;
+}
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_C.EXPORTS)          # the ctypes table and the header agree
-    assert lib.svoxt_abi_version() == _C.ABI_VERSION == 16
+    assert lib.svoxt_abi_version() == _C.ABI_VERSION == 17
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -77,14 +77,21 @@ def test_no_kernel_keeps_private_arrays_in_scratch_memory():
             worst[name] = sc
     # today: grad_wide_kernel (12 bytes in the exact instances at their 80-register budget, 32-40 in the
     # native-math ones at the 64 registers that let four workgroups share a CU: loop-invariant LDS addresses and
-    # pointers, written once in front of a sweep) and the COUNTING instances of grad_fused_kernel<SH9> (16-20 bytes;
-    # instrumentation).  Nothing above 48 bytes: the two GPU faults in this project's records both came with the
-    # first dispatch of a kernel that needed a much larger frame than anything before it (r02: 152 bytes, an
-    # experiment build; r03: 88 bytes, grad_fused_kernel<SH9> when its sort / reduce phase was a function with a
-    # dozen pointer parameters -- the same source as a textual include spills nothing).
+    # pointers, written once in front of a sweep) and the INSTRUMENTATION instances of grad_fused_kernel<SH9>
+    # (counting: 16-20 bytes; checked, r04: 8).  Nothing above 48 bytes, as a matter of speed (a spill that appears
+    # is a regression to remove) -- NOT because larger frames are known to be unsafe: the r03 fault came with the
+    # first dispatch of an 88-byte frame (grad_fused_kernel<SH9> when its sort / reduce phase was a function), and
+    # the ISA of that build, recreated in r04 (exp/fault_r03_recreate.sh, profiles/r04_fault_isa.txt), holds only
+    # compile-time-offset register spills, stored under a full EXEC mask: no private array in memory, no index that
+    # could leave it; the checked instances (tests/test_gpu_checked_backward.py) find no LDS / pool / table index
+    # out of range at any full-size geometry either.
     assert all(v <= 48 for v in worst.values()), worst
-    assert all(("grad_wide_kernel" in k) or ("grad_fused_kernel" in k and k.split("grad_fused_kernel")[1].startswith("ILi1ELi9ELb")
-                                             and "ELb1ELi0E" in k) for k in worst), worst
+    import re
+
+    def instrumentation(k):
+        m = re.search(r"grad_fused_kernelILi1ELi9ELb[01]ELb([01])ELi\dELb[01]ELb([01])E", k)
+        return m is not None and "1" in m.groups()
+    assert all(("grad_wide_kernel" in k) or instrumentation(k) for k in worst), worst
 
 
 def test_out_data_dim():

@@ -93,7 +93,10 @@ def _camera_worker(rank, world, port, n_cam, result_dir):
         c = Case(depth=4, K=4, data_format="RGBA", width=8, height=8)
         ot, opt = c.oracle_tree(), c.oracle_opts()
         W, H, fx = 12, 10, 16.0
-        poses = torch.stack([torch.from_numpy(synth.camera_pose(azimuth_deg=25.0 + 50.0 * k).astype(np.float32))
+        # n_cam == 8: the cameras of BASELINE configs[4] / SURVEY.md 8(d) config 5 (azimuth 30 + 45 k degrees),
+        # four per rank here (camera i on rank i % 2), one per rank on eight GPUs: the same gather layout
+        az = (lambda k: 30.0 + 45.0 * k) if n_cam == 8 else (lambda k: 25.0 + 50.0 * k)
+        poses = torch.stack([torch.from_numpy(synth.camera_pose(azimuth_deg=az(k)).astype(np.float32))
                              for k in range(n_cam)])
 
         def render_fn(features, c2w):        # the oracle's camera rays + the PyTorch oracle renderer
@@ -107,20 +110,23 @@ def _camera_worker(rank, world, port, n_cam, result_dir):
         f2 = torch.from_numpy(ot.features).double().requires_grad_(True)
         ref = torch.stack([render_fn(f2, poses[k]) for k in range(n_cam)])
         (ref * gout).sum().backward()
+        # every camera in ITS slot of the gathered [n_cam, H, W, C+1] (a permuted layout has equal max-norm overall)
+        slot_ok = all(torch.equal(full[k], ref[k]) for k in range(n_cam))
+        distinct = n_cam < 2 or not torch.equal(ref[0], ref[1])
         np.save(os.path.join(result_dir, f"cam{rank}.npy"), np.array([
             float((full - ref).abs().max()), float((feats.grad - f2.grad).abs().max()),
-            float(f2.grad.abs().max()), full.shape[0], float(ref[..., 3].max())]))
+            float(f2.grad.abs().max()), full.shape[0], float(ref[..., 3].max()), float(slot_ok and distinct)]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_cam", [2, 3, 1])      # one per rank, a ragged split, fewer cameras than ranks
+@pytest.mark.parametrize("n_cam", [2, 3, 1, 8])   # one per rank, a ragged split, fewer cameras than ranks, config 5's eight
 def test_render_cameras_two_ranks(tmp_path, n_cam):
     port = 31500 + (os.getpid() + n_cam) % 2000
     mp.spawn(_camera_worker, args=(2, port, n_cam, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
-        dout, dgrad, gmax, n, amax = np.load(tmp_path / f"cam{r}.npy")
-        assert n == n_cam and amax > 0.1
+        dout, dgrad, gmax, n, amax, slots = np.load(tmp_path / f"cam{r}.npy")
+        assert n == n_cam and amax > 0.1 and slots == 1.0
         assert dout == 0.0
         assert gmax > 0 and dgrad <= 1e-12 * max(gmax, 1.0)
 
