@@ -12,6 +12,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef SVOXT_ROLES_CSUM
+#define SVOXT_ROLES_CSUM 1               // 0 (exp/build_rev.sh ... -DSVOXT_ROLES_CSUM=0): no checksum is formed or compared -- what it costs
+#endif
+
 namespace svoxt {
 
 // The packed leaf id (node * N^3 + u * N^2 + v * N + w, common.cuh:90-93) of the crossing at t, for
@@ -319,7 +323,7 @@ __device__ __forceinline__ uint32_t march_rec_tile(const TreeDev& tr, const Rays
     static_assert(!(MASK && STOP), "the stop rule needs sigma itself");
     const int lane = (int)(threadIdx.x & 63);
     uint32_t cs = 0u;
-    if constexpr (CSUM) *csum = 0u;
+    if (csum != nullptr) *csum = 0u;
     rec_tab_init(ltab);
     const int S = L.S;
     int64_t cur_block = 0;
@@ -484,7 +488,7 @@ __device__ __forceinline__ uint32_t shade_tile_body(const TreeDev& tr, const Ray
                 uint2 e = COH ? rec_get_coherent(L.rec + rec_index_in(blk, lane, k)) : rec_get(L.rec + rec_index_in(blk, lane, k));
                 if constexpr (COH) {
                     if (stale_test && k == 0) e.x ^= 1u;
-                    cs ^= rec_hash(k, e.x, e.y);
+                    if constexpr (SVOXT_ROLES_CSUM != 0) cs ^= rec_hash(k, e.x, e.y);
                     e.x = min(e.x, (uint32_t)(tr.M - 1));
                 }
                 const int32_t idx = (int32_t)e.x;
@@ -553,7 +557,7 @@ __device__ __forceinline__ uint32_t shade_tile_body(const TreeDev& tr, const Ray
         }
         aw[2] = __float_as_uint(light);              // the final transmittance, for the single-march backward
     }
-    if constexpr (COH) return tile_checksum_part(cs, wave == 1 ? a_x : 0u, lane);
+    if constexpr (COH && SVOXT_ROLES_CSUM != 0) return tile_checksum_part(cs, wave == 1 ? a_x : 0u, lane);
     else return 0u;
 }
 
@@ -692,7 +696,7 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
         // instructions per crossing go ahead of the shading wavefronts' many (issue priority 3 of 0..3)
         __builtin_amdgcn_s_setprio(3);
         uint32_t cs_lane;
-        const uint32_t ax = march_rec_tile<true, false, ACC, true, true>(tr, rays, opt, L, aux, sigma_mask, tile, rstage, ltab, &cs_lane);
+        const uint32_t ax = march_rec_tile<true, false, ACC, true, SVOXT_ROLES_CSUM != 0>(tr, rays, opt, L, aux, sigma_mask, tile, rstage, ltab, &cs_lane);
         // Two tiles in three have no sample at all (800 x 800, depth-8 shell).  What the shade would leave for such a
         // tile -- the background in every pixel, by the operations shade_tile_body performs for a ray without records
         // (light = 1, acc = 0) -- the marching wavefront leaves itself, and the queue entry says so: the shading
@@ -713,7 +717,8 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
             if ((threadIdx.x & 63) == 0) tile_state[tile] = kTileShaded;
         }
         // (a lane without a ray, or whose ray misses the cube, returned ax = 0 and recorded nothing: it folds in as zero)
-        const uint32_t csum = empty ? 0u : tile_checksum_part(ax != 0u ? cs_lane : 0u, ax, (int)(threadIdx.x & 63));
+        uint32_t csum = 0u;
+        if constexpr (SVOXT_ROLES_CSUM != 0) csum = empty ? 0u : tile_checksum_part(ax != 0u ? cs_lane : 0u, ax, (int)(threadIdx.x & 63));
         publish_tile(tile_state, ntiles, empty ? (tile | kTileEmpty) : tile, csum, agent_fence);      // (the queue addresses are formed behind the march: nothing of them lives across it)
         return;
     }

@@ -55,7 +55,7 @@ def test_config5_eight_cameras_depth9_features32_one_rank(gpu, capsys):
             np.testing.assert_array_equal(got, want, err_msg=f"camera {k}")
         # the cameras differ (a layout that repeated one camera would pass the subsample of that camera only)
         assert not torch.equal(full[0], full[1]) and not torch.equal(full[3], full[7])
-        alpha = full[..., 31]
+        alpha = full.detach()[..., 31]
         assert float(alpha.min()) >= 0 and float(alpha.max()) <= 1 and float(alpha.mean()) > 0.05
         # ---- backward: the loss takes every camera; the oracle's gradient is the sum over the cameras
         gout = synth.grad_output(N_CAM * W * H, 32).reshape(N_CAM, H, W, 32)

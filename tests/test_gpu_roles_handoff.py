@@ -121,7 +121,8 @@ def test_rescue_path_reproduces_pixels_lists_and_handover(name, gpu, monkeypatch
             assert dropped > 0 and fallback >= dropped
         if flags & S:
             assert mismatch > 0 and fallback >= mismatch
-        assert fallback >= dropped + gaveup + mismatch          # (+ tiles no consumer ever took, if the dispatcher strayed)
+        assert fallback >= dropped + mismatch                   # (+ what consumers that gave up, or never came, left behind; an
+                                                                #  entry nobody waited for may also name a tile without samples)
         if not flags & (D | N | S):
             assert mismatch == 0, f"flags {flags:#x}: a hand-over read something its march had not written: {ctr}"
     with capsys.disabled():
