@@ -57,7 +57,7 @@ WORKLOADS = {
 }
 
 
-ROUND = "r03"        # which round's committed profiles the line quotes (profiles/<ROUND>_*)
+ROUND = "r04"        # which round's committed profiles the line quotes (profiles/<ROUND>_*)
 PREWARM_STEPS = 30   # untimed, before the --warmup steps: printed in the line
 
 
@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--share-device", action="store_true",
                     help="dry run: put every rank on cuda:0 (to rehearse the N>1 code path on a 1-GPU box)")
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "all_reduce", "direct"],
+                    help="N > 1: the gradient all-reduce (auto: both are timed on a gradient-sized buffer first, the faster is used)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -213,7 +215,43 @@ def main():
             torch.cuda.synchronize()
         atomic_requests, merged_rows = ctr.read()
         features.grad = None
-    reducer = parallel.OverlappedGradReducer(dist, backend=args.backend) if dist is not None else None
+    # N > 1: which gradient exchange?  RCCL's own all-reduce (ring / tree over its channels) or the direct form priced in
+    # DESIGN.md 7 (reduce-scatter + all-gather as two rounds of simultaneous point-to-point transfers, one per xGMI link)?
+    # Measured here on a gradient-sized buffer, both checked against each other; the faster one is what the step uses.
+    exchange = None
+    if dist is not None and not args.forward_only:
+        probe = torch.ones((M, K), dtype=torch.float32, device=dev)
+        timings = {}
+        for mode in ("all_reduce", "direct"):
+            try:
+                red = parallel.OverlappedGradReducer(dist, backend=args.backend, mode=mode)
+                for rep_i in range(2 + 5):
+                    if rep_i == 2:
+                        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                    probe.fill_(1.0)
+                    red.start(probe)
+                    red.wait()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 5
+                ok = bool((probe == float(world)).all().item())
+                t = torch.tensor([dt if ok else float("inf")], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                timings[mode] = float(t.item())
+            except Exception as exc:                     # (a backend without point-to-point on this device: gloo dry runs)
+                timings[mode] = float("inf")
+                print(f"[bench] exchange '{mode}' unavailable: {exc.__class__.__name__}: {exc}", file=sys.stderr)
+        best = min(timings, key=timings.get) if args.exchange == "auto" else args.exchange
+        if timings.get(best, float("inf")) == float("inf"):
+            best = "all_reduce"
+        exchange = {"used": best, "probe_ms": {k: (None if v == float("inf") else round(v * 1e3, 4)) for k, v in timings.items()},
+                    "bytes": 4 * M * K,
+                    "what": "all-reduce(sum) of a gradient-sized buffer, 5 repetitions after 2, max over ranks: the backend's own "
+                            "all_reduce in 32 MB row chunks against parallel.direct_all_reduce (two rounds of simultaneous "
+                            "point-to-point transfers, one per link of the mesh); the faster is used by the timed steps"}
+        del probe
+    reducer = parallel.OverlappedGradReducer(dist, backend=args.backend, mode=exchange["used"] if exchange else "all_reduce") \
+        if dist is not None else None
     gathered = torch.empty((world * Q, C + 1), dtype=torch.float32, device=dev) if dist is not None else None
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
 
@@ -443,6 +481,24 @@ def main():
                             if "grad_fused" in (route_bwd or "") else ""),
                 "atomic_requests": atomic_requests, "merged_rows": merged_rows,
                 "floor_ms": round(atomic_requests / ATOMIC_REQUESTS_PER_S * 1e3, 4), "measured_ms": round(bwd_ms, 4)}
+        # What binds the dominant kernel group -- from this run's own numbers, not asserted: the working set of
+        # configs 1-3 never leaves the Infinity Cache and the two big kernels sit at 0.13-0.29 of the HBM roofline, so
+        # "hbm" would misname it.  forward: as long as the dependent chain of its longest ray
+        # (+ the shading backlog) -> "latency"; per-tile backward of 3-channel payloads: a chain of barrier-separated
+        # phases over an atomic-request floor it does not reach -> "latency"; backward of wide rows in exact mode:
+        # vector ALU (the bit-exact expf replica and a double-precision divide per sigmoid) -> "valu".
+        wide_exact = "grad_wide_kernel" in (route_bwd or "") and "native" not in (route_bwd or "")
+        if dom == "backward" and wide_exact:
+            bound, bound_detail = "valu", ("vector ALU: the exact sigmoids of both sweeps (pexpf + a double-precision divide each); "
+                                           "rocprofv3 PMC of this command: SQ_INSTS_VALU per (sample, channel) in profiles/" + ROUND + "_*")
+        else:
+            lim = limits.get(dom, {})
+            bound = "latency"
+            bound_detail = (("the dependent chain of the longest ray: floor %(floor_ms)s ms against %(measured_ms)s measured" % lim)
+                            if dom == "forward" else
+                            ("barrier-separated phases per tile; its atomic-request floor is %s ms of the %s measured"
+                             % (lim.get("floor_ms"), lim.get("measured_ms"))))
+        step_ref = ref_fwd + (0 if args.forward_only else ref_bwd)
         res = {
             "metric": "Mrays/s fwd+bwd, 800×800 render, depth-8 SH9 N3Tree, 1→8 MI355X"
                       if args.workload == "d8_sh9_800" and not args.forward_only
@@ -483,7 +539,10 @@ def main():
                                  "step_total": fwd_bytes + bwd_bytes,
                                  "step_gbps": round((fwd_bytes + bwd_bytes) / (ms_per_step * 1e-3) / 1e9, 2)},
             "roofline": {
-                "bound": "hbm",
+                "bound": bound,
+                "bound_detail": bound_detail,
+                "frac_of": "hbm (secondary: the fraction of the 8 TB/s HBM roofline the dominant group's compulsory bytes reach; "
+                           "the group is bound by `bound`, see limits)",
                 "kernel": dom_kernel,
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
@@ -498,6 +557,13 @@ def main():
                 "reference_equivalent_gbps": round(dom_ref / (dom_ms * 1e-3) / 1e9, 2),
                 "reference_equivalent_note": "SURVEY.md 8(d): the bytes the REFERENCE's algorithm moves for the same result "
                                              "(a tree march per pass, 8 B per gradient float) / this kernel group's time",
+                # SURVEY.md 8(d)'s own figure for the WHOLE step, so that nobody has to recompute it: above 1 does not
+                # mean skipped work -- the sample lists replace two of the reference's three marches, the grid its
+                # descent, the per-tile merge its per-sample atomics; the same route is held bit for bit (forward) /
+                # to 1e-5 of the tight scale (gradient) at full size by tests/test_gpu_query_and_misc.py
+                "reference_equivalent": {"bytes_per_step": step_ref, "gbps": round(step_ref / (ms_per_step * 1e-3) / 1e9, 2),
+                                         "frac_of_hbm_peak": round(step_ref / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "forward_bytes": ref_fwd, "backward_bytes": None if args.forward_only else ref_bwd},
                 # both kernel groups (the dominant one is whichever took longer in this run: at the headline config the
                 # two are within 2 % of each other and take turns)
                 "groups": {g: {"ms": round(ms_, 4), "compulsory_bytes": b_, "achieved": round(b_ / (ms_ * 1e-3) / 1e9, 2),
@@ -509,10 +575,20 @@ def main():
         }
         if other:
             res["other_routes"] = other
+            # the drop-in route's number at top level: `value` is the `config.route` route
+            plain = next((o for o in other if o["route"] == "plain"), None)
+            if plain is not None:
+                res["value_plain"] = plain["value"]
+                res["value_plain_note"] = ("the two calls the reference's own autograd function makes (svox_t/renderer.py:60-77), no "
+                                           "argument the reference lacks; `value` is route '%s'" % args.route)
+        if args.route == "plain":
+            res["value_plain"] = round(value, 3)
         if single_march is not None:
             res["tolerance_mode"] = single_march
         if accumulation is not None:
             res["accumulation_arrangement"] = accumulation
+        if exchange is not None:
+            res["gradient_exchange"] = exchange
         if world > 1:
             res["multi_gpu_note"] = ("kernel_ms is the compute stream's forward / backward per step; ms_per_step - kernel "
                                      "time = exposed collectives + host; unmeasured on hardware by the builder (no 8-GPU node)")

@@ -199,6 +199,165 @@ def render_cameras(renderer_or_fn, features: torch.Tensor, c2ws: torch.Tensor,
     return _CameraSet.apply(features, fn, c2ws, group)
 
 
+def _peer(dist_module, group, r: int) -> int:
+    return dist_module.get_global_rank(group, r) if group is not None else r
+
+
+def _exchange(dist_module, sends, recvs, group):
+    """One round of point-to-point traffic with every peer at once: sends / recvs = [(tensor, group rank)].  On the
+    "nccl" backend (RCCL) the batch is one grouped launch -- every xGMI link of the mesh carries its pair's bytes at the
+    same time, which is what an all-to-all is on this fabric; gloo runs the same calls for the CPU tests."""
+    ops = []
+    for t, r in sends:
+        if t.numel():
+            ops.append(dist_module.P2POp(dist_module.isend, t, _peer(dist_module, group, r), group))
+    for t, r in recvs:
+        if t.numel():
+            ops.append(dist_module.P2POp(dist_module.irecv, t, _peer(dist_module, group, r), group))
+    if ops:
+        for w in dist_module.batch_isend_irecv(ops):
+            w.wait()
+
+
+def direct_all_reduce(dist_module, grad: torch.Tensor, group=None) -> torch.Tensor:
+    """all-reduce(sum) of a row-major gradient [M, ...] in place, built for a point-to-point mesh (xGMI: a link per
+    pair of GPUs, no switch) instead of a ring:
+
+        reduce-scatter   rank r owns the contiguous row range shard_bounds(M, W, r); every rank sends each peer that
+                         peer's range of its local gradient -- W - 1 transfers of S / W bytes, one per link, all at once
+                         -- and adds the W - 1 pieces it receives to its own range;
+        all-gather       every rank sends its summed range to each peer, again one transfer of S / W per link.
+
+    Per link and direction 2 S / W bytes move in two rounds: 2 S / (W B) seconds at B bytes/s per link, against
+    2 (W - 1) S / (W B) for a ring that uses one link per step (DESIGN.md 7 has the table).  No padding, no staging copy of
+    the gradient: ranges are views, ragged splits are fine.  Adds happen in rank order on the owner (own, then peers
+    ascending): the result is the same on every rank, bit for bit."""
+    W, me = dist_module.get_world_size(group), dist_module.get_rank(group)
+    if W == 1 or grad.numel() == 0:
+        return grad
+    assert grad.is_contiguous()
+    M = grad.shape[0]
+    bounds = [shard_bounds(M, W, r) for r in range(W)]
+    lo, hi = bounds[me]
+    peers = [r for r in range(W) if r != me]
+    recv = grad.new_empty((len(peers), hi - lo) + tuple(grad.shape[1:]))
+    _exchange(dist_module, [(grad[bounds[r][0]:bounds[r][1]], r) for r in peers], [(recv[j], r) for j, r in enumerate(peers)], group)
+    own = grad[lo:hi]
+    for j in range(len(peers)):
+        own += recv[j]
+    _exchange(dist_module, [(own, r) for r in peers], [(grad[bounds[r][0]:bounds[r][1]], r) for r in peers], group)
+    return grad
+
+
+def touched_blocks(grad: torch.Tensor, block_rows: int) -> torch.Tensor:
+    """uint8 [ceil(M / block_rows)]: 1 where a block of rows holds a non-zero entry.  (A row whose contributions cancel to
+    exactly zero counts as untouched: leaving out a zero changes no sum.)"""
+    M = grad.shape[0]
+    nblk = (M + block_rows - 1) // block_rows
+    flat = grad.reshape(M, -1)
+    full = M // block_rows
+    mask = torch.zeros((nblk,), dtype=torch.uint8, device=grad.device)
+    if full:
+        mask[:full] = (flat[:full * block_rows].reshape(full, -1) != 0).any(dim=1)
+    if full < nblk:
+        mask[full] = (flat[full * block_rows:] != 0).any()
+    return mask
+
+
+def sparse_all_reduce(dist_module, grad: torch.Tensor, group=None, block_rows: int = 256, mask: Optional[torch.Tensor] = None):
+    """all-reduce(sum) of grad [M, K] in place, moving only the blocks of `block_rows` rows that somebody touched.
+
+    A camera's backward touches the feature rows its rays cross; rows no rank touched are zero everywhere and need not
+    travel at all, rows one rank touched need no reduction.  Same two rounds as direct_all_reduce, over blocks:
+        0  all-gather of the ranks' block masks (ceil(M / block_rows) bytes each), read on the host: sizes are known
+           to both ends of every transfer (one host synchronisation per exchange: tens of microseconds, which is why
+           this form is for gradients of tens of MB and up);
+        1  every rank sends each owner the blocks of that owner's range it touched, compacted; the owner adds them in;
+        2  every owner sends each peer the blocks of its range that ANYONE touched.
+    Bytes per link: (what the rank touched of a range) one way, (the union over ranks of a range) the other, instead
+    of S / W each way.  Returns (grad, stats) with stats = blocks sent in round 1 / round 2 / a dense exchange's.
+    The adds are in rank order on the owner, as in direct_all_reduce: equal to it bit for bit."""
+    W, me = dist_module.get_world_size(group), dist_module.get_rank(group)
+    if W == 1 or grad.numel() == 0:
+        return grad, {"round1_blocks": 0, "round2_blocks": 0, "dense_blocks": 0}
+    assert grad.is_contiguous() and grad.dim() == 2
+    M, K = grad.shape
+    nblk = (M + block_rows - 1) // block_rows
+    if mask is None:
+        mask = touched_blocks(grad, block_rows)
+    masks = mask.new_empty((W, nblk))
+    if hasattr(dist_module, "all_gather_into_tensor") and grad.is_cuda:
+        dist_module.all_gather_into_tensor(masks, mask, group=group)
+    else:
+        dist_module.all_gather(list(masks.unbind(0)), mask, group=group)
+    masks_h = masks.cpu().bool()                                   # the one host synchronisation
+    union = masks_h.any(dim=0)
+    bb = [shard_bounds(nblk, W, r) for r in range(W)]               # owner ranges, in blocks
+    peers = [r for r in range(W) if r != me]
+    full = M // block_rows                                          # the last block may be short: it travels padded
+
+    def blocks_view(t):
+        """[full, block_rows, K] view of the whole blocks (+ the short last block handled by pad / unpad below)."""
+        return t[:full * block_rows].view(full, block_rows, K)
+
+    tail = None
+    if full < nblk:                                                 # a padded copy of the short last block
+        tail = grad.new_zeros((block_rows, K))
+        tail[:M - full * block_rows] = grad[full * block_rows:]
+
+    def gather(ids):
+        """the blocks `ids` (a LongTensor on the host) as one contiguous [n, block_rows, K] buffer"""
+        ids = ids.to(grad.device)
+        out = grad.new_empty((ids.numel(), block_rows, K))
+        whole = ids < full
+        if whole.any():
+            out[whole] = blocks_view(grad)[ids[whole]]
+        if (~whole).any():
+            out[~whole] = tail
+        return out
+
+    def scatter(ids, buf, add):
+        nonlocal tail
+        ids = ids.to(grad.device)
+        whole = ids < full
+        if whole.any():
+            if add:
+                blocks_view(grad).index_add_(0, ids[whole], buf[whole])
+            else:
+                blocks_view(grad).index_copy_(0, ids[whole], buf[whole])
+        if (~whole).any():
+            if add:
+                tail += buf[~whole][0]
+            else:
+                tail = buf[~whole][0].clone()
+
+    idx = torch.arange(nblk)
+    # round 1: my touched blocks of each owner's range -> that owner; what the peers touched of mine <- them
+    send_ids = {r: idx[bb[r][0]:bb[r][1]][masks_h[me, bb[r][0]:bb[r][1]]] for r in peers}
+    recv_ids = {r: idx[bb[me][0]:bb[me][1]][masks_h[r, bb[me][0]:bb[me][1]]] for r in peers}
+    sbuf = {r: gather(send_ids[r]) for r in peers}
+    rbuf = {r: grad.new_empty((recv_ids[r].numel(), block_rows, K)) for r in peers}
+    _exchange(dist_module, [(sbuf[r], r) for r in peers], [(rbuf[r], r) for r in peers], group)
+    for r in peers:                                                 # rank order: the same sums on every owner
+        if recv_ids[r].numel():
+            scatter(recv_ids[r], rbuf[r], add=True)
+    # round 2: the union-touched blocks of my range -> everyone; theirs <- them
+    mine = idx[bb[me][0]:bb[me][1]][union[bb[me][0]:bb[me][1]]]
+    own = gather(mine)
+    theirs = {r: idx[bb[r][0]:bb[r][1]][union[bb[r][0]:bb[r][1]]] for r in peers}
+    rbuf2 = {r: grad.new_empty((theirs[r].numel(), block_rows, K)) for r in peers}
+    _exchange(dist_module, [(own, r) for r in peers], [(rbuf2[r], r) for r in peers], group)
+    for r in peers:
+        if theirs[r].numel():
+            scatter(theirs[r], rbuf2[r], add=False)
+    if tail is not None:
+        grad[full * block_rows:] = tail[:M - full * block_rows]
+    stats = {"round1_blocks": int(sum(v.numel() for v in send_ids.values())),
+             "round2_blocks": int(mine.numel()) * len(peers),
+             "dense_blocks": int(sum(bb[r][1] - bb[r][0] for r in peers)) + (bb[me][1] - bb[me][0]) * len(peers)}
+    return grad, stats
+
+
 class OverlappedGradReducer:
     """All-reduce(sum) of the feature gradient off the critical path.
 
@@ -219,8 +378,14 @@ class OverlappedGradReducer:
     bench.py --gpus N times the accumulation arrangement and says so.
     """
 
-    def __init__(self, dist_module=dist, group=None, backend: str = "nccl", chunk_bytes: int = 32 << 20):
-        self.dist, self.group, self.backend = dist_module, group, backend
+    def __init__(self, dist_module=dist, group=None, backend: str = "nccl", chunk_bytes: int = 32 << 20,
+                 mode: str = "all_reduce"):
+        """mode: "all_reduce" -- the backend's own all-reduce per row chunk (RCCL chooses ring / tree and its channels);
+        "direct" -- direct_all_reduce: reduce-scatter and all-gather as two rounds of simultaneous point-to-point
+        transfers, one per link of the mesh (the form priced for xGMI); "touched" -- sparse_all_reduce
+        (only row blocks somebody touched; one host synchronisation per exchange, so start() then blocks the host)."""
+        assert mode in ("all_reduce", "direct", "touched")
+        self.dist, self.group, self.backend, self.mode = dist_module, group, backend, mode
         self.chunk_bytes = int(chunk_bytes)
         self._works, self._grad = [], None
         self._side = torch.cuda.Stream() if backend == "nccl" and torch.cuda.is_available() else None
@@ -238,21 +403,35 @@ class OverlappedGradReducer:
             return
         assert grad.is_contiguous()
         self._grad = grad                                   # stays alive while it travels
+
+        def issue():
+            if self.mode == "direct":
+                direct_all_reduce(self.dist, grad, self.group)     # (its waits are stream waits under "nccl": the host goes on)
+                return []
+            if self.mode == "touched":
+                sparse_all_reduce(self.dist, grad, self.group)
+                return []
+            return [self.dist.all_reduce(grad[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    for lo, hi in self.chunks(grad)]
         if self._side is not None:
             self._side.wait_stream(torch.cuda.current_stream(grad.device))
             grad.record_stream(self._side)
             with torch.cuda.stream(self._side):
-                self._works = [self.dist.all_reduce(grad[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-                               for lo, hi in self.chunks(grad)]
+                self._works = issue()
+                self._side_done = torch.cuda.Event()
+                self._side_done.record(self._side)
         else:
-            self._works = [self.dist.all_reduce(grad[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-                           for lo, hi in self.chunks(grad)]
+            self._works = issue()
 
     def wait(self) -> Optional[torch.Tensor]:
         """The reduced gradient handed to the last start() (None if there was none)."""
         for w in self._works:
             w.wait()                                        # nccl: the current stream waits; gloo: the host does
         self._works = []
+        ev = getattr(self, "_side_done", None)
+        if ev is not None and self._grad is not None:       # (the direct / touched exchanges end with kernels of the side stream)
+            torch.cuda.current_stream(self._grad.device).wait_event(ev)
+            self._side_done = None
         g, self._grad = self._grad, None
         return g
 
