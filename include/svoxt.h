@@ -98,6 +98,13 @@ typedef struct svoxt_tree {
                                     sigma_mask_thresh == options.sigma_thresh. */
     float          sigma_mask_thresh;
     int32_t        reserved0;    /* 0 */
+    const float*   exp_table;    /* device, optional (ABI v17; RGBA-style rows of K = 8 / 16 / 32 floats only): [M, K], entry (row, c)
+                                    = the exponential exp(-features[row][c]) exactly as the kernels form it, for the K - 1
+                                    feature columns, and sigma itself in the last column, built by svoxt_exp_table_build for
+                                    THIS feature content, or NULL.  Pure cache like accel and sigma_mask (results are
+                                    identical with or without it): the sigmoids of such a payload do not depend on the view,
+                                    so the shade kernel of the two-kernel forward and both sweeps of the per-tile backward
+                                    read the table instead of forming the exponential once per sample. */
 } svoxt_tree;
 
 /* RaysSpec (data_spec.hpp:52-65); with c2w set, CameraSpec (data_spec.hpp:113-126):
@@ -329,6 +336,10 @@ int svoxt_fwd_fills_terms(const svoxt_tree* tree, const svoxt_options* opt, int3
  * the Infinity Cache. */
 int64_t svoxt_sigma_mask_bytes(int64_t M);
 int svoxt_sigma_mask_build(const svoxt_tree* tree, float sigma_thresh, void* mask, void* stream);
+/* The exponentials table of svoxt_tree.exp_table (ABI v17; no counterpart in the reference) for RGBA-style rows of
+ * 8 / 16 / 32 floats: table <- device float [M, K], 16-byte aligned, and -- in the same pass over the feature table --
+ * the sigma bitmask (mask as for svoxt_sigma_mask_build, or NULL).  Rebuild after any change to the features. */
+int svoxt_exp_table_build(const svoxt_tree* tree, float sigma_thresh, void* mask, float* table, void* stream);
 int svoxt_volume_render_fwd_record(const svoxt_tree* tree, const svoxt_rays* rays,
                                    const svoxt_options* opt, float* out,
                                    const svoxt_sample_lists* lists, void* stream);

@@ -60,6 +60,7 @@ class _CTree(ctypes.Structure):          # struct svoxt_tree
         ("accel", ctypes.c_void_p), ("accel_log2", ctypes.c_int32),
         ("xform_dim", ctypes.c_int32),
         ("sigma_mask", ctypes.c_void_p), ("sigma_mask_thresh", ctypes.c_float), ("reserved0", ctypes.c_int32),
+        ("exp_table", ctypes.c_void_p),
     ]
 
 
@@ -119,6 +120,7 @@ EXPORTS = {
     "svoxt_fwd_fills_terms": (ctypes.c_int, [_P(_CTree), _P(_COptions), _i32]),
     "svoxt_sigma_mask_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "svoxt_sigma_mask_build": (ctypes.c_int, [_P(_CTree), ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "svoxt_exp_table_build": (ctypes.c_int, [_P(_CTree), ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "svoxt_compact_rows": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "svoxt_compact_rows_clear": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "svoxt_query_leaves_workspace_bytes": (ctypes.c_int64, [_i64]),
@@ -209,6 +211,11 @@ NATIVE_MATH = _env_flag("SVOXT_NATIVE_MATH", "0")
 # SVOXT_FWD_OVERLAP=0: march and shade of the two-kernel forward as two launches instead of one grid that
 # carries both roles (include/svoxt.h, svoxt_sample_lists.tile_state); result-neutral
 FWD_OVERLAP = _env_flag("SVOXT_FWD_OVERLAP", "1")
+# RGBA-style rows of 8 / 16 / 32 floats, exact mode: the forward builds a table of the rows' exponentials in the pass that
+# builds the sigma bitmask (include/svoxt.h, svoxt_tree.exp_table: the sigmoids of such a payload do not depend on the
+# view); its shade kernel and both sweeps of the per-tile backward read that instead of forming one exponential per
+# sample and channel.  Result-neutral (the same bits); costs M * K * 4 bytes per outstanding forward.  SVOXT_EXP_TABLE=0: off
+EXP_TABLE = _env_flag("SVOXT_EXP_TABLE", "1")
 # --- not environment switches: routes the tests exercise by assignment
 BWD_TERMS = True     # False: no hand-over between the sweeps of the exact backwards (every row gathered twice)
 BWD_FUSED = True     # False: list walk and per-tile merge of an image's backward as two kernels (the form view rotations take)
@@ -459,28 +466,41 @@ def _pack_tree_accel(tree: TreeSpec) -> _CTree:
 _SIGMA_CACHE: dict = {}
 
 
-def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool) -> None:
+def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool, table: bool = False):
+    """ct.sigma_mask <- the bitmask of this feature content; table: also ct.exp_table <- the rows' exponentials (rows of
+    8 / 16 / 32 floats), built in the same pass.  Returns the table tensor (or None): a recording forward keeps it on its
+    lists for the backward of the same feature content."""
     f = tree.features
     if not SIGMA_MASK or ct.M == 0:
-        return
+        return None
+    table = bool(table and EXP_TABLE and f.dim() == 2 and f.is_contiguous() and f.dtype == torch.float32)
     key = id(f)
-    mask = None
+    mask = etab = None
     keep = keep and bool(getattr(tree, "static_features", False))
     if keep:
         ent = _SIGMA_CACHE.get(key)
-        if ent is not None and ent[0]() is f and ent[1] == (f._version, f.data_ptr()) and ent[2] == thresh:
-            mask = ent[3]
+        if ent is not None and ent[0]() is f and ent[1] == (f._version, f.data_ptr()) and ent[2] == thresh \
+                and (ent[4] is not None or not table):
+            mask, etab = ent[3], (ent[4] if table else None)
     if mask is None:
         dev = f.device
         with torch.cuda.device(dev):
             mask = torch.empty((_lib.svoxt_sigma_mask_bytes(ct.M) // 8,), dtype=torch.int64, device=dev)
-            _call("svoxt_sigma_mask_build", ctypes.byref(ct), ctypes.c_float(thresh), _ptr(mask), _stream(dev))
+            if table:
+                etab = torch.empty_like(f, requires_grad=False)
+                _call("svoxt_exp_table_build", ctypes.byref(ct), ctypes.c_float(thresh), _ptr(mask), _ptr(etab), _stream(dev))
+            else:
+                _call("svoxt_sigma_mask_build", ctypes.byref(ct), ctypes.c_float(thresh), _ptr(mask), _stream(dev))
         if keep:
             _SIGMA_CACHE[key] = (weakref.ref(f, lambda _r, _k=key: _SIGMA_CACHE.pop(_k, None)),
-                                 (f._version, f.data_ptr()), thresh, mask)
+                                 (f._version, f.data_ptr()), thresh, mask, etab)
     ct.sigma_mask = mask.data_ptr()
     ct.sigma_mask_thresh = thresh
     ct._keepalive_mask = mask
+    if etab is not None:
+        ct.exp_table = etab.data_ptr()
+        ct._keepalive_etab = etab
+    return etab
 
 
 # SVOXT_GRAD_SCRATCH=0: every backward over sample lists allocates and fills its padded gradient buffer itself.
@@ -662,6 +682,7 @@ class SampleLists:
         self.consumed = False   # which rewrites `rec`: the lists then serve no second backward
         self.terms = None       # (att, e0, e1, e2) per record slot for the exact one-kernel backward
         self.terms_state = 0    # 2: filled by the forward; 0: scratch (the backward's first sweep fills it)
+        self.exp_table = None   # rows of 8 / 16 / 32 floats: the exponentials table the forward built (svoxt_tree.exp_table)
         self.flags = 0          # svoxt_sample_lists.flags: how the kernels that write / read these lists work
 
     def note_usage(self):
@@ -913,8 +934,12 @@ def _volume_render(tree, rays, opt, record):
         if (will_record and BWD_EXACT and BWD_TERMS and BWD_FUSED and BWD_GATHER) else 0
     # the march of the two-kernel forward reads a bit per row instead of gathering sigma -- where that
     # forward is what runs and the stop rule (which needs sigma itself) does not apply
+    etab = None
     if ((split or fills == 3) and FWD_SPLIT != "0") if will_record else (split and co.stop_thresh == 0.0):
-        _attach_sigma_mask(tree, ct, float(co.sigma_thresh), keep=not will_record)
+        # rows of 8 / 16 / 32 floats in exact mode: the same pass leaves the rows' exponentials for the shade kernel
+        # (and, on the lists, for the per-tile backward of this feature content)
+        etab = _attach_sigma_mask(tree, ct, float(co.sigma_thresh), keep=not will_record,
+                                  table=wide and split and not NATIVE_MATH)
     LAST_ROUTE["forward_terms"] = False
     # march and shade of a 3-channel payload as ONE launch (fwd_roles_kernel): the conditions of the library's launch_fwd_roles
     roles = bool(FWD_OVERLAP and LIST_POOL and ct.sigma_mask and ct.N == 2 and ct.xform is None and ct.weight_accum is None
@@ -931,6 +956,7 @@ def _volume_render(tree, rays, opt, record):
         if will_record:
             lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
             lists.flags = lflags
+            lists.exp_table = etab
             if fills:
                 # the exact per-tile backward will want (att, e0, e1, e2) of every sample: this forward has them
                 lists.terms = torch.empty((lists.pool_blocks * 512 * 4,), dtype=torch.float32, device=dev)
@@ -1055,12 +1081,15 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
                 lists.coef = torch.empty((planes * lists.S, cr.Q, 4), dtype=torch.float32, device=dev)
                 lists.consumed = True         # the two-kernel form rewrites rec
             cl = lists.c_struct()
+            if wide_tile and lists.exp_table is not None and not (lists.flags & LISTS_NATIVE_MATH):
+                ct.exp_table = lists.exp_table.data_ptr()      # (the table of the feature content the lists were recorded with)
             LAST_ROUTE["backward"] = (
                 ("grad_fused_kernel<EXACT> (two sweeps over the lists + per-tile merge)" if fo is None else
                  "grad_fused_kernel (one sweep over the lists + per-tile merge; accum from the forward's output)") if fused else
                 "render_bwd_kernel<GATHER> + grad_merge_kernel (list walk, then per-tile merge)" if gather else
                 ("grad_wide_kernel (two sweeps over the lists, sigmoids per record once + once per distinct row; per-tile merge"
-                 + (", native exp / rcp)" if lists.flags & LISTS_NATIVE_MATH else ")"))
+                 + (", native exp / rcp)" if lists.flags & LISTS_NATIVE_MATH else
+                    ", exponentials from the forward's table)" if lists.exp_table is not None else ")"))
                 if wide_tile else
                 "render_bwd_kernel<ONEPASS> (two list walks, sigmoids formed once; one atomic row + one sigma atomic per sample)"
                 if (wide and fo is None and BWD_TERMS) else

@@ -93,6 +93,9 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
         else if (native)                                                                                      \
             hipLaunchKernelGGL((grad_wide_kernel<KK, true>), dim3(nb), dim3(512), 0, st, tr, rays, opt, grad_out, L, aux, \
                                grad, gstride, (unsigned long long*)nullptr);                                  \
+        else if (tr.etab != nullptr)                                                                          \
+            hipLaunchKernelGGL((grad_wide_kernel<KK, false, false, false, true>), dim3(nb), dim3(512), 0, st, tr, rays, opt, grad_out, L, aux, \
+                               grad, gstride, (unsigned long long*)nullptr);                                  \
         else                                                                                                  \
             hipLaunchKernelGGL((grad_wide_kernel<KK, false>), dim3(nb), dim3(512), 0, st, tr, rays, opt, grad_out, L, aux, \
                                grad, gstride, (unsigned long long*)nullptr);                                  \

@@ -1226,12 +1226,18 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 // pool, 17 sweep 1's compacted position, 18 a compacted record's slot, 19 a feature row outside the table, 20 sweep
 // 2's table entry, 21 the list of occupied entries, 22 a record's place in the sorted order, 23 an occupied entry
 // read by the reduce, 24 a sorted record read by the reduce, 25 the row a sum is sent to.
-template <int K, bool FAST = false, bool COUNT = false, bool CHECK = false>
+// ETAB (exact mode, r04): the rows are read from tr.etab -- etab[row][c] = pexpf(-features[row][c]), sigma in the last
+// column (exp_table_kernel, built once per forward) -- so neither sweep forms the exponential of a feature again, and
+// the double-precision reciprocals 1 / (1 + e) take rcp_unit_range (the compiler's division sequence minus what their
+// operand range makes an identity).  The same bits.
+template <int K, bool FAST = false, bool COUNT = false, bool CHECK = false, bool ETAB = false>
 __global__ void __launch_bounds__(512, FAST ? 8 : 6)
 grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                  RecLists L, const uint4* __restrict__ aux, float* __restrict__ grad, int gstride,
                  unsigned long long* __restrict__ counters = nullptr) {
     static_assert(K == 8 || K == 16 || K == 32, "row widths with an instance");
+    static_assert(!(ETAB && FAST), "the table holds the exact exponentials");
+    const float* __restrict__ const rows = ETAB ? tr.etab : tr.features;
     if (tile_never_recorded(L, blockIdx.x)) return;          // (r03: before anything else is requested)
 #define SVOXT_CHK(i, n, site) chk<CHECK>(i, n, counters, site)
     constexpr int C = K - 1, W = 8, NT = 64 * W, T = 1024, R = 1024, RPP = R / (64 * W);
@@ -1344,12 +1350,12 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
             float a1[8];
             double a2[8];
             if (on) {
-                load_row<8>(tr.features + (int64_t)SVOXT_CHK((int32_t)r_sl[slot], tr.M, 19) * K + 8 * gq, row);
+                load_row<8>(rows + (int64_t)SVOXT_CHK((int32_t)r_sl[slot], tr.M, 19) * K + 8 * gq, row);
                 const float* __restrict__ gr = gl + ray * KG + 8 * gq;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (8 * gq + j < C) {                      // (the last lane's eighth column is sigma)
-                        const double sd = sigmoid_d<true>(row[j]);
+                        const double sd = ETAB ? rcp_unit_range(1.0 + (double)row[j]) : sigmoid_d<true>(row[j]);
                         const float gj = gr[j];
                         a1[j] = (float)sd * gj;
                         a2[j] = sd * (double)gj;
@@ -1545,7 +1551,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                     // the entry's records start where the previous occupied entry's end (table order = sorted order)
                     if (i > 0) ps[u] = SVOXT_CHK(cnt[SVOXT_CHK((int)slots[i - 1], T, 23)], R + 1, 24);
                     if constexpr (CHECK) { if (ps[u] > pes[u]) { atomicAdd(counters + kChkBase + 24, 1ull); ps[u] = pes[u]; } }
-                    xs[u] = tr.features[(int64_t)idxs[u] * K + col];
+                    xs[u] = rows[(int64_t)idxs[u] * K + col];
                 }
             }
 #pragma unroll
@@ -1555,7 +1561,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                 const int p = ps[u];
                 float sig = 0.f, om = 0.f;
                 if (idx >= 0 && col < C) {
-                    sig = FAST ? nsigmoidf(xs[u]) : (float)sigmoid_d<true>(xs[u]);
+                    sig = FAST ? nsigmoidf(xs[u]) : ETAB ? (float)rcp_unit_range(1.0 + (double)xs[u]) : (float)sigmoid_d<true>(xs[u]);
                     om = 1.f - sig;
                 }
                 float acc = 0.f;

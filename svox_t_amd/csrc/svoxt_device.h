@@ -44,6 +44,10 @@ struct TreeDev {
     // of `child` / `data` would find, never a different answer.
     const uint32_t* __restrict__ accel;
     int accel_g;
+    // optional (RGBA-style rows of 8 / 16 / 32 floats): exp_table[row][c] = pexpf(-features[row][c]) for the feature
+    // columns, sigma unchanged in the last one (svoxt_exp_table_build).  Derived data, like the grid: the same bits
+    // the kernels would form themselves, formed once per row instead of once per sample and sweep.
+    const float* __restrict__ etab;
 };
 
 struct RaysDev {
@@ -645,6 +649,30 @@ __device__ __forceinline__ float neg_sh_dot(const float* __restrict__ basis, con
         tmp += pr;
     }
     return -tmp;
+}
+
+// The double-precision quotients of the reference's `w / (1.0 + expf(-x))` family (rt_kernel.cu:300,304,408,420,472,
+// 476) for THEIR operand range, with the compiler's own operation sequence minus what that range makes an identity.
+// hipcc expands n / d in double to  v_div_scale x2, v_rcp_f64, two Newton steps (4 fma), q = n r, rem = fma(-d, q, n),
+// v_div_fmas(rem, r, q), v_div_fixup.  Here n is a float in {0} u [2^-149, 1] (a weight T (1 - att), or 1.0) and d =
+// 1.0 + double(e) with e a float >= 0 or +inf, so d is in [1, 2^128] or +inf: no operand is scaled (v_div_scale
+// pre-scales only a denormal or tiny operand, a quotient or reciprocal that would be denormal, or exponents 768 apart:
+// none can occur -- the quotient is >= 2^-277), v_div_fmas without a scale flag is a plain fma, and what remains is the
+// same rcp / fma / mul sequence and the same v_div_fixup (which delivers the n = 0, d = inf cases as the full sequence
+// does).  Bit-identical to the `/` operator on that range: exp/div_check.hip sweeps all 2^31 patterns of e against it
+// on the GPU (tests/test_gpu_div_exact.py).  9 double-precision instructions instead of 11 (8 for the reciprocal).
+__device__ __forceinline__ double div_unit_range(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    const double q = n * r;
+    return __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-d, q, n), r, q), d, n);
+}
+__device__ __forceinline__ double rcp_unit_range(double d) {        // 1.0 / d, d as above
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-d, r, 1.0), r, r), d, 1.0);
 }
 
 // The reference's `w / (1.0 + expf(-x))` family is evaluated in double

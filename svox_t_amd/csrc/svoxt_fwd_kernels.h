@@ -307,6 +307,43 @@ sigma_mask_kernel(const float* __restrict__ features, int64_t M, int K, float th
     }
 }
 
+// (r04) The exponentials of RGBA-style rows of K = 8 / 16 / 32 floats, once per ROW: etab[row][c] = pexpf(-features[row][c])
+// for the C = K - 1 feature columns, sigma itself in the last one.  The sigmoids of such a payload are view-independent
+// (rt_kernel.cu:304, 420, 476: 1 / (1 + expf(-row[c]))), so what every sample of a row needs is a function of the row:
+// at 1024 x 1024 / depth 9 the forward formed 13.4 M x 31 of these exponentials, the backward's sweeps 13.4 M x 31 and
+// 5.9 M x 31 more -- for 4.7 M rows.  One streaming pass (the pass that builds the sigma bitmask reads every line of the
+// table anyway: this kernel builds the mask too) writes the table; the shade kernel and both sweeps of the per-tile
+// backward then read IT instead of the features -- the same bits, by construction.  A thread takes four floats of a row.
+template <int K>
+__global__ void __launch_bounds__(256)
+exp_table_kernel(const float* __restrict__ features, int64_t M, float thresh, uint8_t* __restrict__ mask_bytes,
+                 float* __restrict__ etab) {
+    static_assert(K == 8 || K == 16 || K == 32, "row widths with a table");
+    constexpr int P = K / 4, RW = 64 / P;            // threads per row, rows per wavefront
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = t / P;
+    const int part = (int)(t % P);
+    bool bit = false;
+    if (row < M) {
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(features) + t);      // read once: nothing of it is needed again
+        v4f e;
+        e.x = pexpf(-v.x); e.y = pexpf(-v.y); e.z = pexpf(-v.z);
+        if (part == P - 1) { e.w = v.w; bit = v.w > thresh; }
+        else e.w = pexpf(-v.w);
+        reinterpret_cast<v4f*>(etab)[t] = e;
+    }
+    const unsigned long long b = __ballot(bit);
+    if (mask_bytes != nullptr && (threadIdx.x & 63) == 0 && row < M) {
+        uint32_t bits = 0u;                          // bit i: row (row + i) of this wavefront's RW rows
+#pragma unroll
+        for (int i = 0; i < RW; ++i) bits |= (uint32_t)((b >> (i * P + P - 1)) & 1ull) << i;
+        uint8_t* dst = mask_bytes + (row >> 3);      // (row is a multiple of RW here, RW a multiple of 8)
+#pragma unroll
+        for (int j = 0; j < RW / 8; ++j) dst[j] = (uint8_t)(bits >> (8 * j));
+    }
+}
+
 // MASK (no stop rule): whether a row's sigma exceeds sigma_thresh comes from one bit per feature row
 // (svoxt_sigma_mask_build: M / 8 bytes, resident in L2) instead of a 4-byte gather that pulls a
 // 64-byte line of the feature table -- half of this kernel's traffic, and HBM traffic once the table
@@ -434,15 +471,15 @@ march_rec_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
 constexpr int kShadeP = 7;                       // list positions per round: one per wavefront but the first
 typedef float shade_v4f __attribute__((ext_vector_type(4)));
 // LOBES (FMT_SH instances): the basis values are those of opt.format = SG or ASG with BD lobes (precalc_lobes).
-// COH also: returns this wavefront's part of the tile's checksum (tile_checksum_part) over what it LOADED -- list
-// lengths, records -- for the caller to compare with the march's; what it loads is made harmless first (a block id
+// COH also: returns the XOR of rec_hash over the records this LANE loaded (its wavefront's list positions of its ray),
+// for the caller to combine per ray and compare with the march's checksum; what it loads is made harmless first (a block id
 // inside the pool, a row inside the table), so that a stale line costs a re-shade by the fallback launch, never a
 // fault; `stale_test`: (test only) treat the first record of every ray as if a stale line had been read.
 template <int FMT, int BD, bool XF, bool STOP, bool WTERMS, bool COH, bool LOBES = false>
 __device__ __forceinline__ uint32_t shade_tile_body(const TreeDev& tr, const RaysDev& rays, const Opts& opt, const RecLists& L,
                                                     uint4* __restrict__ aux, float* __restrict__ out, int64_t tile,
                                                     shade_v4f (*terms)[kShadeP][64] /* [2]: (att, e_0, e_1, e_2) of a list position, per ray */,
-                                                    bool stale_test = false) {
+                                                    bool stale_test = false, uint32_t* ax_used = nullptr /* COH: <- the aux.x this lane worked with */) {
     constexpr int C = 3, W = 8, P = kShadeP;
     static_assert(P == W - 1, "one wavefront runs along the rays");
     constexpr int K = (FMT == FMT_RGBA) ? (C + 1) : (C * BD + 1);
@@ -455,7 +492,10 @@ __device__ __forceinline__ uint32_t shade_tile_body(const TreeDev& tr, const Ray
     uint32_t a_x = 0u;
     if (inb) a_x = COH ? aux_get_coherent(aux + q).x : aux[q].x;
     int nrec = (int)(a_x & ~kRecOverflow);
-    if constexpr (COH) nrec = min(nrec, L.S);        // (a stale count must not run the loops away)
+    if constexpr (COH) {
+        nrec = min(nrec, L.S);                       // (a stale count must not run the loops away)
+        if (ax_used != nullptr) *ax_used = a_x;
+    }
     int maxn = nrec;
     for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
     maxn = __builtin_amdgcn_readfirstlane(maxn);     // what decides the barrier count is scalar
@@ -557,8 +597,7 @@ __device__ __forceinline__ uint32_t shade_tile_body(const TreeDev& tr, const Ray
         }
         aw[2] = __float_as_uint(light);              // the final transmittance, for the single-march backward
     }
-    if constexpr (COH && SVOXT_ROLES_CSUM != 0) return tile_checksum_part(cs, wave == 1 ? a_x : 0u, lane);
-    else return 0u;
+    return cs;
 }
 
 // (r04) A queue entry is 64 bits, written and read whole: the tile id (| kTileEmpty) below, the checksum of the tile's
@@ -683,7 +722,6 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
     constexpr int kShadeBytes = 2 * kShadeP * 64 * (int)sizeof(shade_v4f);
     __shared__ __attribute__((aligned(16))) unsigned char lds[kMarchBytes > kShadeBytes ? kMarchBytes : kShadeBytes];
     __shared__ unsigned long long s_ent;
-    __shared__ uint32_t s_part[8];
     const int wave = threadIdx.x >> 6;
     const bool agent_fence = (tflags & kRoleAgentFence) != 0;
     int32_t* const ctrs = tile_state + roles_even(ntiles);
@@ -718,7 +756,7 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
         }
         // (a lane without a ray, or whose ray misses the cube, returned ax = 0 and recorded nothing: it folds in as zero)
         uint32_t csum = 0u;
-        if constexpr (SVOXT_ROLES_CSUM != 0) csum = empty ? 0u : tile_checksum_part(ax != 0u ? cs_lane : 0u, ax, (int)(threadIdx.x & 63));
+        if constexpr (SVOXT_ROLES_CSUM != 0) csum = empty ? 0u : tile_checksum(ax != 0u ? cs_lane : 0u, ax, (int)(threadIdx.x & 63));
         publish_tile(tile_state, ntiles, empty ? (tile | kTileEmpty) : tile, csum, agent_fence);      // (the queue addresses are formed behind the march: nothing of them lives across it)
         return;
     }
@@ -742,20 +780,27 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
         return;
     }
     if (agent_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    uint32_t ax = 0u;
     const uint32_t part = shade_tile_body<FMT, BD, false, false, WTERMS, true, LOBES>(
-        tr, rays, opt, L, aux, out, tile, reinterpret_cast<shade_v4f (*)[kShadeP][64]>(lds), (tflags & kRoleTestStale) && tile % 5 == 0);
-    // what this workgroup loaded, folded like the march folded what it wrote
-    if ((threadIdx.x & 63) == 0) s_part[wave] = part;
+        tr, rays, opt, L, aux, out, tile, reinterpret_cast<shade_v4f (*)[kShadeP][64]>(lds), (tflags & kRoleTestStale) && tile % 5 == 0, &ax);
+    // what this workgroup loaded, folded like the march folded what it wrote: per ray first (the eight wavefronts'
+    // words of a lane; the shade's double buffer is free behind its last barrier), then over the tile
+    uint32_t* s_part = reinterpret_cast<uint32_t*>(lds);
+    s_part[threadIdx.x] = part;
     lds_barrier();
-    if (threadIdx.x == 0) {
-        uint32_t c = 0u;
+    if (wave == 0) {
+        const int lane = (int)threadIdx.x;
+        uint32_t x = 0u;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) c ^= s_part[w];
+        for (int w = 0; w < 8; ++w) x ^= s_part[w * 64 + lane];
+        const uint32_t c = SVOXT_ROLES_CSUM != 0 ? tile_checksum(ax != 0u ? x : 0u, ax, lane) : (uint32_t)(ent >> 32);
+        if (lane == 0) {
         if (c == (uint32_t)(ent >> 32)) {
             tile_state[tile] = kTileShaded;                      // (read by the fallback launch: after this kernel)
             atomicAdd(ctrs + kRoleCtrShaded, 1);
         } else {
             atomicAdd(ctrs + kRoleCtrMismatch, 1);               // stale (or, with the test flag, made to look so): the fallback launch shades it again
+        }
         }
     }
 }
@@ -778,11 +823,17 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
 #ifndef SVOXT_CHAN_SWIZZLE
 #define SVOXT_CHAN_SWIZZLE 1
 #endif
-template <int K, bool STOP, bool FAST>
+// ETAB (exact mode, r04): the rows are read from tr.etab (exp_table_kernel): a channel lane's float IS its exponential,
+// and the attenuations of a block's eight records -- the only exponentials left -- are formed by eight lanes of the
+// ray's group at once (lane c takes record c mod 8: sigma of that record from the sigma lane, delta_t from the lane's
+// own copy of the record line) instead of eight times by every lane; the quotients w / (1 + e) by div_unit_range.
+// Per record and lane ~30 vector instructions where the exact instance without the table executes 74 (r03 PMC).
+template <int K, bool STOP, bool FAST, bool ETAB = false>
 __global__ void __launch_bounds__(256)
 shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
                   uint4* __restrict__ aux, float* __restrict__ out) {
     static_assert(K == 8 || K == 16 || K == 32, "row widths with a channel-lane instance");
+    static_assert(!(ETAB && FAST), "the table holds the exact exponentials");
     constexpr int RPW = 64 / K;                                  // rays per wavefront
     const int lane = threadIdx.x & 63;
     const int c = lane & (K - 1);
@@ -834,7 +885,7 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
     // column address).
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     const bool is_sig = c == K - 1;
-    const char* __restrict__ col_base = reinterpret_cast<const char*>(tr.features) + 4 * c;
+    const char* __restrict__ col_base = reinterpret_cast<const char*>(ETAB ? tr.etab : tr.features) + 4 * c;
     constexpr float kNegLog2e = -1.44269504088896341f;
     // FAST: exponent of 2 = x * sc with sc = fma(dt, mult, base): sigma lane dt * (-ds log2 e), channel lanes -log2 e
     const float sc_mult = is_sig ? ds * kNegLog2e : 0.f, sc_base = is_sig ? 0.f : kNegLog2e;
@@ -859,6 +910,21 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
             const uint32_t row = j < n_here ? idx[j] : 0u;       // (slots past the count hold stale bits)
             x[j] = *reinterpret_cast<const float*>(col_base + (size_t)row * (size_t)(K * 4));
         }
+        float att_mine = 1.f;                                    // ETAB: the attenuation of record (c mod 8) of this lane's ray
+        if constexpr (ETAB) {
+            // sigma of record j sits in the sigma lane's x[j]; lane c needs the one of record c mod 8 (and its own delta_t)
+            const int jm = c & (kRecBlock - 1);
+            float sg = 0.f, dm = 0.f;
+#pragma unroll
+            for (int j = 0; j < kRecBlock; ++j) {
+                const float sj = __shfl(x[j], sig_lane, 64);
+                sg = jm == j ? sj : sg;
+                dm = jm == j ? dt[j] : dm;
+            }
+            att_mine = pexpf(jm < n_here ? -dm * ds * sg : 0.f);
+#pragma unroll
+            for (int j = 0; j < kRecBlock; ++j) ex[j] = j < n_here ? x[j] : 1.f;      // (a position past the list: e = 1, as pexpf(0))
+        } else {
 #pragma unroll
         for (int j = 0; j < kRecBlock; ++j) {
             if constexpr (FAST) {
@@ -869,12 +935,15 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
                 ex[j] = pexpf(j < n_here ? arg : 0.f);
             }
         }
+        }
 #pragma unroll
         for (int j = 0; j < kRecBlock; ++j) {
-            const float att = __shfl(ex[j], sig_lane, 64);       // every lane takes part
+            const float att = ETAB ? __shfl(att_mine, (lane & ~(K - 1)) + j, 64)       // (K >= 8: lane j of the group exists)
+                                   : __shfl(ex[j], sig_lane, 64);                      // every lane takes part
             if (!STOP || !stopped) {
                 const float weight = light * (1.f - att);
                 if constexpr (FAST) acc = __builtin_fmaf(weight, __builtin_amdgcn_rcpf(1.f + ex[j]), acc);
+                else if constexpr (ETAB) acc = (float)((double)acc + div_unit_range((double)weight, 1.0 + (double)ex[j]));
                 else acc = (float)((double)acc + (double)weight / (1.0 + (double)ex[j]));
                 light *= att;
                 if constexpr (STOP) {

@@ -135,6 +135,8 @@ TreeDev to_dev(const svoxt_tree* t) {
     const bool use_accel = t->accel != nullptr && t->N == 2;
     d.accel = use_accel ? reinterpret_cast<const uint32_t*>(t->accel) : nullptr;
     d.accel_g = use_accel ? t->accel_log2 : 0;
+    // the exponentials table serves RGBA-style rows of 8 / 16 / 32 floats only
+    d.etab = (t->exp_table != nullptr && (t->K == 8 || t->K == 16 || t->K == 32)) ? t->exp_table : nullptr;
     return d;
 }
 
@@ -334,6 +336,9 @@ bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float
             const unsigned nbc = (unsigned)(((int64_t)nb * 64 / (64 / KK) + 3) / 4);                          \
             if (fast) hipLaunchKernelGGL((shade_chan_kernel<KK, STOP, true>), dim3(nbc), dim3(256), 0, st,    \
                                          tr, rays, opt, L, aux, out);                                    \
+            else if (tr.etab != nullptr)                                                                      \
+                hipLaunchKernelGGL((shade_chan_kernel<KK, STOP, false, true>), dim3(nbc), dim3(256), 0, st,   \
+                                   tr, rays, opt, L, aux, out);                                          \
             else hipLaunchKernelGGL((shade_chan_kernel<KK, STOP, false>), dim3(nbc), dim3(256), 0, st,        \
                                     tr, rays, opt, L, aux, out);                                         \
             if (fast) hipLaunchKernelGGL((tail_chan_kernel<KK, N2, true>), dim3(nb), dim3(256), 0, st,        \
@@ -648,6 +653,26 @@ int svoxt_sigma_mask_build(const svoxt_tree* tree, float sigma_thresh, void* mas
     const int64_t words = (tree->M + 63) / 64;
     hipLaunchKernelGGL(svoxt::sigma_mask_kernel, dim3((unsigned)((words + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
                        tree->features, tree->M, tree->K, sigma_thresh, reinterpret_cast<unsigned long long*>(mask));
+    return check_launch(fn);
+}
+
+int svoxt_exp_table_build(const svoxt_tree* tree, float sigma_thresh, void* mask, float* table, void* stream) {
+    const char* fn = "svoxt_exp_table_build";
+    int rc;
+    if ((rc = check_tree(tree, fn))) return rc;
+    if (tree->K != 8 && tree->K != 16 && tree->K != 32)
+        return fail(SVOXT_ERR_UNSUPPORTED, "%s: the table serves RGBA-style rows of 8, 16 or 32 floats", fn);
+    if (tree->M == 0) return SVOXT_OK;
+    if (table == nullptr || ((uintptr_t)table & 15u) != 0 || ((uintptr_t)tree->features & 15u) != 0)
+        return fail(SVOXT_ERR_INVALID, "%s: table is NULL, or table / features not 16-byte aligned", fn);
+    if (mask != nullptr && ((uintptr_t)mask & 7u) != 0) return fail(SVOXT_ERR_INVALID, "%s: mask not 8-byte aligned", fn);
+    const int64_t threads = tree->M * (tree->K / 4);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* mb = reinterpret_cast<uint8_t*>(mask);
+    if (tree->K == 8) hipLaunchKernelGGL((svoxt::exp_table_kernel<8>), grid, dim3(256), 0, st, tree->features, tree->M, sigma_thresh, mb, table);
+    else if (tree->K == 16) hipLaunchKernelGGL((svoxt::exp_table_kernel<16>), grid, dim3(256), 0, st, tree->features, tree->M, sigma_thresh, mb, table);
+    else hipLaunchKernelGGL((svoxt::exp_table_kernel<32>), grid, dim3(256), 0, st, tree->features, tree->M, sigma_thresh, mb, table);
     return check_launch(fn);
 }
 

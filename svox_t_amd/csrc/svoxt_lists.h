@@ -226,21 +226,31 @@ __device__ __forceinline__ void lds_barrier() {
 // A checksum of a tile's lists as its march wrote them (r04): handed to the shading workgroup of fwd_roles_kernel with the
 // tile id, recomputed there from what that workgroup LOADED -- a stale line (the hand-over rests on measured cache
 // behaviour, not on the memory model: see fwd_roles_kernel) then shows as a mismatch and the tile is left to the
-// fallback launch instead of being shaded from wrong records.  XOR-linear, so that each wavefront of the consumer can
-// fold the records it loaded by itself: a record contributes rec_hash(k, row, delta_t) to its ray's word, the ray's
-// word (with its list length | overflow flag mixed in) is rotated by the ray's lane, all 64 are XORed.
+// fallback launch instead of being shaded from wrong records.  Per ray: the XOR over its records of rec_hash(k, row,
+// delta_t) (XOR, so that the wavefronts of the consumer, which each load some list positions of all 64 rays, can fold
+// what they loaded by themselves and combine per ray afterwards); per tile: every ray's word, with its list length |
+// overflow flag mixed in, put through a bijection of its lane with full avalanche -- a difference in ONE ray always
+// shows, differences in several cancel with probability 2^-32 -- and XORed over the 64 lanes.
 __device__ __forceinline__ uint32_t rec_hash(int k, uint32_t idx, uint32_t dt_bits) {
-    return __builtin_rotateleft32(idx, (uint32_t)k & 31u) ^ __builtin_rotateleft32(dt_bits, (uint32_t)(5 * k + 11) & 31u);
+    const uint32_t kk = (uint32_t)k;
+    return __builtin_rotateleft32(idx + kk * 0x9E3779u, kk & 31u) ^ __builtin_rotateleft32(dt_bits ^ kk, (5u * kk + 11u) & 31u);
 }
 __device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v ^= (uint32_t)__shfl_xor((int)v, off, 64);
     return v;
 }
-// (the part of a tile's checksum that one wavefront holds: rays_xor = XOR of rec_hash over the records this lane
-// saw; ax = the ray's aux.x, given by ONE of the wavefronts that fold a tile, 0 by the others)
-__device__ __forceinline__ uint32_t tile_checksum_part(uint32_t rays_xor, uint32_t ax, int lane) {
-    return wave_xor(__builtin_rotateleft32(rays_xor ^ (ax * 0x9E3779B1u), (uint32_t)lane & 31u));
+// (rays_xor: XOR of rec_hash over ALL records of this lane's ray; ax: the ray's aux.x; 0 / 0 for a lane without a ray.)
+// Per lane a bijection with full avalanche (murmur3's finalizer on the word offset by the lane): a first version that
+// only multiplied by an odd number of the lane let the SAME small difference in every lane -- which is what the test's
+// "stale" records are -- cancel in the XOR over the lanes once in ~2 000 tiles (measured: one tile in 690 shaded from
+// perturbed records and marked good); with the finalizer 0 of 2 000 000 simulated tiles per flipped bit.
+__device__ __forceinline__ uint32_t tile_checksum(uint32_t rays_xor, uint32_t ax, int lane) {
+    uint32_t h = (rays_xor ^ (ax * 0x9E3779B1u)) + (uint32_t)lane * 0x9E3779B1u;
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return wave_xor(h);
 }
 
 // CHECK instances of the per-tile backwards (svoxt_set_bwd_check; r04): every index into an LDS array, a private

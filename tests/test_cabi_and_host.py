@@ -48,7 +48,7 @@ def test_struct_layouts_match_header(tmp_path):
                    ctypes.sizeof(_C._CLists), _C._CRays.c2w.offset, _C._CRays.fy.offset, _C._CTree.accel_log2.offset,
                    _C._CTree.xform_dim.offset, ctypes.sizeof(_C._CMotion), _C._CLists.coef_bytes.offset,
                    _C._CTree.sigma_mask_thresh.offset, _C._CLists.flags.offset]
-    assert got[:3] == [44, 64, 128]
+    assert got[:3] == [44, 64, 136]                     # (svoxt_tree grew by exp_table in ABI v17)
 
 
 def test_no_kernel_keeps_private_arrays_in_scratch_memory():

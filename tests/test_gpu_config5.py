@@ -72,11 +72,12 @@ def test_config5_eight_cameras_depth9_features32_one_rank(gpu, capsys):
             tight += tk
         assert_grads_close(feats.grad.cpu().numpy(), want, tight, what="8 cameras, summed")
         # ---- memory: one rank's share per camera is lists 206 MiB + hand-over 206 MiB + pixels 128 MiB; here eight of
-        # them are alive at once (the forwards of all cameras precede the first backward), plus the gathered
+        # them are alive at once (the forwards of all cameras precede the first backward; each also holds its 578 MiB table of
+        # exponentials, r04), plus the gathered
         # [8, 1024, 1024, 32] (1 GiB), the upstream gradient (1 GiB) and two gradient tables (578 MiB each)
         with capsys.disabled():
             print(f"\n[config 5 on one rank] peak device memory above the tree: forward {peak_fwd / MIB:.0f} MiB, "
                   f"forward+backward {peak / MIB:.0f} MiB; gathered result {full.numel() * 4 / MIB:.0f} MiB")
-        assert peak < 12 * 1024 * MIB, peak
+        assert peak < 16 * 1024 * MIB, peak
     finally:
         dist.destroy_process_group()

@@ -117,11 +117,11 @@ def test_rescue_path_reproduces_pixels_lists_and_handover(name, gpu, monkeypatch
         assert (grad - grad0).abs().max().item() <= 1e-6 * grad0.abs().max().item(), f"flags {flags:#x}: gradient"
         # every tile with a sample is shaded exactly once that counts: in the launch (checksum equal) or by the fallback
         assert shaded + fallback == busy, (flags, ctr, busy)
-        if flags & D:
-            assert dropped > 0 and fallback >= dropped
-        if flags & S:
-            assert mismatch > 0 and fallback >= mismatch
-        assert fallback >= dropped + mismatch                   # (+ what consumers that gave up, or never came, left behind; an
+        if flags & D and not flags & N:                         # (with N a small grid's consumers all give up before they take a tile)
+            assert dropped > 0 and fallback >= dropped, ctr
+        if flags & S and not flags & N:
+            assert mismatch > 0 and fallback >= mismatch, ctr
+        assert fallback >= dropped + mismatch, ctr              # (+ what consumers that gave up, or never came, left behind; an
                                                                 #  entry nobody waited for may also name a tile without samples)
         if not flags & (D | N | S):
             assert mismatch == 0, f"flags {flags:#x}: a hand-over read something its march had not written: {ctr}"
