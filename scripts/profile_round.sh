@@ -5,7 +5,7 @@
 #   scripts/profile_round.sh <outdir under gpurun_out> [a|b|all]     then copy what is to be judged into profiles/
 #   (a: the headline config and the f-rows; b: configs[3], exact and native math)
 set -u
-ROUND=r03      # = bench.py's ROUND
+ROUND=r04      # = bench.py's ROUND
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-prof}
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT

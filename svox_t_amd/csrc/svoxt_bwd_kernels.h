@@ -13,6 +13,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef SVOXT_WIDE_ETAB_WAVES
+#define SVOXT_WIDE_ETAB_WAVES 8          // wavefronts per SIMD the table instance of grad_wide_kernel is compiled for (8: four workgroups per CU)
+#endif
+
 namespace svoxt {
 
 // ---------------------------------------------------------------------------
@@ -1231,7 +1235,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 // the double-precision reciprocals 1 / (1 + e) take rcp_unit_range (the compiler's division sequence minus what their
 // operand range makes an identity).  The same bits.
 template <int K, bool FAST = false, bool COUNT = false, bool CHECK = false, bool ETAB = false>
-__global__ void __launch_bounds__(512, FAST ? 8 : 6)
+__global__ void __launch_bounds__(512, FAST ? 8 : ETAB ? SVOXT_WIDE_ETAB_WAVES : 6)
 grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                  RecLists L, const uint4* __restrict__ aux, float* __restrict__ grad, int gstride,
                  unsigned long long* __restrict__ counters = nullptr) {
@@ -1320,6 +1324,32 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
         // the sums over the channels run in the reference's order, handed from lane to lane
         constexpr int G = K / 8;
         const int gq = threadIdx.x & (G - 1);
+        if constexpr (!FAST && ETAB) {
+            // (r04) lane = RECORD, the whole row: with the exponentials in the table a column costs a reciprocal and two
+            // products, and what dominated the G-lanes-per-record form below was its bookkeeping -- the two ordered sums
+            // over the channels hopped from lane to lane G - 1 times, every hop's eight-step chain issued for all G lanes
+            // with one of them active: 195 of the 328 instructions per record and lane (ISA, K = 32).  Here a lane runs
+            // its record's 31 columns in order by itself: the same operations in the same order, ~17 instructions per
+            // column, no shuffle; a window's first positions hold up to 1 024 records for the 512 lanes.
+            for (int p = threadIdx.x; p < nb1; p += NT) {
+                const int slot = SVOXT_CHK((int)order[SVOXT_CHK(p, R, 17)], R, 18);
+                const int ray = slot & 63;
+                float row[K];
+                load_row<K>(rows + (int64_t)SVOXT_CHK((int32_t)r_sl[slot], tr.M, 19) * K, row);
+                const float* __restrict__ gr = gl + ray * KG;
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const double sd = rcp_unit_range(1.0 + (double)row[c]);
+                    const float gj = gr[c];
+                    t1 += (float)sd * gj;
+                    t2 = (float)((double)t2 + sd * (double)gj);
+                }
+                r_w[slot] = pexpf<true>(-r_dt[slot] * row[K - 1] * dsl[ray]);
+                r_t1[slot] = t1;
+                r_sg[slot] = t2;
+            }
+        } else
         for (int p0 = wave * (64 / G); p0 < nb1; p0 += NT / G) {      // (scalar bounds: every lane takes part in the shuffles)
             const int p = p0 + (lane / G);
             const bool on = p < nb1;
