@@ -524,32 +524,6 @@ def _grad_scratch(dev, M: int, stride: int):
     return ent
 
 
-# Rows of 8 / 16 / 32 floats accumulate their gradient straight into the dense [M, K] tensor the caller gets (a row is
-# whole 64-byte lines as it stands: no padded scratch, no compaction), which therefore starts as M * K * 4 bytes of
-# zeros per step: 606 MB at depth 9 / K = 32, ~0.08 ms of pure streaming in front of the backward.  The forward that
-# records for that backward knows the buffer will be needed: it allocates it and has it zeroed on a SIDE stream, beside
-# its own kernels (a march bound by the latency of its longest ray leaves the memory system mostly idle), and the
-# backward waits for that fill's event instead of filling.  SVOXT_GRAD_PREZERO=0: the backward fills by itself.
-GRAD_PREZERO = _env_flag("SVOXT_GRAD_PREZERO", "1")
-_SIDE_STREAMS: dict = {}
-
-
-def _prezeroed_grad(dev, M: int, K: int):
-    """(zeroed [M, K] buffer, event after which it is zero) -- the fill runs on a side stream from here on."""
-    cur = torch.cuda.current_stream(dev)
-    side = _SIDE_STREAMS.get(dev)
-    if side is None:
-        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(dev)
-    buf = torch.empty((M, K), dtype=torch.float32, device=dev)
-    side.wait_stream(cur)                       # whatever used this memory before is ordered in front of the fill
-    with torch.cuda.stream(side):
-        buf.zero_()
-        ev = torch.cuda.Event()
-        ev.record(side)
-    buf.record_stream(side)
-    return buf, ev
-
-
 def invalidate_caches(*tensors) -> None:
     """Drop what this module derived from the CONTENT of the given tensors (child / data: the acceleration
     grid; features: a cached sigma bitmask) and bump their torch version counters.  For writers that bypass
@@ -709,7 +683,6 @@ class SampleLists:
         self.terms = None       # (att, e0, e1, e2) per record slot for the exact one-kernel backward
         self.terms_state = 0    # 2: filled by the forward; 0: scratch (the backward's first sweep fills it)
         self.exp_table = None   # rows of 8 / 16 / 32 floats: the exponentials table the forward built (svoxt_tree.exp_table)
-        self.grad_buf = None    # rows of 8 / 16 / 32 floats: (the backward's [M, K] gradient, zeroed on a side stream; its event)
         self.flags = 0          # svoxt_sample_lists.flags: how the kernels that write / read these lists work
 
     def note_usage(self):
@@ -984,8 +957,6 @@ def _volume_render(tree, rays, opt, record):
             lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
             lists.flags = lflags
             lists.exp_table = etab
-            if wide and split and GRAD_PREZERO and BWD_GATHER and BWD_TERMS and BWD_FUSED and ct.M > 0:
-                lists.grad_buf = _prezeroed_grad(dev, ct.M, ct.K)       # (zeroed beside the kernels launched below)
             if fills:
                 # the exact per-tile backward will want (att, e0, e1, e2) of every sample: this forward has them
                 lists.terms = torch.empty((lists.pool_blocks * 512 * 4,), dtype=torch.float32, device=dev)
@@ -1079,14 +1050,7 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
         gather = False
     with torch.cuda.device(dev):
         kept = _grad_scratch(dev, M, stride) if (GRAD_SCRATCH and lists is not None and stride != K and M > 0) else None
-        pre = None
-        if lists is not None and lists.grad_buf is not None:
-            pre, lists.grad_buf = lists.grad_buf, None            # (serves one backward)
-            if stride != K or tuple(pre[0].shape) != (M, K) or pre[0].device != dev:
-                pre = None
-        if pre is not None:
-            torch.cuda.current_stream(dev).wait_event(pre[1])
-        buf = kept[0] if kept is not None else pre[0] if pre is not None else torch.empty((M, stride), dtype=torch.float32, device=dev)
+        buf = kept[0] if kept is not None else torch.empty((M, stride), dtype=torch.float32, device=dev)
         if lists is not None:
             if lists.aux.shape[0] != cr.Q or lists.aux.device != dev:
                 raise RuntimeError("sample lists do not belong to this ray batch")
@@ -1132,7 +1096,7 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
                 "render_bwd_kernel<REPLAY> (list walk, one atomic row per sample)")
             if fused or wide_tile:
                 cl.coef_bytes = -1            # list walk and merge as one kernel: no buffer, rec stays as recorded
-            if kept is not None or pre is not None:
+            if kept is not None:
                 cl.flags |= LISTS_GRAD_ZEROED
             _call("svoxt_volume_render_bwd_replay", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(grad_output), grad_output.shape[1], _ptr(buf), stride, ctypes.byref(cl), _ptr(fo),

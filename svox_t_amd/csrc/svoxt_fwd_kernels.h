@@ -828,11 +828,8 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
 // ray's group at once (lane c takes record c mod 8: sigma of that record from the sigma lane, delta_t from the lane's
 // own copy of the record line) instead of eight times by every lane; the quotients w / (1 + e) by div_unit_range.
 // Per record and lane ~30 vector instructions where the exact instance without the table executes 74 (r03 PMC).
-#ifndef SVOXT_CHAN_ETAB_WAVES
-#define SVOXT_CHAN_ETAB_WAVES 1          // min wavefronts per SIMD the table instance of shade_chan_kernel is compiled for (1: unconstrained)
-#endif
 template <int K, bool STOP, bool FAST, bool ETAB = false>
-__global__ void __launch_bounds__(256, ETAB ? SVOXT_CHAN_ETAB_WAVES : 1)
+__global__ void __launch_bounds__(256)
 shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
                   uint4* __restrict__ aux, float* __restrict__ out) {
     static_assert(K == 8 || K == 16 || K == 32, "row widths with a channel-lane instance");

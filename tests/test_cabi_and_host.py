@@ -85,7 +85,9 @@ def test_no_kernel_keeps_private_arrays_in_scratch_memory():
     # compile-time-offset register spills, stored under a full EXEC mask: no private array in memory, no index that
     # could leave it; the checked instances (tests/test_gpu_checked_backward.py) find no LDS / pool / table index
     # out of range at any full-size geometry either.
-    assert all(v <= 48 for v in worst.values()), worst
+    # (r04: the table instances of grad_wide_kernel are compiled for 64 registers -- four workgroups per CU: backward
+    # 1.70 -> 1.59 ms at depth 9 -- and keep 36-52 bytes of loop invariants in scratch for it)
+    assert all(v <= 64 for v in worst.values()), worst
     import re
 
     def instrumentation(k):
