@@ -13,9 +13,6 @@
 
 #pragma clang fp contract(off)
 
-#ifndef SVOXT_WIDE_PF
-#define SVOXT_WIDE_PF 1                  // the table instance of grad_wide_kernel requests a window's records a window ahead
-#endif
 #ifndef SVOXT_WIDE_ETAB_WAVES
 #define SVOXT_WIDE_ETAB_WAVES 8          // wavefronts per SIMD the table instance of grad_wide_kernel is compiled for (8: four workgroups per CU)
 #endif
@@ -1290,18 +1287,6 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
     if (threadIdx.x == 0) { s_nb = 0; s_ns = 0; }
     lds_barrier();
 
-    // (r04, table instances) With the arithmetic halved the kernel waits: 70 % of its wavefront-cycles (PMC), a window
-    // being a chain of barrier-separated phases with two trips to memory in each sweep.  The first of them -- the
-    // window's records (and, in sweep 2, the hand-over) -- is requested a WINDOW ahead: by every lane, at a position
-    // some ray of the tile has (its block exists; a lane whose list is shorter reads a stale slot and ignores it).
-    constexpr bool PF = ETAB && SVOXT_WIDE_PF != 0;
-    auto rec_at = [&](int k) {
-        k = min(k, maxn - 1);
-        return rec_get(L.rec + rec_index_in(SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 16), lane, k));
-    };
-    uint2 e_nx[RPP];
-#pragma unroll
-    for (int rd = 0; rd < RPP; ++rd) e_nx[rd] = PF ? rec_at(rd * W + wave) : make_uint2(0u, 0u);
     // ---- sweep 1
     float light1 = 1.f, accum = 0.f, light_ray = 1.f;
     for (int k0 = 0; k0 < maxn; k0 += RPP * W) {
@@ -1313,18 +1298,8 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
             for (int rd = 0; rd < RPP; ++rd) {
                 const int k = k0 + rd * W + wave;
                 have[rd] = k < nrec;
-                if constexpr (PF) {
-                    e[rd] = e_nx[rd];
-                } else {
-                    e[rd] = make_uint2(0u, 0u);
-                    if (have[rd]) e[rd] = rec_get(L.rec + rec_index_in(SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 16), lane, k));
-                }
-            }
-            if constexpr (PF) {
-                if (k0 + RPP * W < maxn) {                   // (scalar) the next window's, in flight across this one
-#pragma unroll
-                    for (int rd = 0; rd < RPP; ++rd) e_nx[rd] = rec_at(k0 + RPP * W + rd * W + wave);
-                }
+                e[rd] = make_uint2(0u, 0u);
+                if (have[rd]) e[rd] = rec_get(L.rec + rec_index_in(SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 16), lane, k));
             }
 #pragma unroll
             for (int rd = 0; rd < RPP; ++rd) {
@@ -1491,18 +1466,6 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
     for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
     for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
     lds_barrier();
-    float2 h_nx[RPP];
-    auto both_at = [&](int k, uint2& e, float2& h) {
-        k = min(k, maxn - 1);
-        const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 16);
-        e = rec_get(L.rec + rec_index_in(blk, lane, k));
-        h = tot2[terms_index_pm(blk, lane, k)];
-    };
-#pragma unroll
-    for (int rd = 0; rd < RPP; ++rd) {
-        h_nx[rd] = make_float2(0.f, 0.f);
-        if constexpr (PF) both_at(rd * W + wave, e_nx[rd], h_nx[rd]);
-    }
     for (int k0 = 0; k0 < maxn; k0 += RPP * W) {
         {   // the window's two rounds together: records and hand-over first, then the sigma gathers, then the table
             uint2 e[RPP];
@@ -1512,23 +1475,12 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
             for (int rd = 0; rd < RPP; ++rd) {
                 const int k = k0 + rd * W + wave;
                 have[rd] = k < nrec;
-                if constexpr (PF) {
-                    e[rd] = e_nx[rd];
-                    h[rd] = h_nx[rd];
-                } else {
-                    e[rd] = make_uint2(0u, 0u);
-                    h[rd] = make_float2(0.f, 0.f);
-                    if (have[rd]) {
-                        const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 16);
-                        e[rd] = rec_get(L.rec + rec_index_in(blk, lane, k));
-                        h[rd] = tot2[terms_index_pm(blk, lane, k)];
-                    }
-                }
-            }
-            if constexpr (PF) {
-                if (k0 + RPP * W < maxn) {                   // (scalar) the next window's, in flight across this one
-#pragma unroll
-                    for (int rd = 0; rd < RPP; ++rd) both_at(k0 + RPP * W + rd * W + wave, e_nx[rd], h_nx[rd]);
+                e[rd] = make_uint2(0u, 0u);
+                h[rd] = make_float2(0.f, 0.f);
+                if (have[rd]) {
+                    const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 16);
+                    e[rd] = rec_get(L.rec + rec_index_in(blk, lane, k));
+                    h[rd] = tot2[terms_index_pm(blk, lane, k)];
                 }
             }
 #pragma unroll
