@@ -713,11 +713,32 @@ __device__ __forceinline__ unsigned long long pop_tile(int32_t* __restrict__ til
     return ent;
 }
 
+// (r04) Which tiles a marching workgroup takes.  Workgroup b runs on XCD b mod 8 (observed; nothing depends on it but
+// speed), and left alone marching workgroup b takes tiles 8 b .. 8 b + 7: every XCD gets every eighth 64 x 8 pixel strip
+// of every tile row, so no two vertically neighbouring strips -- whose rays cross the same leaves -- share an L2, and
+// each of the eight L2s fetches (almost) every feature row and tree word of the view (r03 PMC: 373 MB fetched for
+// ~110 MB of distinct lines).  RolesMap.gb > 0: the groups of 8 tiles are cut into BANDS of gb consecutive groups (two
+// tile rows of an 800-pixel image), band B goes to XCD B mod 8, and the workgroups of an XCD walk its bands in order:
+// a band's neighbours in the image are on the same L2, bands of one XCD are spread over the whole image (a contiguous
+// eighth per XCD leaves seven XCDs waiting for the one that has the shell's middle: r03).  cnt[x]: the tiles XCD x's
+// marching workgroups hold = the shading workgroups its queue needs.  gb == 0: the plain order.
+// (the last round of bands is cut to gb_last groups each, so that every XCD ends with the same share of what is left)
+struct RolesMap {
+    int gb, full, gb_last;       // groups per band, rounds of 8 full bands, groups per band of the last round
+    int cnt[8];
+};
+__host__ __device__ inline int64_t roles_group_of(const RolesMap& m, int b) {      // marching workgroup b -> its group of 8 tiles
+    if (m.gb <= 0) return b;
+    const int x = b & 7, s = b >> 3;
+    if (s < m.full * m.gb) return ((int64_t)(s / m.gb) * 8 + x) * m.gb + s % m.gb;
+    return (int64_t)m.full * 8 * m.gb + (int64_t)x * m.gb_last + (s - m.full * m.gb);
+}
+
 template <int FMT, int BD, int ACC, bool WTERMS, bool LOBES = false>
 __global__ void __launch_bounds__(512)
 fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux, float* __restrict__ out,
                  const uint32_t* __restrict__ sigma_mask, int32_t* __restrict__ tile_state, int n_march, int ntiles,
-                 int tflags /* kRoleTest* | kRoleAgentFence: 0 in production */) {
+                 int tflags /* kRoleTest* | kRoleAgentFence: 0 in production */, RolesMap map) {
     constexpr int kMarchBytes = 8 * (kRecBlock * 64 * (int)sizeof(uint2) + kMaxRecBlocks * (int)sizeof(int32_t));
     constexpr int kShadeBytes = 2 * kShadeP * 64 * (int)sizeof(shade_v4f);
     __shared__ __attribute__((aligned(16))) unsigned char lds[kMarchBytes > kShadeBytes ? kMarchBytes : kShadeBytes];
@@ -726,7 +747,7 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
     const bool agent_fence = (tflags & kRoleAgentFence) != 0;
     int32_t* const ctrs = tile_state + roles_even(ntiles);
     if ((int)blockIdx.x < n_march) {
-        const int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+        const int64_t tile = roles_group_of(map, (int)blockIdx.x) * 8 + wave;
         if (tile >= ntiles) return;
         uint2* rstage = reinterpret_cast<uint2*>(lds) + wave * (kRecBlock * 64);
         int32_t* ltab = reinterpret_cast<int32_t*>(lds + 8 * kRecBlock * 64 * sizeof(uint2)) + wave * kMaxRecBlocks;
@@ -762,10 +783,7 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
     }
     // is this shading workgroup one of those its XCD needs?  (see above; the same in every wavefront)
     const int i = (int)blockIdx.x - n_march, a = i & 7, b = i >> 3;
-    const int G = (ntiles + 7) >> 3;                             // march workgroups that hold tiles
-    int mine = a < G ? 8 * ((G - a + 7) >> 3) : 0;
-    if (((G - 1) & 7) == a) mine -= 8 * G - ntiles;              // the last march workgroup may be partial
-    if (b >= mine) return;
+    if (b >= map.cnt[a]) return;                                 // (cnt: tiles of the marching workgroups congruent to a mod 8)
     if (threadIdx.x == 0) s_ent = pop_tile(tile_state, ntiles, (tflags & kRoleTestNoPoll) ? 1 : kRolePolls);
     __syncthreads();
     const unsigned long long ent = s_ent;

@@ -187,6 +187,35 @@ bool launch_fwd_xform(const TreeDev& tr, const RaysDev& rays, const Opts& opt, i
     return false;
 }
 
+#ifndef SVOXT_ROLES_BAND_ROWS
+#define SVOXT_ROLES_BAND_ROWS 0          // tile rows per band of fwd_roles_kernel's marching order (0: the plain order)
+#endif
+// fwd_roles_kernel's launch shape: the marching workgroups' tile map (RolesMap), how many of them, and the grid
+struct RolesLaunch { RolesMap map; int n_march; unsigned grid; };
+inline RolesLaunch roles_launch(unsigned nb, int tiles_per_row) {
+    RolesLaunch r;
+    const int G = (int)((nb + 7) / 8);                              // groups of 8 tiles
+    int gb = 0;
+    if (SVOXT_ROLES_BAND_ROWS > 0) {
+        gb = tiles_per_row > 0 ? (SVOXT_ROLES_BAND_ROWS * tiles_per_row + 7) / 8 : 32;
+        if (gb < 1 || G <= 8 * gb) gb = 0;                           // (fewer than a band per XCD: nothing to arrange)
+    }
+    r.map.gb = gb;
+    r.map.full = gb > 0 ? G / (8 * gb) : 0;                         // rounds of eight full bands
+    const int rest = gb > 0 ? G - r.map.full * 8 * gb : 0;          // groups left for the last round
+    r.map.gb_last = gb > 0 ? (rest + 7) / 8 : 0;
+    r.n_march = gb > 0 ? 8 * (r.map.full * gb + r.map.gb_last) : (G + 7) / 8 * 8;
+    int mx = 0;
+    for (int x = 0; x < 8; ++x) r.map.cnt[x] = 0;
+    for (int b = 0; b < r.n_march; ++b) {                            // (a few thousand iterations per launch)
+        const int64_t t0 = roles_group_of(r.map, b) * 8;
+        if (t0 < (int64_t)nb) r.map.cnt[b & 7] += (int)((int64_t)nb - t0 < 8 ? (int64_t)nb - t0 : 8);
+    }
+    for (int x = 0; x < 8; ++x) if (r.map.cnt[x] > mx) mx = r.map.cnt[x];
+    r.grid = (unsigned)r.n_march + 8u * (unsigned)mx;
+    return r;
+}
+
 // ... with sample lists: the recording forward as march + tile shade + tail launch, leaving the backward's hand-over
 // (position-major: terms_state 3), and the per-tile backward over it -- the exact one-kernel form only.
 template <bool N2>
@@ -198,12 +227,14 @@ bool launch_lobes_fwd_record(const TreeDev& tr, const RaysDev& rays, const Opts&
     if constexpr (N2) {
         // march and shade in one launch (fwd_roles_kernel<..., LOBES>) where SH takes it too: up to 16 lobes, grid at hand
         if (tile_state != nullptr && sigma_mask != nullptr && acc && opt.basis_dim <= 16 && nb < (1u << 30)) {
-            const int n_march = (int)(((nb + 7) / 8 + 7) / 8 * 8);
-            const unsigned grid = (unsigned)n_march + (unsigned)n_march * 8;
+            const RolesLaunch rl = roles_launch(nb, rays.tiles_per_row);
+            const int n_march = rl.n_march;
+            const unsigned grid = rl.grid;
+            const RolesMap rmap = rl.map;
 #define SVOXT_LOBES_ROLES(BB)                                                                                       \
     {                                                                                                               \
         hipLaunchKernelGGL((fwd_roles_kernel<FMT_SH, BB, 1, true, true>), dim3(grid), dim3(512), 0, st,             \
-                           tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags);           \
+                           tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap);     \
         hipLaunchKernelGGL((shade_tile_kernel<FMT_SH, BB, false, false, true, true>), dim3(nb), dim3(512), 0, st,   \
                            tr, rays, opt, L, aux, out, (const int32_t*)tile_state);                                 \
         hipLaunchKernelGGL((render_fwd_kernel<FMT_SH, 3, BB, true, false, false, true, true>), dim3(nb), dim3(kBlock), \
@@ -392,20 +423,22 @@ bool launch_fwd_roles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
     } else {
         const unsigned nb = nblocks(rays.Q);
         if (nb >= (1u << 30)) return false;
-        const int n_march = (int)(((nb + 7) / 8 + 7) / 8 * 8);          // a multiple of 8: see fwd_roles_kernel
-        const unsigned grid = (unsigned)n_march + (unsigned)n_march * 8;   // + 8 shading workgroups per march workgroup (the active ones: one per tile)
+        const RolesLaunch rl = roles_launch(nb, rays.tiles_per_row);
+        const int n_march = rl.n_march;                                 // a multiple of 8: see fwd_roles_kernel
+        const unsigned grid = rl.grid;                                  // + the shading workgroups (the active ones: one per tile)
+        const RolesMap rmap = rl.map;
         const bool acc = tr.accel != nullptr;
         const bool wt = L.terms != nullptr;
 #define SVOXT_ROLES(F, BB)                                                                                        \
         {                                                                                                         \
             if (acc && wt) hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 1, true>), dim3(grid), dim3(512), 0, st,   \
-                                              tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags); \
+                                              tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
             else if (acc) hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 1, false>), dim3(grid), dim3(512), 0, st,   \
-                                             tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags); \
+                                             tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
             else if (wt) hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 0, true>), dim3(grid), dim3(512), 0, st,     \
-                                            tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags); \
+                                            tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
             else hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 0, false>), dim3(grid), dim3(512), 0, st,            \
-                                    tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags); \
+                                    tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
             if (wt) hipLaunchKernelGGL((shade_tile_kernel<F, BB, false, false, true>), dim3(nb), dim3(512), 0, st, \
                                        tr, rays, opt, L, aux, out, (const int32_t*)tile_state);                   \
             else hipLaunchKernelGGL((shade_tile_kernel<F, BB, false, false, false>), dim3(nb), dim3(512), 0, st,  \
