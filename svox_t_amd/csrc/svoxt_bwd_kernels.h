@@ -1136,7 +1136,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             {   // (experiment: the table's two random accesses a second time, at another entry; a counter nobody reads)
                 const uint32_t h2 = (h * 37u + 11u) & (uint32_t)(T - 1);
                 asm volatile("" :: "v"(atomicCAS(keys + h2, -2, -2)));
-                atomicAdd(&s_nb, 0);
+                atomicAdd(cnt + h2, 0);
             }
 #endif
             r_sl[slot] = (h << 6) | (uint32_t)lane;
