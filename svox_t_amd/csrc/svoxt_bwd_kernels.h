@@ -13,9 +13,6 @@
 
 #pragma clang fp contract(off)
 
-#ifndef SVOXT_FUSED_LDS_PROBE
-#define SVOXT_FUSED_LDS_PROBE 0          // 1 (experiment only): grad_fused_kernel issues each of its random LDS accesses twice -- what LDS conflicts can cost it
-#endif
 #ifndef SVOXT_WIDE_ETAB_WAVES
 #define SVOXT_WIDE_ETAB_WAVES 8          // wavefronts per SIMD the table instance of grad_wide_kernel is compiled for (8: four workgroups per CU)
 #endif
@@ -1132,13 +1129,6 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             }
             h = (uint32_t)SVOXT_CHK((int)h, T, 4);
             atomicAdd(cnt + h, 1);
-#if SVOXT_FUSED_LDS_PROBE
-            {   // (experiment: the table's two random accesses a second time, at another entry; a counter nobody reads)
-                const uint32_t h2 = (h * 37u + 11u) & (uint32_t)(T - 1);
-                asm volatile("" :: "v"(atomicCAS(keys + h2, -2, -2)));
-                atomicAdd(cnt + h2, 0);
-            }
-#endif
             r_sl[slot] = (h << 6) | (uint32_t)lane;
             r_w[slot] = att; r_sg[slot] = tc; r_dt[slot] = __uint_as_float(e.y);
             r_c[slot] = cf[0]; r_c[R + slot] = cf[1]; r_c[2 * R + slot] = cf[2];
