@@ -293,8 +293,8 @@ typedef struct svoxt_sample_lists {
                               one-kernel forward fills it (svoxt_fwd_fills_terms says whether it will); the
                               backward, told so by terms_state = 2 or 3 (what svoxt_fwd_fills_terms returned:
                               the layout the forward wrote), then gathers no feature row and forms no
-                              exponential in either of its sweeps.  terms_state = 0: scratch only -- the
-                              backward's first sweep fills it for the second.  Same bits every way.
+                              exponential in either of its sweeps.  terms_state = 0 (3-channel payloads, since ABI v17): the
+                              buffer is ignored and both sweeps gather the rows.  Same bits every way.
                               RGBA rows of 8 / 16 / 32 floats (C = 7 / 15 / 31): scratch between the two sweeps of
                               their exact backwards, 8 bytes per record slot for the per-tile kernel (attenuation,
                               second-pass total_color), 4 for the per-ray one; NULL or smaller: the per-ray list

@@ -1061,10 +1061,6 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
                     raise RuntimeError("fwd_output must match grad_output")
                 fo = fwd_output
             fused = gather and BWD_FUSED and ct.xform is None      # (fo None: the fused kernel's exact form)
-            if fused and fo is None and BWD_TERMS and lists.terms is None:
-                # sweep 1 -> sweep 2 hand-over: 16 bytes per list slot (when the forward did not leave them)
-                lists.terms = torch.empty((lists.pool_blocks * 512 * 4,), dtype=torch.float32, device=dev)
-                lists.terms_state = 0
             wide = co.format == FORMAT_RGBA and grad_output.shape[1] in (8, 16, 32) and K == grad_output.shape[1]
             # ... per tile (grad_wide_kernel) for coherent batches on N = 2 trees, else per ray (render_bwd_kernel<ONEPASS>)
             wide_tile = wide and fo is None and BWD_TERMS and BWD_FUSED and ct.N == 2 and ct.xform is None and \

@@ -121,22 +121,22 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
                            tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out, (float4*)nullptr);   \
         unsigned long long* ctr = reinterpret_cast<unsigned long long*>(g_bwd_counters);                      \
         unsigned long long* chkw = reinterpret_cast<unsigned long long*>(g_bwd_check);                        \
-        if (chkw != nullptr) {   /* the checked instance of the route that would run */                       \
-            if (fwd_out != nullptr)                                                                           \
-                hipLaunchKernelGGL((grad_fused_kernel<F, BB, false, false, 0, false, true>), dim3(nb), dim3(512), 0, st, \
-                                   tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);            \
-            else if (L.terms != nullptr && terms_state == 2)                                                  \
-                hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 2, false, true>), dim3(nb), dim3(512), 0, st, \
-                                   tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);            \
-            else if (L.terms != nullptr && terms_state == 3)                                                  \
+        if (chkw != nullptr) {   /* the checked instance of the route that would run: the default route (the forward's      \
+                                    position-major hand-over) for every payload, the other routes for SH9 */  \
+            if (L.terms != nullptr && terms_state == 3 && fwd_out == nullptr)                                 \
                 hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 3, false, true>), dim3(nb), dim3(512), 0, st, \
                                    tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);            \
-            else if (L.terms != nullptr)                                                                      \
-                hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 1, false, true>), dim3(nb), dim3(512), 0, st, \
-                                   tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);            \
-            else                                                                                              \
-                hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 0, false, true>), dim3(nb), dim3(512), 0, st, \
-                                   tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);            \
+            else if constexpr (F == FMT_SH && BB == 9) {                                                      \
+                if (fwd_out != nullptr)                                                                       \
+                    hipLaunchKernelGGL((grad_fused_kernel<F, BB, false, false, 0, false, true>), dim3(nb), dim3(512), 0, st, \
+                                       tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);        \
+                else if (L.terms != nullptr && terms_state == 2)                                              \
+                    hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 2, false, true>), dim3(nb), dim3(512), 0, st, \
+                                       tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);        \
+                else                                                                                          \
+                    hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 0, false, true>), dim3(nb), dim3(512), 0, st, \
+                                       tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw); \
+            } else return false;                                                                              \
             return true;                                                                                      \
         }                                                                                                     \
         if (fwd_out != nullptr && ctr == nullptr)                                                             \
@@ -148,10 +148,7 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
         else if (ctr == nullptr && L.terms != nullptr && terms_state == 3)                                    \
             hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 3>), dim3(nb), dim3(512), 0, st,        \
                                tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                      \
-        else if (ctr == nullptr && L.terms != nullptr)                                                        \
-            hipLaunchKernelGGL((grad_fused_kernel<F, BB, true, false, 1>), dim3(nb), dim3(512), 0, st,        \
-                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                      \
-        else if (ctr == nullptr)                                                                              \
+        else if (ctr == nullptr)   /* (no hand-over from the forward: both sweeps gather the rows) */         \
             hipLaunchKernelGGL((grad_fused_kernel<F, BB, true>), dim3(nb), dim3(512), 0, st,                  \
                                tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                 \
         else if (fwd_out != nullptr)                                                                          \
@@ -193,8 +190,7 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
                            tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out, (float4*)nullptr);        \
         unsigned long long* chkw = reinterpret_cast<unsigned long long*>(g_bwd_check);                        \
         if (chkw != nullptr && terms_state == 2)                                                              \
-            hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 2, false, true>), dim3(nb), dim3(512), 0, st, \
-                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);                \
+            return false;                                                                                     \
         else if (chkw != nullptr)                                                                             \
             hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 3, false, true>), dim3(nb), dim3(512), 0, st, \
                                tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride, chkw);                \

@@ -822,10 +822,10 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
 // of their own value (r02, tests/test_gpu_query_and_misc.py) -- opt-in.
 // COUNT (instrumentation, svoxt_set_bwd_counters): counters[0] += 64-byte atomic requests sent,
 // counters[1] += (tile, pass, feature row) groups; the work itself is unchanged.
-// TERMS (EXACT only): 1 = sweep 1 hands (att, e_0, e_1, e_2) of every sample to sweep 2 through
-// L.terms (position-major); 2 / 3 = the recording forward left them there (render_fwd_kernel:
-// lane-major lines; shade_tile_kernel: position-major): neither sweep gathers a feature row or forms
-// an exponential.
+// TERMS (EXACT only): 2 / 3 = the recording forward left (att, e_0, e_1, e_2) of every sample in L.terms
+// (render_fwd_kernel: lane-major lines; shade_tile_kernel: position-major): neither sweep gathers a feature
+// row or forms an exponential; 0 = both sweeps gather the rows.  (1, a hand-over from sweep 1 to sweep 2 for
+// lists whose forward left none, existed until r04: no caller of the operator layer reached it.)
 // Two workgroups per CU (77 KB of LDS each) need at most 128 registers: said to the compiler,
 // because one branch too many costs exactly that (r02: 116 -> 130 registers, 0.38 -> 0.55 ms).
 // LOBES (FMT_SH instances over the forward's hand-over): the 64 rays' basis values are those of opt.format = SG or ASG.
@@ -860,6 +860,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     constexpr int HALF = K < 16 ? K : 16;                    // columns 0-15 / 16-31 / ...: see grad_merge_kernel
     constexpr int NH = (K + HALF - 1) / HALF;                // rounds of columns in the reduce
     constexpr int KS = HALF | 1;                             // staging row: one round of columns
+    static_assert(TERMS == 0 || TERMS == 2 || TERMS == 3, "hand-over layouts");
     static_assert(K <= 32 || (EXACT && TERMS >= 2), "wide rows: only with the forward's hand-over (no row in registers)");
     static_assert(!LOBES || (FMT == FMT_SH && EXACT && TERMS >= 2), "lobes: only over the forward's hand-over");
     __shared__ int32_t keys[T];
@@ -999,9 +1000,6 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                         }
                         ex[c] = pexpf<true>(-x);
                     }
-                    // sweep 2 needs the same attenuation and the same three exponentials: 16 bytes per
-                    // sample instead of gathering the row and forming them again
-                    if constexpr (TERMS == 1) terms[terms_index_pm(blk, lane, k)] = make_float4(att, ex[0], ex[1], ex[2]);
                 }
                 float total_color = 0.f;
 #pragma unroll
@@ -1029,7 +1027,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                     }
                 }
             }
-            if constexpr (TERMS >= 2) lds_barrier();         // (TERMS 1: this sweep's global stores are read by the next)
+            if constexpr (TERMS >= 2) lds_barrier();
             else __syncthreads();
         };
         for (int rd = 0;;) {                                 // rounds 0 .. nr1 (the last one only advances)
