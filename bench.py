@@ -422,6 +422,10 @@ def main():
             # (att, e0, e1, e2) per sample, left by the recording forward for the exact backward
             "backward_terms_written": 16 * A if (recording and forward_terms) else 0,
         }
+        if fmt == "RGBA" and K in (8, 16, 32) and _C.EXP_TABLE and not _C.NATIVE_MATH and "shade_chan" in (route_fwd or ""):
+            # the exponentials table (svoxt_tree.exp_table): every forward that is not told the features are static
+            # reads the feature table once and writes the table once; the shade then reads ITS rows (counted above)
+            fwd_parts["exp_table_pass"] = 0 if args.forward_only else 2 * 4 * M * K
         bwd_parts = None
         kept_scratch = bool(_C.GRAD_SCRATCH and "render_bwd_kernel (marches" not in (route_bwd or ""))
         if not args.forward_only:
