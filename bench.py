@@ -492,9 +492,16 @@ def main():
         # phases over an atomic-request floor it does not reach -> "latency"; backward of wide rows in exact mode:
         # vector ALU (the bit-exact expf replica and a double-precision divide per sigmoid) -> "valu".
         wide_exact = "grad_wide_kernel" in (route_bwd or "") and "native" not in (route_bwd or "")
-        if dom == "backward" and wide_exact:
+        if dom == "backward" and wide_exact and "forward's table" not in (route_bwd or ""):
             bound, bound_detail = "valu", ("vector ALU: the exact sigmoids of both sweeps (pexpf + a double-precision divide each); "
                                            "rocprofv3 PMC of this command: SQ_INSTS_VALU per (sample, channel) in profiles/" + ROUND + "_*")
+        elif dom == "backward" and wide_exact:
+            lim = limits.get(dom, {})
+            bound = "latency"
+            bound_detail = ("barrier-separated phases per tile and window at four workgroups per CU: with the exponentials from the "
+                            "forward's table the kernel waits 70 % of its wavefront-cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES, 11 % VALU "
+                            "active: profiles/" + ROUND + "_d9_rgba32_1024_pmc_summary.txt); its atomic-request floor is %s ms of the %s measured"
+                            % (lim.get("floor_ms"), lim.get("measured_ms")))
         else:
             lim = limits.get(dom, {})
             bound = "latency"

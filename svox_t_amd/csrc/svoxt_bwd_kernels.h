@@ -13,9 +13,6 @@
 
 #pragma clang fp contract(off)
 
-#ifndef SVOXT_WIDE_STOP
-#define SVOXT_WIDE_STOP 0                // experiment: 1 = grad_wide_kernel ends after sweep 1, 2 = its sweep 2 skips the reduce
-#endif
 #ifndef SVOXT_WIDE_ETAB_WAVES
 #define SVOXT_WIDE_ETAB_WAVES 8          // wavefronts per SIMD the table instance of grad_wide_kernel is compiled for (8: four workgroups per CU)
 #endif
@@ -1462,9 +1459,6 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
         }
     }
 
-#if SVOXT_WIDE_STOP == 1
-    return;
-#endif
     // ---- sweep 2
     float light = 1.f;
     for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
@@ -1570,9 +1564,6 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
         }
         const int col = lane & (K - 1), sub = lane / K;
         constexpr int D = 4;                                 // rows in flight per lane: a row gather is ~1 us, its use ~0.3 us
-#if SVOXT_WIDE_STOP == 2
-        if (ns >= 0) { if (k0 + RPP * W >= maxn) break; lds_barrier(); for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; } for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu; lds_barrier(); continue; }
-#endif
         for (int i0 = wave * SPW; i0 < ns; i0 += D * W * SPW) {
             int32_t idxs[D];
             int ps[D], pes[D];
