@@ -14,9 +14,6 @@
 #pragma clang fp contract(off)
 
 #ifndef SVOXT_WIDE_ETAB_WAVES
-#ifndef SVOXT_WIDE_PASS_CAP
-#define SVOXT_WIDE_PASS_CAP 1024
-#endif
 #define SVOXT_WIDE_ETAB_WAVES 8          // wavefronts per SIMD the table instance of grad_wide_kernel is compiled for (8: four workgroups per CU)
 #endif
 
@@ -1463,40 +1460,15 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
     }
 
     // ---- sweep 2
-    // (r04) A PASS is as many windows of 16 list positions as fit the record arrays, its records compact -- the slot of
-    // (position k, ray l) = the records of the pass in front of position k + the rays below l that have position k, both
-    // from the ballot "nrec > k" (lane = ray in every wavefront) -- as in grad_fused_kernel since r03.  Lists are
-    // ragged: at 1024 x 1024 / depth 9 a window of 16 positions holds 370 records of 1 024 slots on average, so a tile
-    // went through 6-7 rounds of table clear, scan, sort and reduce where 2-3 do, and a feature row left the CU once
-    // per window instead of once per ~40 positions (the reduce is at 1.5x its atomic-request floor: step 59).
     float light = 1.f;
     for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
+    for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
     lds_barrier();
-    const unsigned long long lane_lt2 = (1ull << lane) - 1ull;
-    auto window_records = [&](int kw) {                      // records at positions kw .. kw + 15 (scalar)
-        int n = 0;
-#pragma unroll
-        for (int j = 0; j < RPP * W; ++j) n += (int)__popcll(__ballot(nrec > kw + j));
-        return n;
-    };
-    for (int k0 = 0; k0 < maxn;) {
-        const int kp0 = k0;                                  // first position of the pass
-        int npass = 0;                                       // records of the pass so far
-        while (true) {
-            // this window: records and hand-over first, then the table
+    for (int k0 = 0; k0 < maxn; k0 += RPP * W) {
+        {   // the window's two rounds together: records and hand-over first, then the sigma gathers, then the table
             uint2 e[RPP];
             float2 h[RPP];
             bool have[RPP];
-            int slot[RPP];
-            int nwin = 0;
-#pragma unroll
-            for (int j = 0; j < RPP * W; ++j) {              // (every wavefront forms all 16 ballots: they are scalar work)
-                const unsigned long long m = __ballot(nrec > k0 + j);
-#pragma unroll
-                for (int rd = 0; rd < RPP; ++rd)
-                    if (j == rd * W + wave) slot[rd] = npass + nwin + (int)__popcll(m & lane_lt2);
-                nwin += (int)__popcll(m);
-            }
 #pragma unroll
             for (int rd = 0; rd < RPP; ++rd) {
                 const int k = k0 + rd * W + wave;
@@ -1521,43 +1493,33 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                     }
                     h32 = (uint32_t)SVOXT_CHK((int)h32, T, 20);
                     atomicAdd(cnt + h32, 1);
-                    const int sl = SVOXT_CHK(slot[rd], R, 18);
-                    r_sl[sl] = (h32 << 6) | (uint32_t)lane;
-                    r_w[sl] = h[rd].x;                // the attenuation sweep 1 formed: no sigma gather here
-                    r_sg[sl] = h[rd].y;
-                    r_dt[sl] = __uint_as_float(e[rd].y);
+                    const int slot = (rd * W + wave) * 64 + lane;
+                    r_sl[slot] = (h32 << 6) | (uint32_t)lane;
+                    r_w[slot] = h[rd].x;              // the attenuation sweep 1 formed: no sigma gather here
+                    r_sg[slot] = h[rd].y;
+                    r_dt[slot] = __uint_as_float(e[rd].y);
                 }
             }
-            npass += nwin;
-            k0 += RPP * W;
-            if (k0 >= maxn || npass + window_records(k0) > SVOXT_WIDE_PASS_CAP) break;      // (scalar)
         }
         lds_barrier();
         if (wave == 0) {                                     // along the rays: (att, total_color) -> (weight, sigma entry)
-            int base = 0;
-#pragma unroll 1
-            for (int kb = kp0; kb < k0; kb += 8) {           // eight positions' operands at a time
+#pragma unroll
+            for (int j0 = 0; j0 < RPP * W; j0 += 8) {        // eight positions' operands at a time
                 float av[8], tv[8], dv[8];
-                int s2v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const unsigned long long m = __ballot(nrec > kb + j);
-                    s2v[j] = base + (int)__popcll(m & lane_lt2);
-                    base += (int)__popcll(m);
-                    av[j] = 1.f; tv[j] = 0.f; dv[j] = 0.f;
-                    if (kb + j < nrec) {
-                        s2v[j] = SVOXT_CHK(s2v[j], R, 18);
-                        av[j] = r_w[s2v[j]]; tv[j] = r_sg[s2v[j]]; dv[j] = r_dt[s2v[j]];
-                    }
+                    const int s2 = (j0 + j) * 64 + lane;
+                    av[j] = r_w[s2]; tv[j] = r_sg[s2]; dv[j] = r_dt[s2];
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    if (kb + j < nrec) {
+                    if (k0 + j0 + j < nrec) {
+                        const int s2 = (j0 + j) * 64 + lane;
                         const float weight = light * (1.f - av[j]);
                         light *= av[j];
                         accum -= weight * tv[j];
-                        r_w[s2v[j]] = weight;
-                        r_sg[s2v[j]] = dv[j] * ds * (tv[j] * light - accum) + dv[j] * ds * g_sig * light_ray;
+                        r_w[s2] = weight;
+                        r_sg[s2] = dv[j] * ds * (tv[j] * light - accum) + dv[j] * ds * g_sig * light_ray;
                     }
                 }
             }
@@ -1582,15 +1544,14 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
             if (lane == 63) { s_nb = incl; s_ns = uincl; }
         }
         lds_barrier();
-        if constexpr (CHECK) {                               // the table's counters must add up to the records of the pass
-            if (threadIdx.x == 0 && __builtin_amdgcn_readfirstlane(s_nb) != npass) atomicAdd(counters + kChkBase + 24, 1ull);
-        }
-        for (int rr = threadIdx.x; rr < npass; rr += NT) {   // (the records of the pass are slots 0 .. npass - 1)
-            const uint32_t v = r_sl[SVOXT_CHK(rr, R, 22)];
-            const int pos = SVOXT_CHK(atomicAdd(cnt + SVOXT_CHK((int)(v >> 6), T, 20), 1), R, 22);
-            r_t1[pos] = r_w[rr];                             // (r_dt was consumed by the chain above)
-            r_dt[pos] = r_sg[rr];
-            s_ray[pos] = (uint8_t)(v & 63u);
+        for (int rr = threadIdx.x; rr < R; rr += NT) {
+            const uint32_t v = r_sl[rr];
+            if (v != 0xffffffffu) {
+                const int pos = SVOXT_CHK(atomicAdd(cnt + SVOXT_CHK((int)(v >> 6), T, 20), 1), R, 22);
+                r_t1[pos] = r_w[rr];                         // (r_dt was consumed by the chain above)
+                r_dt[pos] = r_sg[rr];
+                s_ray[pos] = (uint8_t)(v & 63u);
+            }
         }
         lds_barrier();
         // ---- reduce: lane = column; after the scatter cnt[h] is where the records of entry h END
@@ -1646,9 +1607,10 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                 if (idx >= 0) atomicAdd(grad + (int64_t)idx * gstride + col, acc);
             }
         }
-        if (k0 >= maxn) break;                               // last pass (scalar condition)
+        if (k0 + RPP * W >= maxn) break;                     // last window (scalar condition)
         lds_barrier();
         for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
+        for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
         lds_barrier();
     }
 #undef SVOXT_CHK
