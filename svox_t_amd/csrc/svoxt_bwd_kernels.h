@@ -14,6 +14,9 @@
 #pragma clang fp contract(off)
 
 #ifndef SVOXT_WIDE_ETAB_WAVES
+#ifndef SVOXT_WIDE_STAGE_ROWS
+#define SVOXT_WIDE_STAGE_ROWS 2
+#endif
 #define SVOXT_WIDE_ETAB_WAVES 8          // wavefronts per SIMD the table instance of grad_wide_kernel is compiled for (8: four workgroups per CU)
 #endif
 
@@ -1563,37 +1566,41 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
             }
         }
         const int col = lane & (K - 1), sub = lane / K;
-        constexpr int D = 4;                                 // rows in flight per lane: a row gather is ~1 us, its use ~0.3 us
-        for (int i0 = wave * SPW; i0 < ns; i0 += D * W * SPW) {
-            int32_t idxs[D];
-            int ps[D], pes[D];
-            float xs[D];
+        // (r04) Two stages of D rows each: the rows of the NEXT stage are requested before this stage's sums are sent.
+        // A wavefront's vector-memory operations complete in order, the atomics among them: rows requested behind a
+        // stage's atomics arrive after the memory side has taken those atomics AND a trip to memory; requested a stage
+        // ahead they have the stage's arithmetic to arrive in.
+        constexpr int D = SVOXT_WIDE_STAGE_ROWS;             // rows in flight per lane and stage
+        struct Stage { int32_t idxs[D]; int ps[D], pes[D]; float xs[D]; };
+        auto fetch = [&](Stage& st, int i0) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
                 const int i = i0 + u * W * SPW + sub;
-                idxs[u] = -1; ps[u] = 0; pes[u] = 0; xs[u] = 0.f;
+                st.idxs[u] = -1; st.ps[u] = 0; st.pes[u] = 0; st.xs[u] = 0.f;
                 if (i < ns) {
                     const int h = SVOXT_CHK((int)slots[i], T, 23);
-                    idxs[u] = SVOXT_CHK(keys[h], tr.M, 25);
-                    pes[u] = SVOXT_CHK(cnt[h], R + 1, 24);
+                    st.idxs[u] = SVOXT_CHK(keys[h], tr.M, 25);
+                    st.pes[u] = SVOXT_CHK(cnt[h], R + 1, 24);
                     // the entry's records start where the previous occupied entry's end (table order = sorted order)
-                    if (i > 0) ps[u] = SVOXT_CHK(cnt[SVOXT_CHK((int)slots[i - 1], T, 23)], R + 1, 24);
-                    if constexpr (CHECK) { if (ps[u] > pes[u]) { atomicAdd(counters + kChkBase + 24, 1ull); ps[u] = pes[u]; } }
-                    xs[u] = rows[(int64_t)idxs[u] * K + col];
+                    if (i > 0) st.ps[u] = SVOXT_CHK(cnt[SVOXT_CHK((int)slots[i - 1], T, 23)], R + 1, 24);
+                    if constexpr (CHECK) { if (st.ps[u] > st.pes[u]) { atomicAdd(counters + kChkBase + 24, 1ull); st.ps[u] = st.pes[u]; } }
+                    st.xs[u] = rows[(int64_t)st.idxs[u] * K + col];
                 }
             }
+        };
+        auto send = [&](const Stage& st, int i0) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
                 if (i0 + u * W * SPW >= ns) break;           // (scalar)
-                const int32_t idx = idxs[u];
-                const int p = ps[u];
+                const int32_t idx = st.idxs[u];
+                const int p = st.ps[u];
                 float sig = 0.f, om = 0.f;
                 if (idx >= 0 && col < C) {
-                    sig = FAST ? nsigmoidf(xs[u]) : ETAB ? (float)rcp_unit_range(1.0 + (double)xs[u]) : (float)sigmoid_d<true>(xs[u]);
+                    sig = FAST ? nsigmoidf(st.xs[u]) : ETAB ? (float)rcp_unit_range(1.0 + (double)st.xs[u]) : (float)sigmoid_d<true>(st.xs[u]);
                     om = 1.f - sig;
                 }
                 float acc = 0.f;
-                int n_here = pes[u] - p, n_max = n_here;
+                int n_here = st.pes[u] - p, n_max = n_here;
                 for (int off = 32; off >= K; off >>= 1) n_max = max(n_max, __shfl_xor(n_max, off, 64));
                 n_max = __builtin_amdgcn_readfirstlane(n_max);
                 for (int t = 0; t < n_max; ++t) {
@@ -1606,6 +1613,16 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                 }
                 if (idx >= 0) atomicAdd(grad + (int64_t)idx * gstride + col, acc);
             }
+        };
+        constexpr int STEP = D * W * SPW;
+        Stage sa, sb;
+        fetch(sa, wave * SPW);
+        for (int i0 = wave * SPW; i0 < ns; i0 += 2 * STEP) {
+            fetch(sb, i0 + STEP);
+            send(sa, i0);
+            if (i0 + STEP >= ns) break;                      // (scalar)
+            fetch(sa, i0 + 2 * STEP);
+            send(sb, i0 + STEP);
         }
         if (k0 + RPP * W >= maxn) break;                     // last window (scalar condition)
         lds_barrier();
