@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 17
+#define SVOXT_ABI_VERSION 18
 
 enum {
     SVOXT_OK = 0,
@@ -259,6 +259,10 @@ int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
  *                                again -- a fill of M * grad_stride floats per step less.  The caller answers for the
  *                                zeros (a scratch a failed call may have left half written must be filled again). */
 #define SVOXT_LISTS_GRAD_ZEROED 16
+/*   SVOXT_LISTS_BEGUN            (read by the recording forwards; ABI v18) blocktab, pool_next and tile_state hold -1
+ *                                in every word already (svoxt_sigma_mask_build_fill on the same stream): the call
+ *                                does not fill them again. */
+#define SVOXT_LISTS_BEGUN 32
 /* Test and measurement switches of the one-launch forward (fwd_roles_kernel; ABI v17), all result-neutral: its shading
  * workgroups drop every third tile they take / give up after one poll / treat what they load for every fifth tile as a
  * stale read would look -- the fallback launch must then deliver the same pixels, lists and hand-over -- and
@@ -336,6 +340,12 @@ int svoxt_fwd_fills_terms(const svoxt_tree* tree, const svoxt_options* opt, int3
  * the Infinity Cache. */
 int64_t svoxt_sigma_mask_bytes(int64_t M);
 int svoxt_sigma_mask_build(const svoxt_tree* tree, float sigma_thresh, void* mask, void* stream);
+/* ... and, in the same launch (ABI v18), fill_bytes bytes at `fill` (device, 16-byte aligned, a multiple of 16) set to
+ * 0xff: the state a recording forward's pooled lists start from (blocktab, pool_next and tile_state, allocated in one
+ * piece).  A caller that builds the mask right before a recording forward hands the lists over with
+ * SVOXT_LISTS_BEGUN and saves that forward's own fill launch. */
+int svoxt_sigma_mask_build_fill(const svoxt_tree* tree, float sigma_thresh, void* mask, void* fill, int64_t fill_bytes,
+                                void* stream);
 /* The exponentials table of svoxt_tree.exp_table (ABI v17; no counterpart in the reference) for RGBA-style rows of
  * 8 / 16 / 32 floats: table <- device float [M, K], 16-byte aligned, and -- in the same pass over the feature table --
  * the sigma bitmask (mask as for svoxt_sigma_mask_build, or NULL).  Rebuild after any change to the features. */

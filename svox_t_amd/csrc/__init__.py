@@ -43,7 +43,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -98,7 +98,7 @@ class _CLists(ctypes.Structure):         # struct svoxt_sample_lists
 
 
 # svoxt_sample_lists.flags (include/svoxt.h)
-LISTS_NATIVE_MATH, LISTS_FWD_ONE_KERNEL, LISTS_FWD_TWO_KERNELS, LISTS_FWD_NO_OVERLAP, LISTS_GRAD_ZEROED = 1, 2, 4, 8, 16
+LISTS_NATIVE_MATH, LISTS_FWD_ONE_KERNEL, LISTS_FWD_TWO_KERNELS, LISTS_FWD_NO_OVERLAP, LISTS_GRAD_ZEROED, LISTS_BEGUN = 1, 2, 4, 8, 16, 32
 LISTS_TEST_DROP, LISTS_TEST_NOPOLL, LISTS_TEST_STALE, LISTS_FWD_AGENT_FENCE = 256, 512, 1024, 2048
 
 
@@ -120,6 +120,8 @@ EXPORTS = {
     "svoxt_fwd_fills_terms": (ctypes.c_int, [_P(_CTree), _P(_COptions), _i32]),
     "svoxt_sigma_mask_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "svoxt_sigma_mask_build": (ctypes.c_int, [_P(_CTree), ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "svoxt_sigma_mask_build_fill": (ctypes.c_int, [_P(_CTree), ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, _i64,
+                                                   ctypes.c_void_p]),
     "svoxt_exp_table_build": (ctypes.c_int, [_P(_CTree), ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "svoxt_compact_rows": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "svoxt_compact_rows_clear": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
@@ -466,10 +468,12 @@ def _pack_tree_accel(tree: TreeSpec) -> _CTree:
 _SIGMA_CACHE: dict = {}
 
 
-def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool, table: bool = False):
+def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool, table: bool = False, begin=None):
     """ct.sigma_mask <- the bitmask of this feature content; table: also ct.exp_table <- the rows' exponentials (rows of
     8 / 16 / 32 floats), built in the same pass.  Returns the table tensor (or None): a recording forward keeps it on its
-    lists for the backward of the same feature content."""
+    lists for the backward of the same feature content.  begin: the SampleLists of the recording forward that follows --
+    where the mask is built here and now, the same launch leaves their tables in the state that forward starts from
+    (svoxt_sigma_mask_build_fill) and the lists say so (LISTS_BEGUN)."""
     f = tree.features
     if not SIGMA_MASK or ct.M == 0:
         return None
@@ -489,6 +493,10 @@ def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool, ta
             if table:
                 etab = torch.empty_like(f, requires_grad=False)
                 _call("svoxt_exp_table_build", ctypes.byref(ct), ctypes.c_float(thresh), _ptr(mask), _ptr(etab), _stream(dev))
+            elif begin is not None and begin.both is not None:
+                _call("svoxt_sigma_mask_build_fill", ctypes.byref(ct), ctypes.c_float(thresh), _ptr(mask), _ptr(begin.both),
+                      begin.both.numel() * 4, _stream(dev))
+                begin.begun = True
             else:
                 _call("svoxt_sigma_mask_build", ctypes.byref(ct), ctypes.c_float(thresh), _ptr(mask), _stream(dev))
         if keep:
@@ -669,12 +677,15 @@ class SampleLists:
             self.pool_blocks = (_pool_blocks_for(tiles, S) + 31) // 32 * 32      # 32 equal parts, a counter each
             nt = tiles * (S // 8)
             # table, then the 32 counters, then the tile states, ready queues and their counters (march and shade in one launch): one fill
-            both = torch.empty((nt + 32 * 16 + 17 * tiles + 514,), dtype=torch.int32, device=device)
+            # (rounded up to whole 16-byte words: svoxt_sigma_mask_build_fill can then do lists_begin's fill)
+            both = torch.empty(((nt + 32 * 16 + 17 * tiles + 514 + 3) // 4 * 4,), dtype=torch.int32, device=device)
             self.blocktab, self.pool_next, self.tile_state = both[:nt], both[nt:nt + 32 * 16], both[nt + 32 * 16:]
+            self.both = both
         else:
             # rec[tile][block][lane][8]: every ray owns S slots
             self.pool_blocks = tiles * (S // 8)
-            self.blocktab = self.pool_next = self.tile_state = None
+            self.blocktab = self.pool_next = self.tile_state = self.both = None
+        self.begun = False      # the tables were filled by the launch that built the sigma bitmask (LISTS_BEGUN)
         self.rec = torch.empty((self.pool_blocks * 512, 2), dtype=torch.int32, device=device)
         self.aux = torch.empty((Q, 4), dtype=torch.int32, device=device)
         self.S = S
@@ -711,7 +722,7 @@ class SampleLists:
                        None if self.blocktab is None else self.blocktab.data_ptr(),
                        self.pool_blocks if self.pooled else 0,
                        None if self.pool_next is None else self.pool_next.data_ptr(),
-                       self.terms_state, self.flags,
+                       self.terms_state, self.flags | (LISTS_BEGUN if self.begun else 0),
                        None if self.tile_state is None else self.tile_state.data_ptr())
 
 
@@ -935,11 +946,15 @@ def _volume_render(tree, rays, opt, record):
     # the march of the two-kernel forward reads a bit per row instead of gathering sigma -- where that
     # forward is what runs and the stop rule (which needs sigma itself) does not apply
     etab = None
+    lists = None
+    if will_record:
+        with torch.cuda.device(dev):
+            lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
     if ((split or fills == 3) and FWD_SPLIT != "0") if will_record else (split and co.stop_thresh == 0.0):
         # rows of 8 / 16 / 32 floats in exact mode: the same pass leaves the rows' exponentials for the shade kernel
         # (and, on the lists, for the per-tile backward of this feature content)
         etab = _attach_sigma_mask(tree, ct, float(co.sigma_thresh), keep=not will_record,
-                                  table=wide and split and not NATIVE_MATH)
+                                  table=wide and split and not NATIVE_MATH, begin=lists)
     LAST_ROUTE["forward_terms"] = False
     # march and shade of a 3-channel payload as ONE launch (fwd_roles_kernel): the conditions of the library's launch_fwd_roles
     roles = bool(FWD_OVERLAP and LIST_POOL and ct.sigma_mask and ct.N == 2 and ct.xform is None and ct.weight_accum is None
@@ -954,7 +969,6 @@ def _volume_render(tree, rays, opt, record):
     with torch.cuda.device(dev):
         out = torch.empty((cr.Q, get_out_data_dim(opt, ct.K)), dtype=torch.float32, device=dev)
         if will_record:
-            lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
             lists.flags = lflags
             lists.exp_table = etab
             if fills:

@@ -278,6 +278,10 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     const int S = L.S;
     int64_t cur_block = 0;
 
+    if constexpr (GATHER) {
+        // tail-only launch (coef_out == NULL): nothing to do when no ray of the batch overflowed (one scalar load)
+        if (coef_out == nullptr && no_ray_overflowed(L)) return;
+    }
     const int lane = threadIdx.x & 63;
     float* stage = stage_all + (threadIdx.x >> 6) * (64 * KS);
     int32_t* sidx = sidx_all + (threadIdx.x >> 6) * 64;

@@ -37,10 +37,10 @@ __device__ __forceinline__ uint32_t leaf_slot(const TreeDev& tr, const Ray& r, f
 // kernel left in `out` (colour sums, transmittance in the alpha slot) and march on from
 // aux[q].y, then finalise the pixel and the recorded final transmittance.
 // LOBES (FMT_SH instances): the basis values are those of opt.format = SG or ASG with BD lobes (precalc_lobes).
+// render_fwd_ray: one ray, tid = its launch thread (render_fwd_kernel's; fwd_finish_kernel walks tiles with it).
 template <int FMT, int C, int BD, bool N2, bool REC, bool XF = false, bool RESUME = false, bool LOBES = false>
-__global__ void __launch_bounds__(kBlock)
-render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
-                  RecLists L, uint4* __restrict__ aux) {
+__device__ __forceinline__ void render_fwd_ray(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* __restrict__ out,
+                                               const RecLists& L, uint4* __restrict__ aux, const int64_t tid) {
     static_assert(!XF || FMT == FMT_SH, "view rotations only matter for view-dependent formats");
     static_assert(!LOBES || (FMT == FMT_SH && !XF), "lobes stand in for an SH basis");
     static_assert(!(RESUME && REC), "the tail launch does not record");
@@ -52,7 +52,6 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
     if constexpr (REC) rec_tab_init(ltab);
     const int S = L.S;
     int64_t cur_block = 0;
-    const int64_t tid = ((int64_t)blockIdx.x + rays.tile0) * kBlock + threadIdx.x;
     const int64_t q = ray_of_thread(rays, tid);
     if (q >= rays.Q) return;
     float* o = out + q * (C + 1);
@@ -191,8 +190,20 @@ render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
         }
         aux[q] = make_uint4((uint32_t)nrec | (over ? kRecOverflow : 0u), __float_as_uint(t_resume),
                             __float_as_uint(light), 0u);
+        if (over) note_overflow(L);
     }
     if constexpr (RESUME) aux[q].z = __float_as_uint(light);
+}
+
+template <int FMT, int C, int BD, bool N2, bool REC, bool XF = false, bool RESUME = false, bool LOBES = false>
+__global__ void __launch_bounds__(kBlock)
+render_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
+                  RecLists L, uint4* __restrict__ aux) {
+    if constexpr (RESUME) {
+        if (no_ray_overflowed(L)) return;                    // (one scalar load: see kPoolOverflowWord)
+    }
+    render_fwd_ray<FMT, C, BD, N2, REC, XF, RESUME, LOBES>(tr, rays, opt, out, L, aux,
+                                                           ((int64_t)blockIdx.x + rays.tile0) * kBlock + threadIdx.x);
 }
 
 // Generic fallback: any K, any format, component sub-range; accumulators in
@@ -289,8 +300,19 @@ render_fwd_generic_kernel(TreeDev tr, RaysDev rays, Opts opt, int C, float* __re
 // the lists are for a backward, which wants every sample with sigma > 0 (:382,456).
 // One bit per feature row: sigma > thresh (svoxt_sigma_mask_build).  A wavefront takes four groups of 64
 // rows -- four independent loads per lane in flight, one 8-byte word per group -- 1024 rows per workgroup.
+// (r04) fill (svoxt_sigma_mask_build_fill): the workgroups behind the first mask_blocks set fill_vec 16-byte words to all
+// ones -- the -1 the block table, pool counters and tile states of a recording forward's lists start from: the fill that
+// forward would otherwise launch by itself (a launch is ~4.5 us however little it does; the two are independent).
 __global__ void __launch_bounds__(256)
-sigma_mask_kernel(const float* __restrict__ features, int64_t M, int K, float thresh, unsigned long long* __restrict__ mask) {
+sigma_mask_kernel(const float* __restrict__ features, int64_t M, int K, float thresh, unsigned long long* __restrict__ mask,
+                  unsigned mask_blocks = ~0u, uint4* __restrict__ fill = nullptr, int64_t fill_vec = 0) {
+    if (blockIdx.x >= mask_blocks) {
+        const int64_t i0 = ((int64_t)(blockIdx.x - mask_blocks) * 256 + threadIdx.x) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < fill_vec) fill[i0 + j] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int64_t word0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;      // first of this wavefront's four words
     const int64_t words = (M + 63) / 64;
@@ -449,6 +471,7 @@ __device__ __forceinline__ uint32_t march_rec_tile(const TreeDev& tr, const Rays
     }
     rec_stage_finish(rstage, lane, L.rec, cur_block, nrec);
     aux[q] = make_uint4((uint32_t)nrec | over, __float_as_uint(t_resume), __float_as_uint(1.f), 0u);
+    if (over != 0u) note_overflow(L);
     if constexpr (CSUM) *csum = cs;
     return (uint32_t)nrec | over;
 }
@@ -632,6 +655,54 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
     shade_tile_body<FMT, BD, XF, STOP, WTERMS, false, LOBES>(tr, rays, opt, L, aux, out, tile, terms);
     if (tile_state != nullptr && threadIdx.x == 0)                              // (fallback of fwd_roles_kernel: counted)
         atomicAdd(const_cast<int32_t*>(tile_state) + roles_even(gridDim.x + rays.tile0) + kRoleCtrFallback, 1);
+}
+
+// (r04) What follows fwd_roles_kernel, as ONE small launch: the fallback shade of every tile the launch left unshaded
+// and the tails of the rays whose lists overflowed.  As two launches over all tiles -- 80 000 wavefronts to find every
+// tile shaded, 10 000 to find no ray overflowed -- they were 6.3 + 4.4 us of the 800 x 800 forward's 0.25 ms (VERDICT r03
+// item 5).  A workgroup takes a contiguous run of tiles: its threads read the run's states at once and collect the
+// unshaded ones (none, normally), it shades those (shade_tile_body: the whole workgroup per tile), then -- one scalar
+// load says whether any ray of the batch overflowed -- its wavefronts walk the run's tiles with render_fwd_ray<RESUME>.
+template <int FMT, int BD, bool WTERMS, bool LOBES = false>
+__global__ void __launch_bounds__(512)
+fwd_finish_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux, float* __restrict__ out,
+                  int32_t* __restrict__ tile_state, int ntiles) {
+    __shared__ shade_v4f terms[2][kShadeP][64];
+    constexpr int CAP = 64;
+    __shared__ int32_t s_list[CAP];
+    __shared__ int32_t s_n;
+    const int run = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t0 = (int)blockIdx.x * run, t1 = min(t0 + run, ntiles);
+    if (t0 >= t1) return;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int i = t0 + (int)threadIdx.x; i < t1; i += 512) {
+        if (tile_state[i] != kTileShaded) {
+            const int pos = atomicAdd(&s_n, 1);
+            if (pos < CAP) s_list[pos] = i;
+        }
+    }
+    __syncthreads();
+    const int n = s_n;                                       // (the same in every thread)
+    int32_t* const fallback_ctr = tile_state + roles_even(ntiles) + kRoleCtrFallback;
+    if (n > CAP) {                                           // more than the list holds: the run, tile by tile
+        for (int tile = t0; tile < t1; ++tile) {
+            if (tile_state[tile] == kTileShaded) continue;   // (uniform)
+            shade_tile_body<FMT, BD, false, false, WTERMS, false, LOBES>(tr, rays, opt, L, aux, out, tile, terms);
+            if (threadIdx.x == 0) atomicAdd(fallback_ctr, 1);
+            __syncthreads();
+        }
+    } else {
+        for (int j = 0; j < n; ++j) {
+            shade_tile_body<FMT, BD, false, false, WTERMS, false, LOBES>(tr, rays, opt, L, aux, out, s_list[j], terms);
+            if (threadIdx.x == 0) atomicAdd(fallback_ctr, 1);
+            __syncthreads();
+        }
+    }
+    if (no_ray_overflowed(L)) return;
+    __syncthreads();                                         // (a tail resumes from what the shade of its tile left)
+    for (int tile = t0 + (int)(threadIdx.x >> 6); tile < t1; tile += 8)
+        render_fwd_ray<FMT, 3, BD, true, false, false, true, LOBES>(tr, rays, opt, out, L, aux, (int64_t)tile * 64 + (threadIdx.x & 63));
 }
 
 // ---------------------------------------------------------------------------

@@ -190,6 +190,7 @@ bool launch_fwd_xform(const TreeDev& tr, const RaysDev& rays, const Opts& opt, i
 #ifndef SVOXT_ROLES_BAND_ROWS
 #define SVOXT_ROLES_BAND_ROWS 0          // tile rows per band of fwd_roles_kernel's marching order (0: the plain order)
 #endif
+inline unsigned finish_grid(unsigned nb) { return nb < 512u ? nb : 512u; }     // fwd_finish_kernel: runs of tiles, two workgroups per CU
 // fwd_roles_kernel's launch shape: the marching workgroups' tile map (RolesMap), how many of them, and the grid
 struct RolesLaunch { RolesMap map; int n_march; unsigned grid; };
 inline RolesLaunch roles_launch(unsigned nb, int tiles_per_row) {
@@ -235,10 +236,8 @@ bool launch_lobes_fwd_record(const TreeDev& tr, const RaysDev& rays, const Opts&
     {                                                                                                               \
         hipLaunchKernelGGL((fwd_roles_kernel<FMT_SH, BB, 1, true, true>), dim3(grid), dim3(512), 0, st,             \
                            tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap);     \
-        hipLaunchKernelGGL((shade_tile_kernel<FMT_SH, BB, false, false, true, true>), dim3(nb), dim3(512), 0, st,   \
-                           tr, rays, opt, L, aux, out, (const int32_t*)tile_state);                                 \
-        hipLaunchKernelGGL((render_fwd_kernel<FMT_SH, 3, BB, true, false, false, true, true>), dim3(nb), dim3(kBlock), \
-                           0, st, tr, rays, opt, out, L, aux);                                                      \
+        hipLaunchKernelGGL((fwd_finish_kernel<FMT_SH, BB, true, true>), dim3(finish_grid(nb)), dim3(512), 0, st,    \
+                           tr, rays, opt, L, aux, out, tile_state, (int)nb);                                        \
         return true;                                                                                                \
     }
             switch (opt.basis_dim) {
@@ -439,12 +438,11 @@ bool launch_fwd_roles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
                                             tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
             else hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 0, false>), dim3(grid), dim3(512), 0, st,            \
                                     tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
-            if (wt) hipLaunchKernelGGL((shade_tile_kernel<F, BB, false, false, true>), dim3(nb), dim3(512), 0, st, \
-                                       tr, rays, opt, L, aux, out, (const int32_t*)tile_state);                   \
-            else hipLaunchKernelGGL((shade_tile_kernel<F, BB, false, false, false>), dim3(nb), dim3(512), 0, st,  \
-                                    tr, rays, opt, L, aux, out, (const int32_t*)tile_state);                      \
-            hipLaunchKernelGGL((render_fwd_kernel<F, 3, BB, true, false, false, true>), dim3(nb), dim3(kBlock), 0, st, \
-                               tr, rays, opt, out, L, aux);                                                       \
+            /* the fallback shade of what the launch left unshaded + the tails of overflowed rays: one small launch */ \
+            if (wt) hipLaunchKernelGGL((fwd_finish_kernel<F, BB, true>), dim3(finish_grid(nb)), dim3(512), 0, st, \
+                                       tr, rays, opt, L, aux, out, tile_state, (int)nb);                          \
+            else hipLaunchKernelGGL((fwd_finish_kernel<F, BB, false>), dim3(finish_grid(nb)), dim3(512), 0, st,   \
+                                    tr, rays, opt, L, aux, out, tile_state, (int)nb);                             \
             return true;                                                                                          \
         }
         if (opt.format == FMT_RGBA && tr.K == 4) SVOXT_ROLES(FMT_RGBA, 0)
@@ -516,7 +514,7 @@ static int check_lists(const svoxt_sample_lists* l, const svoxt_options* opt, co
 
 // a recording forward starts with an empty block table and pool (pooled lists only)
 static int lists_begin(const svoxt_sample_lists* l, int64_t Q, hipStream_t st, const char* fn) {
-    if (l->blocktab == nullptr) return SVOXT_OK;
+    if (l->blocktab == nullptr || (l->flags & SVOXT_LISTS_BEGUN)) return SVOXT_OK;
     const size_t n = (size_t)(rec_rays(Q) / 64) * (l->max_samples / kRecBlock) * sizeof(int32_t);
     const size_t nc = sizeof(int32_t) * kSubPools * kSubPoolStride;
     const size_t ns = l->tile_state != nullptr ? (size_t)roles_state_words(rec_rays(Q) / 64) * sizeof(int32_t) : 0;   // states, counters, queues: all -1
@@ -677,16 +675,31 @@ int svoxt_volume_render_fwd_scratch(const svoxt_tree* tree, const svoxt_rays* ra
 
 int64_t svoxt_sigma_mask_bytes(int64_t M) { return M < 0 ? -1 : (M + 63) / 64 * 8; }
 
-int svoxt_sigma_mask_build(const svoxt_tree* tree, float sigma_thresh, void* mask, void* stream) {
-    const char* fn = "svoxt_sigma_mask_build";
+static int sigma_mask_build(const svoxt_tree* tree, float sigma_thresh, void* mask, void* fill, int64_t fill_bytes, void* stream,
+                            const char* fn) {
     int rc;
     if ((rc = check_tree(tree, fn))) return rc;
-    if (tree->M == 0) return SVOXT_OK;
-    if (mask == nullptr || ((uintptr_t)mask & 7u) != 0) return fail(SVOXT_ERR_INVALID, "%s: mask is NULL or not 8-byte aligned", fn);
+    if (fill_bytes < 0 || (fill_bytes > 0 && (fill == nullptr || ((uintptr_t)fill & 15u) != 0 || (fill_bytes & 15) != 0)))
+        return fail(SVOXT_ERR_INVALID, "%s: fill is NULL or not 16-byte aligned, or fill_bytes not a multiple of 16", fn);
+    if (tree->M == 0 && fill_bytes == 0) return SVOXT_OK;
+    if (tree->M > 0 && (mask == nullptr || ((uintptr_t)mask & 7u) != 0))
+        return fail(SVOXT_ERR_INVALID, "%s: mask is NULL or not 8-byte aligned", fn);
     const int64_t words = (tree->M + 63) / 64;
-    hipLaunchKernelGGL(svoxt::sigma_mask_kernel, dim3((unsigned)((words + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
-                       tree->features, tree->M, tree->K, sigma_thresh, reinterpret_cast<unsigned long long*>(mask));
+    const unsigned mb = (unsigned)((words + 15) / 16);
+    const int64_t fv = fill_bytes / 16;
+    const unsigned fb = (unsigned)((fv + 1023) / 1024);                      // 256 threads x 4 words
+    hipLaunchKernelGGL(svoxt::sigma_mask_kernel, dim3(mb + fb), dim3(256), 0, (hipStream_t)stream,
+                       tree->features, tree->M, tree->K, sigma_thresh, reinterpret_cast<unsigned long long*>(mask),
+                       mb, reinterpret_cast<uint4*>(fill), fv);
     return check_launch(fn);
+}
+
+int svoxt_sigma_mask_build(const svoxt_tree* tree, float sigma_thresh, void* mask, void* stream) {
+    return sigma_mask_build(tree, sigma_thresh, mask, nullptr, 0, stream, "svoxt_sigma_mask_build");
+}
+
+int svoxt_sigma_mask_build_fill(const svoxt_tree* tree, float sigma_thresh, void* mask, void* fill, int64_t fill_bytes, void* stream) {
+    return sigma_mask_build(tree, sigma_thresh, mask, fill, fill_bytes, stream, "svoxt_sigma_mask_build_fill");
 }
 
 int svoxt_exp_table_build(const svoxt_tree* tree, float sigma_thresh, void* mask, float* table, void* stream) {
@@ -974,7 +987,12 @@ static int compact_rows(const float* src, float* src_clear, int64_t M, int32_t K
     const int64_t want = (n + kBlock - 1) / kBlock;
     const unsigned nb = (unsigned)(want < 16384 ? want : 16384);
     if (src_clear != nullptr && src_clear == dst) return fail(SVOXT_ERR_INVALID, "%s: src and dst are the same buffer", fn);
-    if (vec && src_clear != nullptr)
+    if (vec && src_clear != nullptr && stride == 32 && n < (int64_t)0xfff00000) {
+        constexpr int U = 4;
+        const unsigned g = (unsigned)((n + U * 256 - 1) / (U * 256));
+        hipLaunchKernelGGL((compact_rows_clear_pow2_kernel<8, U>), dim3(g), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<float4*>(src_clear), (uint32_t)n, (int)(K / 4), reinterpret_cast<float4*>(dst));
+    } else if (vec && src_clear != nullptr)
         hipLaunchKernelGGL((compact_rows_kernel<v4f, true>), dim3(nb), dim3(kBlock), 0, (hipStream_t)stream,
                            reinterpret_cast<v4f*>(src_clear), n, (int)(K / 4), (int)(stride / 4), reinterpret_cast<v4f*>(dst));
     else if (vec)

@@ -119,6 +119,22 @@ __device__ __forceinline__ int64_t rec_block_u(const RecLists& L, int32_t tabreg
     if (L.tab == nullptr) return tile * (int64_t)(L.S >> 3) + b;
     return (int64_t)__builtin_amdgcn_readlane(tabreg, __builtin_amdgcn_readfirstlane(b));
 }
+// (r04) Pooled lists: word 1 of the pool's counter block (the counters are 16 words apart; lists_begin's fill leaves
+// -1) becomes 1 when a recording kernel fills a list to its capacity.  The tail launches (rays marched on past their
+// lists: render_fwd_kernel<RESUME>, render_bwd_kernel's tail-only form, fwd_finish_kernel) read it with one scalar load
+// and end at once when no ray of the batch overflowed -- the common case -- instead of fetching every ray's list length
+// to find that out.  Conservative: a stop rule that ends a ray at its last record leaves the word set.
+constexpr int kPoolOverflowWord = 1;
+__device__ __forceinline__ void note_overflow(const RecLists& L) {
+    if (L.pool_next != nullptr) L.pool_next[kPoolOverflowWord] = 1;
+}
+__device__ __forceinline__ bool no_ray_overflowed(const RecLists& L) {       // (uniform; false where nobody keeps the word)
+    if (L.pool_next == nullptr) return false;
+    const int32_t* p = L.pool_next + kPoolOverflowWord;
+    int32_t w;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(p) : "memory");
+    return w != 1;
+}
 // Pooled lists: a tile none of whose rays recorded a sample never took its first block -- entry 0 of its table is
 // still the -1 lists_begin left.  ONE scalar load (the address is the workgroup's) answers that before a kernel
 // that works per tile has requested anything else: on an 800 x 800 view of the depth-8 shell two tiles in three

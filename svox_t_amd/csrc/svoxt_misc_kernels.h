@@ -77,6 +77,7 @@ opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
         rec_stage_finish(rstage, (int)threadIdx.x, L.rec, cur_block, nrec);
         aux[q] = make_uint4((uint32_t)nrec | (over ? kRecOverflow : 0u), __float_as_uint(t_resume),
                             __float_as_uint(light), 0u);
+        if (over) note_overflow(L);
     }
 }
 
@@ -457,6 +458,35 @@ compact_rows_kernel(typename std::conditional<CLEAR, V, const V>::type* __restri
             const int64_t r = i / Kv;
             const int c = (int)(i - r * Kv);
             __builtin_nontemporal_store(__builtin_nontemporal_load(src + r * stride_v + c), dst + i);
+        }
+    }
+}
+
+// (r04) The clearing form for the shape the per-tile backwards use -- float4 elements, a padded row of SV of them (a power
+// of two: 8 = 128 bytes for K = 28) -- with 32-bit element indices (shift and mask for row and column where the general
+// kernel divides 64-bit numbers: ~100 instructions per element, 14 us of vector arithmetic at 800 x 800 / depth 8 beside
+// 30 us of memory time) and U elements per thread in flight: all loads, then the stores.
+template <int SV, int U>
+__global__ void __launch_bounds__(256)
+compact_rows_clear_pow2_kernel(float4* __restrict__ src, uint32_t n /* rows * SV */, int Kv, float4* __restrict__ dst) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f* s = reinterpret_cast<v4f*>(src);
+    v4f* d = reinterpret_cast<v4f*>(dst);
+    const uint32_t i0 = (blockIdx.x * (uint32_t)U) * 256u + threadIdx.x;        // (the host keeps n + U * 256 below 2^32)
+    v4f v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t i = i0 + (uint32_t)u * 256u;
+        v[u] = v4f{0.f, 0.f, 0.f, 0.f};
+        if (i < n && (int)(i & (SV - 1)) < Kv) v[u] = __builtin_nontemporal_load(s + i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t i = i0 + (uint32_t)u * 256u;
+        if (i < n) {
+            const uint32_t r = i / SV, c = i & (SV - 1);
+            if ((int)c < Kv) __builtin_nontemporal_store(v[u], d + (size_t)r * (size_t)Kv + c);
+            __builtin_nontemporal_store(v4f{0.f, 0.f, 0.f, 0.f}, s + i);
         }
     }
 }
