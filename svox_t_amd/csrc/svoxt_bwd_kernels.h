@@ -17,7 +17,9 @@
 #ifndef SVOXT_WIDE_STAGE_ROWS
 #define SVOXT_WIDE_STAGE_ROWS 2
 #endif
-#define SVOXT_WIDE_ETAB_WAVES 8          // wavefronts per SIMD the table instance of grad_wide_kernel is compiled for (8: four workgroups per CU)
+#ifndef SVOXT_WIDE_ETAB_WAVES
+#define SVOXT_WIDE_ETAB_WAVES 8
+#endif          // wavefronts per SIMD the table instance of grad_wide_kernel is compiled for (8: four workgroups per CU)
 #endif
 
 namespace svoxt {

@@ -1064,9 +1064,11 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
 // work) and each shades its own channel.  State in and out as for the RESUME launch.
 template <int K, bool N2, bool FAST>
 __global__ void __launch_bounds__(256)
-tail_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, uint4* __restrict__ aux, float* __restrict__ out) {
+tail_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, uint4* __restrict__ aux, float* __restrict__ out, RecLists L) {
     // One workgroup (four wavefronts) per 64-ray tile; with lists that hold every sample -- the
-    // usual case since they are pooled -- the launch is one look at the tile's 64 aux entries.
+    // usual case since they are pooled -- the launch is one scalar load (kPoolOverflowWord), else one look at the
+    // tile's 64 aux entries.
+    if (no_ray_overflowed(L)) return;
     constexpr int RPW = 64 / K;
     __shared__ int any_over;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

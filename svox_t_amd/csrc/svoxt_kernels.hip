@@ -372,9 +372,9 @@ bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float
             else hipLaunchKernelGGL((shade_chan_kernel<KK, STOP, false>), dim3(nbc), dim3(256), 0, st,        \
                                     tr, rays, opt, L, aux, out);                                         \
             if (fast) hipLaunchKernelGGL((tail_chan_kernel<KK, N2, true>), dim3(nb), dim3(256), 0, st,        \
-                                         tr, rays, opt, aux, out);                                            \
+                                         tr, rays, opt, aux, out, L);                                         \
             else hipLaunchKernelGGL((tail_chan_kernel<KK, N2, false>), dim3(nb), dim3(256), 0, st,            \
-                                    tr, rays, opt, aux, out);                                                 \
+                                    tr, rays, opt, aux, out, L);                                              \
             return true;                                                                                      \
         }
         switch (tr.K) {
