@@ -16,9 +16,6 @@
 #ifndef SVOXT_WIDE_STAGE_ROWS
 #define SVOXT_WIDE_STAGE_ROWS 2          // rows per lane and stage of grad_wide_kernel's reduce (1: 1.59 ms, 2: 1.55, 3: 1.77, 4: 1.82 backward)
 #endif
-#ifndef SVOXT_WIDE_AHEAD
-#define SVOXT_WIDE_AHEAD 1               // sweep 2 of grad_wide_kernel requests a window's records ahead of the reduce in front (0: behind it)
-#endif
 #ifndef SVOXT_WIDE_ETAB_WAVES
 #define SVOXT_WIDE_ETAB_WAVES 8          // wavefronts per SIMD the table instance of grad_wide_kernel is compiled for (8: four workgroups per CU)
 #endif
@@ -1474,38 +1471,23 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
     for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
     for (int i = threadIdx.x; i < R; i += NT) r_sl[i] = 0xffffffffu;
     lds_barrier();
-    // (r04) A window's records and hand-over are requested BEFORE the reduce of the window in front sends its sums: a
-    // wavefront's vector-memory operations complete in order, so loads issued behind the reduce's atomics waited until the
-    // memory side had taken every one of them -- once per window.  Requested ahead they arrive under the reduce, and the
-    // atomics have the next window's table, chain and sort to drain in.
-    uint2 e_n[RPP];
-    float2 h_n[RPP];
-    auto request = [&](int kk0) {
-#pragma unroll
-        for (int rd = 0; rd < RPP; ++rd) {
-            const int k = kk0 + rd * W + wave;
-            e_n[rd] = make_uint2(0u, 0u);
-            h_n[rd] = make_float2(0.f, 0.f);
-            if (k < nrec) {
-                const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 16);
-                e_n[rd] = rec_get(L.rec + rec_index_in(blk, lane, k));
-                h_n[rd] = tot2[terms_index_pm(blk, lane, k)];
-            }
-        }
-    };
-    request(0);
     for (int k0 = 0; k0 < maxn; k0 += RPP * W) {
-        {   // the window's two rounds together: records and hand-over (requested a window ahead), then the table
+        {   // the window's two rounds together: records and hand-over first, then the sigma gathers, then the table
             uint2 e[RPP];
             float2 h[RPP];
             bool have[RPP];
 #pragma unroll
             for (int rd = 0; rd < RPP; ++rd) {
-                have[rd] = k0 + rd * W + wave < nrec;
-                e[rd] = e_n[rd];
-                h[rd] = h_n[rd];
+                const int k = k0 + rd * W + wave;
+                have[rd] = k < nrec;
+                e[rd] = make_uint2(0u, 0u);
+                h[rd] = make_float2(0.f, 0.f);
+                if (have[rd]) {
+                    const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 16);
+                    e[rd] = rec_get(L.rec + rec_index_in(blk, lane, k));
+                    h[rd] = tot2[terms_index_pm(blk, lane, k)];
+                }
             }
-            if constexpr (SVOXT_WIDE_AHEAD == 0) { if (k0 > 0) request(k0); for (int rd = 0; rd < RPP; ++rd) { e[rd] = e_n[rd]; h[rd] = h_n[rd]; } }
 #pragma unroll
             for (int rd = 0; rd < RPP; ++rd) {
                 if (have[rd]) {
@@ -1588,9 +1570,6 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
             }
         }
         const int col = lane & (K - 1), sub = lane / K;
-        if constexpr (SVOXT_WIDE_AHEAD != 0) {
-            if (k0 + RPP * W < maxn) request(k0 + RPP * W);  // (scalar condition)
-        }
         // (r04) Two stages of D rows each: the rows of the NEXT stage are requested before this stage's sums are sent.
         // A wavefront's vector-memory operations complete in order, the atomics among them: rows requested behind a
         // stage's atomics arrive after the memory side has taken those atomics AND a trip to memory; requested a stage
