@@ -87,7 +87,7 @@ def pmc_traffic(workload, forward_only, group):
     try:
         with open(path) as f:
             counters = json.load(f)["counters"]
-        ks = {"forward": ("fwd", "roles", "march", "shade", "exptab", "mask"), "backward": ("bwd", "fused", "merge", "wide", "compact")}[group]
+        ks = {"forward": ("fwd", "roles", "finish", "march", "shade", "exptab", "mask"), "backward": ("bwd", "fused", "merge", "wide", "compact")}[group]
         fetch = sum(counters[k]["FETCH_SIZE"] for k in ks if k in counters) * 1024.0
         write = sum(counters[k]["WRITE_SIZE"] for k in ks if k in counters) * 1024.0
         if fetch + write == 0:

@@ -5,7 +5,7 @@ import csv, glob, os, sys, collections, json, re
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.join("gpurun_out", f"pmc_{tag}")
-SHORT = [("fwd_roles", "roles"), ("march_rec", "march"), ("shade_tile", "shade"), ("shade_chan", "shade"), ("render_bwd", "bwd"), ("render_fwd", "fwd"),
+SHORT = [("fwd_roles", "roles"), ("fwd_finish", "finish"), ("march_rec", "march"), ("shade_tile", "shade"), ("shade_chan", "shade"), ("render_bwd", "bwd"), ("render_fwd", "fwd"),
          ("grad_merge", "merge"), ("grad_fused", "fused"), ("grad_wide", "wide"), ("compact_rows", "compact"), ("depth_kernel", "depth"), ("exp_table", "exptab"), ("sigma_mask", "mask")]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 names = {}
