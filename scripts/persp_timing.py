@@ -14,6 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import svox_t_amd as svox          # noqa: E402
+import svox_t_amd.csrc as _C       # noqa: E402
 from svox_t_amd import synth       # noqa: E402
 from svox_t_amd.renderer import pinhole_rays   # noqa: E402
 
@@ -77,6 +78,8 @@ def main():
                      ("ray-batch forward + backward, rays resident", batch_step)):
         ms = timed(fn, a.reps)
         print(f"{name:48s} {ms:7.3f} ms  {Q / ms / 1e3:7.1f} Mrays/s")
+        if "backward" in name:
+            print(f"    route: {_C.LAST_ROUTE['forward']} | {_C.LAST_ROUTE['backward']}")
 
 
 if __name__ == "__main__":

@@ -637,16 +637,21 @@ def get_out_data_dim(opt: RenderOptions, K: int) -> int:
 # memory without waiting, and the next lists of the same shape are sized 1.25x what was used (twice
 # the pool if it ran dry -- a ray that finds no block stops recording and marches the rest, so a pool
 # that is too small costs time, never correctness).  LIST_POOL (SVOXT_LIST_POOL=0) False: dense lists.
-_POOL_HINT: dict = {}       # (tiles, S) -> [blocks to allocate, pending (event, pinned counter, capacity) or None, forwards seen]
+# (r04) The hint is kept per KIND of forward (recording / scratch: a no-grad forward between training steps of the same
+# shape needs a different pool, and one shared hint sent the next 16 training steps through the tails at 2.3x their
+# time: scripts/persp_timing.py), a pool that ran dry is looked at again after EVERY forward until it no longer does,
+# and a pool shrinks by a quarter at most per look.
+_POOL_HINT: dict = {}       # (tiles, S, kind) -> [blocks to allocate, pending (event, pinned counter, capacity) or None, forwards seen, ran dry]
 
 
-def _pool_blocks_for(tiles: int, S: int) -> int:
+def _pool_blocks_for(tiles: int, S: int, kind: str = "record") -> int:
     full = tiles * (S // 8)
-    ent = _POOL_HINT.setdefault((tiles, S), [min(full, tiles * 12), None, 0])
+    ent = _POOL_HINT.setdefault((tiles, S, kind), [min(full, tiles * 12), None, 0, False])
     if ent[1] is not None and ent[1][0].query():
         used, cap = int(ent[1][1].item()), ent[1][2]
         ent[1] = None
-        want = min(full, cap * 2) if used >= cap else min(full, max(tiles, int(used * 1.25) + 64))
+        ent[3] = used >= cap
+        want = min(full, cap * 2) if ent[3] else min(full, max(tiles, int(used * 1.25) + 64, ent[0] * 3 // 4))
         ent[0] = want
     return max(1, ent[0])
 
@@ -668,13 +673,14 @@ class SampleLists:
     include/svoxt.h, svoxt_sample_lists).  Opaque to callers: pass it back to
     volume_render_backward."""
 
-    def __init__(self, Q, S, device, pooled=None):
+    def __init__(self, Q, S, device, pooled=None, kind="record"):
         S = (S + 7) // 8 * 8                                 # whole 64-byte lines of 8 records per lane
         tiles = (Q + 63) // 64
         self.pooled = (LIST_POOL if pooled is None else bool(pooled)) and S <= 512
         self.tiles = tiles
+        self.kind = kind
         if self.pooled:
-            self.pool_blocks = (_pool_blocks_for(tiles, S) + 31) // 32 * 32      # 32 equal parts, a counter each
+            self.pool_blocks = (_pool_blocks_for(tiles, S, kind) + 31) // 32 * 32      # 32 equal parts, a counter each
             nt = tiles * (S // 8)
             # table, then the 32 counters, then the tile states, ready queues and their counters (march and shade in one launch): one fill
             # (rounded up to whole 16-byte words: svoxt_sigma_mask_build_fill can then do lists_begin's fill)
@@ -701,11 +707,11 @@ class SampleLists:
         (read later, without waiting)."""
         if not self.pooled:
             return
-        ent = _POOL_HINT.get((self.tiles, self.S))
+        ent = _POOL_HINT.get((self.tiles, self.S, self.kind))
         if ent is None or ent[1] is not None:
             return
         ent[2] += 1
-        if ent[2] > 2 and ent[2] % 16:          # the first forwards of a shape, then every 16th: three tiny launches each
+        if ent[2] > 2 and ent[2] % 16 and not ent[3]:   # the first forwards of a shape, then every 16th (every one while the pool runs dry): three tiny launches each
             return
         host = _pinned_counter()
         host.copy_((self.pool_next.view(32, 16)[:, 0].max().view(1) + 1) * 32, non_blocking=True)   # the fullest part sets the need
@@ -987,7 +993,7 @@ def _volume_render(tree, rays, opt, record):
             # scratch for the two-kernel forward (march, then shade per tile; the library falls
             # back to the one-kernel forward for payloads it does not cover)
             if LIST_POOL:
-                scratch = SampleLists(cr.Q, _list_cap(ct, FWD_LIST_SAMPLES), dev)
+                scratch = SampleLists(cr.Q, _list_cap(ct, FWD_LIST_SAMPLES), dev, kind="scratch")
                 scratch.flags = lflags
                 cl = scratch.c_struct()
                 _call("svoxt_volume_render_fwd_scratch", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),

@@ -772,7 +772,7 @@ def test_sample_list_pool_runs_dry_or_is_dense(name, pool, gpu, monkeypatch):
     if pool == "dense":
         monkeypatch.setattr(_C, "LIST_POOL", False)
     else:
-        monkeypatch.setattr(_C, "_pool_blocks_for", lambda tiles, S: 32 if pool == "dry" else 64)
+        monkeypatch.setattr(_C, "_pool_blocks_for", lambda tiles, S, kind="record": 32 if pool == "dry" else 64)
     c = Case(**CASES[name])
     tree = c.tree(gpu)
     r = svox.VolumeRenderer(tree)
