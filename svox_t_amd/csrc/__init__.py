@@ -639,8 +639,8 @@ def get_out_data_dim(opt: RenderOptions, K: int) -> int:
 # that is too small costs time, never correctness).  LIST_POOL (SVOXT_LIST_POOL=0) False: dense lists.
 # (r04) The hint is kept per KIND of forward (recording / scratch: a no-grad forward between training steps of the same
 # shape needs a different pool, and one shared hint sent the next 16 training steps through the tails at 2.3x their
-# time: scripts/persp_timing.py), a pool that ran dry is looked at again after EVERY forward until it no longer does,
-# and a pool shrinks by a quarter at most per look.
+# time: scripts/persp_timing.py), and a pool that ran dry is looked at again after EVERY forward until it no longer does.
+# (A pool that shrinks a quarter per look instead of at once: every look a new allocation size -- measured, not kept.)
 _POOL_HINT: dict = {}       # (tiles, S, kind) -> [blocks to allocate, pending (event, pinned counter, capacity) or None, forwards seen, ran dry]
 
 
@@ -651,7 +651,7 @@ def _pool_blocks_for(tiles: int, S: int, kind: str = "record") -> int:
         used, cap = int(ent[1][1].item()), ent[1][2]
         ent[1] = None
         ent[3] = used >= cap
-        want = min(full, cap * 2) if ent[3] else min(full, max(tiles, int(used * 1.25) + 64, ent[0] * 3 // 4))
+        want = min(full, cap * 2) if ent[3] else min(full, max(tiles, int(used * 1.25) + 64))
         ent[0] = want
     return max(1, ent[0])
 
@@ -989,9 +989,11 @@ def _volume_render(tree, rays, opt, record):
             if lists.terms_state == 3 and FWD_SPLIT == "":
                 LAST_ROUTE["forward"] = ("fwd_roles_kernel (march + shade_tile in one launch)" if roles else
                                          "march_rec_kernel + shade_tile_kernel (two-kernel forward)") + ", recording sample lists"
-        elif FWD_LIST_SAMPLES > 0 and cr.Q > 0:
+        elif split and FWD_LIST_SAMPLES > 0 and cr.Q > 0:
             # scratch for the two-kernel forward (march, then shade per tile; the library falls
-            # back to the one-kernel forward for payloads it does not cover)
+            # back to the one-kernel forward for payloads it does not cover).  (r04: only where that forward is what
+            # runs -- the one-kernel forward never touched its scratch, and what note_usage then read as the pool's
+            # use was uninitialised memory: a garbage size hint, looked at again after every forward)
             if LIST_POOL:
                 scratch = SampleLists(cr.Q, _list_cap(ct, FWD_LIST_SAMPLES), dev, kind="scratch")
                 scratch.flags = lflags
