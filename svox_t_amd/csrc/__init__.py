@@ -220,7 +220,8 @@ FWD_OVERLAP = _env_flag("SVOXT_FWD_OVERLAP", "1")
 EXP_TABLE = _env_flag("SVOXT_EXP_TABLE", "1")
 # --- not environment switches: routes the tests exercise by assignment
 BWD_TERMS = True     # False: no hand-over between the sweeps of the exact backwards (every row gathered twice)
-BWD_FUSED = True     # False: list walk and per-tile merge of an image's backward as two kernels (the form view rotations take)
+BWD_FUSED = True     # False: list walk and per-tile merge of an image's backward as two kernels
+BWD_XF_FUSED = True  # False: view rotations (transformation_matrices) through the two-kernel form they took until r04
 ROLES_FLAGS = 0      # OR of LISTS_TEST_* / LISTS_FWD_AGENT_FENCE: test and measurement switches of the one-launch forward
 
 
@@ -1082,7 +1083,9 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
                 if fwd_output.shape != grad_output.shape or fwd_output.dtype != torch.float32:
                     raise RuntimeError("fwd_output must match grad_output")
                 fo = fwd_output
-            fused = gather and BWD_FUSED and ct.xform is None      # (fo None: the fused kernel's exact form)
+            # (fo None: the fused kernel's exact form -- the only one view rotations take: SH up to 9 basis functions)
+            fused = gather and BWD_FUSED and (ct.xform is None or (fo is None and BWD_EXACT and BWD_XF_FUSED and co.format == FORMAT_SH
+                                                                   and co.basis_dim in (1, 4, 9)))
             wide = co.format == FORMAT_RGBA and grad_output.shape[1] in (8, 16, 32) and K == grad_output.shape[1]
             # ... per tile (grad_wide_kernel) for coherent batches on N = 2 trees, else per ray (render_bwd_kernel<ONEPASS>)
             wide_tile = wide and fo is None and BWD_TERMS and BWD_FUSED and ct.N == 2 and ct.xform is None and \
@@ -1102,7 +1105,8 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
             if wide_tile and lists.exp_table is not None and not (lists.flags & LISTS_NATIVE_MATH):
                 ct.exp_table = lists.exp_table.data_ptr()      # (the table of the feature content the lists were recorded with)
             LAST_ROUTE["backward"] = (
-                ("grad_fused_kernel<EXACT> (two sweeps over the lists + per-tile merge)" if fo is None else
+                ("grad_fused_kernel<EXACT, XF> (two sweeps over the lists, a basis per record + per-tile merge)" if ct.xform is not None else
+                 "grad_fused_kernel<EXACT> (two sweeps over the lists + per-tile merge)" if fo is None else
                  "grad_fused_kernel (one sweep over the lists + per-tile merge; accum from the forward's output)") if fused else
                 "render_bwd_kernel<GATHER> + grad_merge_kernel (list walk, then per-tile merge)" if gather else
                 ("grad_wide_kernel (two sweeps over the lists, sigmoids per record once + once per distinct row; per-tile merge"

@@ -111,8 +111,8 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
     // a caller that hands over a coef buffer asks for the two-kernel form; without one (coef_bytes < 0)
     // the per-tile route runs if it can run as ONE kernel.  (The choice is the caller's alone: the
     // Python layer reads SVOXT_BWD_FUSED, the library reads no environment for this.)
-    const bool fused = coef == nullptr && !xf;
-    if (!fused && coef == nullptr) return false;            // the two-kernel form needs its buffer
+    const bool fused = coef == nullptr;
+    if (fused && xf && (fwd_out != nullptr || opt.format != FMT_SH || opt.basis_dim > 9)) return false;   // (the exact one-kernel form only)
     // four wavefronts per tile and tables of 1024 (measured: one wavefront per tile 0.41 ms,
     // two 0.33, four 0.30 before step 15; tables of 512 / 256 cost more passes than they buy)
 #define SVOXT_GATHER(F, BB)                                                                                   \
@@ -170,8 +170,26 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
     hipLaunchKernelGGL((grad_merge_kernel<FMT_SH, BB, 1024, 512, 4, true>), dim3(nb), dim3(256), 0, st, tr, rays, \
                        grad_out, L, coef, aux, grad, gstride);                                                    \
     return true;
+    // (r04) view rotations as ONE kernel: the rays whose list overflowed whole by the per-ray kernel, every other ray by
+    // grad_fused_kernel<..., XF> (no checked / counting instance: svoxt_set_bwd_check and _counters do not see this route)
+#define SVOXT_FUSED_XF(BB)                                                                                        \
+    {                                                                                                             \
+        hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, true, true>), dim3(nb), dim3(kBlock), 0, st,   \
+                           tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out, reinterpret_cast<float4*>(kOnlyOverflowed)); \
+        hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 0, false, false, true>), dim3(nb), dim3(512), 0, st, \
+                           tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                              \
+        return true;                                                                                              \
+    }
     if (xf) {
         if (opt.format != FMT_SH) return false;
+        if (fused) {
+            switch (opt.basis_dim) {
+                case 1: SVOXT_FUSED_XF(1)
+                case 4: SVOXT_FUSED_XF(4)
+                case 9: SVOXT_FUSED_XF(9)
+            }
+            return false;
+        }
         switch (opt.basis_dim) {
             case 1: SVOXT_GATHER_XF(1)
             case 4: SVOXT_GATHER_XF(4)
@@ -179,6 +197,7 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
         }
         return false;
     }
+#undef SVOXT_FUSED_XF
     if (opt.format == FMT_RGBA) { SVOXT_GATHER(FMT_RGBA, 0) }
     // SH16 / SH25 (rows of 49 / 76 floats, r03): the one-kernel per-tile form only, and only over the hand-over a
     // recording forward left (terms_state 2 / 3): the kernel then never holds a feature row
@@ -317,6 +336,9 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
                 done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, lists_dev(lists, rays->Q),
                                          reinterpret_cast<const uint4*>(lists->aux), fwd_out,
                                          reinterpret_cast<float4*>(lists->coef), true, st);
+            else if (lists->coef == nullptr && lists->coef_bytes < 0 && tree->K <= 32 && fwd_out == nullptr && C == 3 && n2)
+                done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, lists_dev(lists, rays->Q),
+                                         reinterpret_cast<const uint4*>(lists->aux), fwd_out, nullptr, true, st);   // list walk + merge as one kernel
             if (!done)
                 done = launch_bwd_xform<true>(tr, rd, od, C, grad_out, grad_features, gs, lists_dev(lists, rays->Q),
                                               reinterpret_cast<const uint4*>(lists->aux), fwd_out, st);

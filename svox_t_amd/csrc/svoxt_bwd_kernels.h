@@ -244,6 +244,7 @@ __device__ __forceinline__ void sample_advance(float att, float total_color, flo
     weight_out = weight;
 }
 
+constexpr uintptr_t kOnlyOverflowed = 1;      // render_bwd_kernel<..., XF> (lists, no GATHER): coef_out = this value, see there
 // REPLAY: rec / aux were filled by render_fwd_kernel<..., REC=true> for the
 // same tree, rays and options: pass 1 walks the list instead of the tree.
 // GATHER (C == 3, lists only): the listed samples are not sent to the gradient table
@@ -282,6 +283,11 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
         // tail-only launch (coef_out == NULL): nothing to do when no ray of the batch overflowed (one scalar load)
         if (coef_out == nullptr && no_ray_overflowed(L)) return;
     }
+    // (r04) XF, lists, no GATHER: coef_out == kOnlyOverflowed restricts the launch to the rays whose list overflowed --
+    // grad_fused_kernel<..., XF> leaves exactly those to it (their last sample, whose basis the second pass keeps, lies
+    // past the list)
+    const bool only_overflowed = XF && REPLAY && !GATHER && reinterpret_cast<uintptr_t>(coef_out) == kOnlyOverflowed;
+    if (only_overflowed && no_ray_overflowed(L)) return;
     const int lane = threadIdx.x & 63;
     float* stage = stage_all + (threadIdx.x >> 6) * (64 * KS);
     int32_t* sidx = sidx_all + (threadIdx.x >> 6) * 64;
@@ -290,6 +296,7 @@ render_bwd_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     const int64_t q = ray_of_thread(rays, tid);
     Ray r;
     bool alive = q < rays.Q;
+    if (only_overflowed) alive = alive && (aux[alive ? q : 0].x & kRecOverflow) != 0u;
     if constexpr (GATHER) {
         // tail-only launch (coef_out == NULL): most wavefronts have no overflowed ray and leave here
         if (coef_out == nullptr && !__any(alive && (aux[alive ? q : 0].x & kRecOverflow) != 0u)) return;
@@ -842,7 +849,14 @@ grad_merge_kernel(TreeDev tr, RaysDev rays, const float* __restrict__ grad_out, 
 // chain's slot, 6 a feature row outside the table; svoxt_tile_reduce.inc: 8 table entry of a record, 9 its place in
 // the sorted order, 10 sorted record number, 11 table entry of a sorted record, 12 the row a sum is sent to,
 // 13 records of the pass != sum of the table's counters.
-template <int FMT, int BD, bool EXACT, bool COUNT = false, int TERMS = 0, bool LOBES = false, bool CHECK = false>
+// XF (r04; SH up to 9 basis functions, EXACT, TERMS 0): per-leaf view rotations (rt_kernel.cu:387-395).  A record's basis is
+// its own -- the leaf's matrix applied to the ray's view direction -- in sweep 1 and for the colour entries; sweep 2's
+// total_color takes the basis sweep 1 ENDED with (the reference's second pass never re-evaluates it: rt_kernel.cu:439-494),
+// which the wavefront that forms a ray's last record leaves in `bases`; the reduce evaluates a record's basis again from
+// the row's matrix and the ray's direction (vds) instead of holding nine more floats per record in LDS.  Rays whose list
+// overflowed are not this kernel's: their last sample lies past the list, so a launch of render_bwd_kernel<..., XF> over
+// those rays alone (kOnlyOverflowed) does all of their work in front.
+template <int FMT, int BD, bool EXACT, bool COUNT = false, int TERMS = 0, bool LOBES = false, bool CHECK = false, bool XF = false>
 __global__ void __launch_bounds__(512, 4)
 grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ grad_out,
                   RecLists L, const uint4* __restrict__ aux, const float* __restrict__ fwd_out,
@@ -870,6 +884,8 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     static_assert(TERMS == 0 || TERMS == 2 || TERMS == 3, "hand-over layouts");
     static_assert(K <= 32 || (EXACT && TERMS >= 2), "wide rows: only with the forward's hand-over (no row in registers)");
     static_assert(!LOBES || (FMT == FMT_SH && EXACT && TERMS >= 2), "lobes: only over the forward's hand-over");
+    static_assert(!XF || (FMT == FMT_SH && EXACT && TERMS == 0 && !LOBES && BD <= 9), "view rotations: SH rows in registers, exact, no hand-over");
+    __shared__ float vds[XF ? 64 * 3 : 1];       // XF: the 64 rays' view directions, for the reduce
     __shared__ int32_t keys[T];
     __shared__ int32_t cnt[T];
     __shared__ uint16_t order[R];
@@ -908,6 +924,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     for (int j = 0; j <= C; ++j) g[j] = grad_out[qc * (C + 1) + j];
     for (int i = threadIdx.x; i < T; i += NT) { keys[i] = -1; cnt[i] = 0; }
     if (!in_batch) a = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (XF) { if (a.x & kRecOverflow) a.x = 0u; }  // (done whole by the launch in front)
     const int nrec = (int)(a.x & ~kRecOverflow);
     int maxn = nrec;
     for (int off = 32; off > 0; off >>= 1) maxn = max(maxn, __shfl_xor(maxn, off, 64));
@@ -923,13 +940,13 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     if (from_tensors) {
         float dx, dy, dz;
         r.delta_scale = dir_to_tree(tr, dsrc, dx, dy, dz);   // setup_ray's, from the direction already at hand
-        if constexpr (FMT == FMT_SH && !LOBES) precalc_basis<BD>(FMT_SH, BD, tr, vsrc[0], vsrc[1], vsrc[2], basis);
+        if constexpr (FMT == FMT_SH && !LOBES && !XF) precalc_basis<BD>(FMT_SH, BD, tr, vsrc[0], vsrc[1], vsrc[2], basis);
     } else if (nrec > 0) {
         setup_ray(tr, rays, opt, q, r);                      // for delta_scale (a ray with samples hits the cube)
         if constexpr (FMT == FMT_SH) {
             float vd[3];
             load_vdir(rays, q, vd);
-            if constexpr (!LOBES) precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
+            if constexpr (!LOBES && !XF) precalc_basis<BD>(FMT_SH, BD, tr, vd[0], vd[1], vd[2], basis);
             else { vsrc[0] = vd[0]; vsrc[1] = vd[1]; vsrc[2] = vd[2]; }
         }
     }
@@ -945,6 +962,9 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             // (the lobes one at a time straight into LDS: 25 unrolled exponentials at this kernel's 128 registers spill 106)
 #pragma unroll 1
             for (int i = 0; i < NB; ++i) bases[lane * BDS + i] = lobe_value(opt.format, tr, vsrc[0], vsrc[1], vsrc[2], i, NB);
+        } else if constexpr (XF) {                           // (bases: by whoever forms the ray's last record, in sweep 1)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vds[lane * 3 + j] = vsrc[j];
         } else {
 #pragma unroll
             for (int i = 0; i < NB; ++i) bases[lane * BDS + i] = basis[i];
@@ -994,6 +1014,13 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                     const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
                     float row[K];
                     load_row<K>(tr.features + (int64_t)SVOXT_CHK((int32_t)e.x, tr.M, 6) * K, row);
+                    if constexpr (XF) {
+                        rotated_sh_basis<BD>(tr, SVOXT_CHK((int32_t)e.x, tr.M, 6), vsrc, basis);
+                        if (k == nrec - 1) {                 // what the reference's second pass keeps using
+#pragma unroll
+                            for (int i = 0; i < NB; ++i) bases[lane * BDS + i] = basis[i];
+                        }
+                    }
                     att = pexpf<true>(-__uint_as_float(e.y) * row[K - 1] * r.delta_scale);
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
@@ -1123,7 +1150,26 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
             } else {
                 float row[K];
                 load_row<K>(tr.features + (int64_t)SVOXT_CHK((int32_t)e.x, tr.M, 6) * K, row);
-                sample_terms<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, att, tc, cf);
+                if constexpr (XF) {
+                    // coef_sample<..., XF>'s operations: the colour coefficients from the record's own basis, total_color
+                    // from the basis sweep 1 ended with (read from LDS column by column: nine registers less)
+                    rotated_sh_basis<BD>(tr, SVOXT_CHK((int32_t)e.x, tr.M, 6), vsrc, basis);
+                    att = pexpf<true>(-__uint_as_float(e.y) * row[K - 1] * r.delta_scale);
+                    tc = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        float tmp = 0.f, tmp2 = 0.f;
+#pragma unroll
+                        for (int i = 0; i < BD; ++i) tmp += basis[i] * row[c * BD + i];
+                        const float sig = (float)sigmoid_d<true>(tmp);
+                        cf[c] = (float)((double)sig * (1.0 - (double)sig));
+#pragma unroll
+                        for (int i = 0; i < BD; ++i) tmp2 += bases[lane * BDS + i] * row[c * BD + i];
+                        tc = (float)((double)tc + sigmoid_d<true>(tmp2) * (double)g[c]);
+                    }
+                } else {
+                    sample_terms<FMT, C, BD, K>(row, basis, g, __uint_as_float(e.y), r.delta_scale, att, tc, cf);
+                }
             }
             const int32_t idx = SVOXT_CHK((int32_t)e.x, tr.M, 6);
             uint32_t h = ((uint32_t)idx * 0x9E3779B1u) >> (32 - __builtin_ctz(T));

@@ -744,6 +744,10 @@ def test_acceleration_grid_never_goes_stale(gpu):
     ("SH4", 13, 5, "lists"),
     ("SH9", 28, 5, "two_kernel"),     # ... list walk + per-tile merge (rotated directions travel with the records)
     ("SH4", 13, 6, "two_kernel_overflow"),
+    ("SH9", 28, 5, "fused"),          # ... as ONE kernel (grad_fused_kernel<..., XF>: a basis per record, r04)
+    ("SH9", 28, 6, "fused_overflow"), # ... rays whose list overflowed go whole through the per-ray kernel in front
+    ("SH4", 13, 6, "fused"),
+    ("SH1", 4, 5, "fused"),
     ("SH16", 49, 4, "lists"),
     ("SG6", 19, 4, "generic"),        # view-dependent format without a specialised kernel
 ])
@@ -765,7 +769,10 @@ def test_transformation_matrices(gpu, monkeypatch, fmt, K, depth, mode):
     Qm, _ = torch.linalg.qr(A)                                # random rotations
     if mode in ("overflow", "two_kernel_overflow"):
         monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", 4)
-    monkeypatch.setattr(_C, "BWD_GATHER", 2 if mode.startswith("two_kernel") else 0)
+    if mode in ("fused_overflow",):
+        monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", 8)
+    monkeypatch.setattr(_C, "BWD_GATHER", 2 if mode.startswith(("two_kernel", "fused")) else 0)
+    monkeypatch.setattr(_C, "BWD_XF_FUSED", mode.startswith("fused"))
     if mode == "exact":
         monkeypatch.setattr(_C, "BWD_EXACT", True)
     r = svox.VolumeRenderer(tree)
@@ -782,13 +789,17 @@ def test_transformation_matrices(gpu, monkeypatch, fmt, K, depth, mode):
         gw, ab = O.volume_render_backward(ot, *c.rays_np(), opt, gout.numpy(), want_abs=True)
     np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
     plain = O.volume_render(ot, *c.rays_np(), opt)
-    assert np.abs(plain - want).max() > 1e-3                  # the rotations do change the image
+    assert fmt == "SH1" or np.abs(plain - want).max() > 1e-3   # the rotations do change the image (a constant basis aside)
     if mode == "standalone":
         grad = _C.volume_render_backward(spec, _rays_spec_from_rays(rays), r._get_options(), gout.to(gpu))
         assert_grads_close(grad.cpu().numpy(), gw, ab)
     else:
         out.backward(gout.to(gpu))
         assert_grads_close(tree.features.grad.cpu().numpy(), gw, ab)
+        if mode.startswith("fused"):
+            assert _C.LAST_ROUTE["backward"].startswith("grad_fused_kernel<EXACT, XF>"), _C.LAST_ROUTE
+        elif mode.startswith("two_kernel"):
+            assert _C.LAST_ROUTE["backward"].startswith("render_bwd_kernel<GATHER>"), _C.LAST_ROUTE
     if fmt != "SH9" or mode != "lists":
         return
     # identity matrices reproduce the plain render exactly
