@@ -309,7 +309,9 @@ typedef struct svoxt_sample_lists {
      * (tile, b) names the 4 KB block of `rec` that holds records 8b .. 8b+7 of the tile's 64 rays
      * (-1: none).  The forward clears the table and hands blocks out of rec's pool_blocks blocks
      * (a positive multiple of 32: the pool is cut into 32 parts, a tile draws from part tile % 32;
-     * pool_next: device int32 [32 * 16], one counter per part, 64 bytes apart, each = blocks handed out - 1;
+     * pool_next: device int32 [32 * 16], one counter per part, 64 bytes apart, each = blocks handed out - 1
+     * (word 1, ABI v18: 1 once a recording kernel has filled a ray's list to its capacity -- what the tail launches
+     * read instead of every ray's list length; -1 after the fill);
      * placed right behind blocktab, table and counters are cleared with one fill) the first time a ray
      * of a tile starts block b; a ray that finds
      * the pool used up stops recording there exactly as one that reaches max_samples does (it marches

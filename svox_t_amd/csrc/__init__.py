@@ -647,13 +647,20 @@ _POOL_HINT: dict = {}       # (tiles, S, kind) -> [blocks to allocate, pending (
 
 def _pool_blocks_for(tiles: int, S: int, kind: str = "record") -> int:
     full = tiles * (S // 8)
-    ent = _POOL_HINT.setdefault((tiles, S, kind), [min(full, tiles * 12), None, 0, False])
-    if ent[1] is not None and ent[1][0].query():
+    ent = _POOL_HINT.setdefault((tiles, S, kind), [min(full, tiles * 12), None, 0, False, []])
+    # (a pool known to have run dry: the look that is under way is waited for -- a dry pool costs more than the wait)
+    if ent[1] is not None and (ent[1][0].query() or ent[3]):
+        if ent[3]:
+            ent[1][0].synchronize()
         used, cap = int(ent[1][1].item()), ent[1][2]
         ent[1] = None
         ent[3] = used >= cap
-        want = min(full, cap * 2) if ent[3] else min(full, max(tiles, int(used * 1.25) + 64))
-        ent[0] = want
+        # sized by the largest of the last eight looks (~128 forwards): batches of one shape that alternate -- a sorted
+        # and an unsorted ray order, two cameras -- keep the pool of the one that needs more
+        hist = ent[4]
+        hist.append(min(full, cap * 2) if ent[3] else used)
+        del hist[:-8]
+        ent[0] = min(full, cap * 2) if ent[3] else min(full, max(tiles, int(max(hist) * 1.25) + 64))
     return max(1, ent[0])
 
 
