@@ -921,3 +921,61 @@ def test_sigma_mask_build_bits(gpu, M, K):
             want = f[:, -1] > np.float32(thresh)
         np.testing.assert_array_equal(bits[:M], want)
         assert not bits[M:].any()
+
+
+@pytest.mark.parametrize("M,K,fill_words", [(1, 4, 4), (1000, 32, 4 * 1024 + 4), (70001, 28, 290_004), (64, 28, 0)])
+def test_sigma_mask_build_fill(gpu, M, K, fill_words):
+    """svoxt_sigma_mask_build_fill (ABI v18): the same mask as svoxt_sigma_mask_build and, from the same launch,
+    exactly fill_bytes bytes of 0xff at `fill` -- nothing in front of them, nothing behind; misaligned or
+    ragged fills are refused."""
+    import ctypes
+    rng = np.random.default_rng(M + 1)
+    feats = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(gpu)
+    ct = _C._CTree(features=feats.data_ptr(), M=M, K=K, N=2, data=feats.data_ptr(), child=feats.data_ptr(), n_internal=1,
+                   offset=feats.data_ptr(), scaling=feats.data_ptr())
+    words = _C._lib.svoxt_sigma_mask_bytes(M) // 8
+    want = torch.zeros((words,), dtype=torch.int64, device=gpu)
+    _C._call("svoxt_sigma_mask_build", ctypes.byref(ct), ctypes.c_float(0.1), want.data_ptr(), None)
+    got = torch.zeros((words,), dtype=torch.int64, device=gpu)
+    guard = 8
+    buf = torch.full((guard + fill_words + guard,), 0x12345678, dtype=torch.int32, device=gpu)
+    fill = buf[guard: guard + fill_words] if fill_words else None
+    _C._call("svoxt_sigma_mask_build_fill", ctypes.byref(ct), ctypes.c_float(0.1), got.data_ptr(),
+             None if fill is None else fill.data_ptr(), fill_words * 4, None)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert (buf[:guard] == 0x12345678).all() and (buf[guard + fill_words:] == 0x12345678).all()
+    if fill_words:
+        assert (fill == -1).all()
+        with pytest.raises(RuntimeError, match="fill"):       # 4 bytes past a 16-byte boundary
+            _C._call("svoxt_sigma_mask_build_fill", ctypes.byref(ct), ctypes.c_float(0.1), got.data_ptr(),
+                     buf[guard + 1:].data_ptr(), 16, None)
+        with pytest.raises(RuntimeError, match="fill"):       # not a multiple of 16 bytes
+            _C._call("svoxt_sigma_mask_build_fill", ctypes.byref(ct), ctypes.c_float(0.1), got.data_ptr(),
+                     fill.data_ptr(), 20, None)
+
+
+def test_overflow_word_of_pooled_lists(gpu, monkeypatch):
+    """Word 1 of the pool's counter block (ABI v18): -1 after a recording forward none of whose rays filled its list,
+    1 after one that did (lists of 8 records on a depth-6 tree) -- what the tail launches read with one scalar load
+    instead of every ray's list length.  The results do not depend on it (the oracle holds both)."""
+    c = Case(depth=6, K=13, data_format="SH4", width=64, height=48)
+    tree = c.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    opt = r._get_options()
+    spec = tree._spec(tree.features)
+    rs = _rays_spec_from_rays(c.rays_gpu(gpu), (48, 64))
+    rs.need_grad = False
+    want = O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts())
+    g = synth.grad_output(c.Q, 4)
+    gw, ab = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.numpy(), want_abs=True)
+    for cap, word in ((96, -1), (8, 1)):
+        monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", cap)
+        out, lists = _C.volume_render(spec, rs, opt, record=True)
+        torch.cuda.synchronize()
+        over = int((lists.aux[:, 0] < 0).sum())                    # bit 31 of aux.x: the ray's list overflowed
+        assert (over > 0) == (word == 1)
+        assert int(lists.pool_next[1]) == word
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+        grad = _C.volume_render_backward(spec, rs, opt, g.to(gpu), lists=lists)
+        assert_grads_close(grad.cpu().numpy(), gw, ab)
