@@ -26,7 +26,11 @@
 namespace svoxt {
 
 constexpr int kOrderBlock = 256;
-constexpr int kOrderBits = 21;          // Morton bits of the key
+#ifndef SVOXT_ORDER_AXIS_BITS
+#define SVOXT_ORDER_AXIS_BITS 7
+#endif
+constexpr int kAxisBits = SVOXT_ORDER_AXIS_BITS;     // cells of 2^-kAxisBits of the cube per axis
+constexpr int kOrderBits = 3 * kAxisBits;   // Morton bits of the key
 
 __device__ __forceinline__ uint32_t spread10(uint32_t x) {      // 10 bits -> every third bit
     x &= 0x3ffu;
@@ -55,8 +59,9 @@ ray_key_kernel(TreeDev tr, RaysDev rays, Opts opt, uint32_t* __restrict__ keys, 
         const float pz = fminf(fmaxf(r.oz + t * r.dz, 0.f), kClampHi);
         // 7 bits per axis: cells of 1/128 of the cube -- a 64-ray group of the sorted batch spans a handful of
         // neighbouring cells; finer keys would order rays WITHIN what a wavefront holds anyway
-        key = (spread10((uint32_t)(px * 128.f)) << 2) | (spread10((uint32_t)(py * 128.f)) << 1) |
-              spread10((uint32_t)(pz * 128.f));
+        constexpr float kCells = (float)(1 << kAxisBits);
+        key = (spread10((uint32_t)(px * kCells)) << 2) | (spread10((uint32_t)(py * kCells)) << 1) |
+              spread10((uint32_t)(pz * kCells));
     }
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
