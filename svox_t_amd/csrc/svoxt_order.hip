@@ -29,9 +29,23 @@ constexpr int kOrderBlock = 256;
 #ifndef SVOXT_ORDER_AXIS_BITS
 #define SVOXT_ORDER_AXIS_BITS 7
 #endif
+#ifndef SVOXT_ORDER_FACE_BITS
+#define SVOXT_ORDER_FACE_BITS 0
+#endif
 constexpr int kAxisBits = SVOXT_ORDER_AXIS_BITS;     // cells of 2^-kAxisBits of the cube per axis
-constexpr int kOrderBits = 3 * kAxisBits;   // Morton bits of the key
+constexpr int kFaceBits = SVOXT_ORDER_FACE_BITS;     // > 0: rays that enter through a face are keyed by (face, u, v), 2^-kFaceBits cells
+constexpr int kOrderBits = 3 * kAxisBits;   // Morton bits of the 3-D key
+constexpr uint32_t kFaceCells = kFaceBits > 0 ? 6u << (2 * kFaceBits) : 0u;      // the face keys come first
+constexpr uint32_t kMissKey = kFaceCells + (1u << kOrderBits);
 
+__device__ __forceinline__ uint32_t spread2d(uint32_t x) {      // 16 bits -> every second bit
+    x &= 0xffffu;
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
 __device__ __forceinline__ uint32_t spread10(uint32_t x) {      // 10 bits -> every third bit
     x &= 0x3ffu;
     x = (x | (x << 16)) & 0x30000ffu;
@@ -51,7 +65,7 @@ ray_key_kernel(TreeDev tr, RaysDev rays, Opts opt, uint32_t* __restrict__ keys, 
     const int64_t q = (int64_t)blockIdx.x * kOrderBlock + threadIdx.x;
     const bool in = q < rays.Q;
     Ray r;
-    uint32_t key = 1u << kOrderBits;                 // misses go last (their wavefronts end at once)
+    uint32_t key = kMissKey;                         // misses go last (their wavefronts end at once)
     if (in && setup_ray(tr, rays, opt, q, r)) {
         const float t = r.tmin;                      // >= 0: the origin itself when it lies inside
         const float px = fminf(fmaxf(r.ox + t * r.dx, 0.f), kClampHi);
@@ -60,8 +74,21 @@ ray_key_kernel(TreeDev tr, RaysDev rays, Opts opt, uint32_t* __restrict__ keys, 
         // 7 bits per axis: cells of 1/128 of the cube -- a 64-ray group of the sorted batch spans a handful of
         // neighbouring cells; finer keys would order rays WITHIN what a wavefront holds anyway
         constexpr float kCells = (float)(1 << kAxisBits);
-        key = (spread10((uint32_t)(px * kCells)) << 2) | (spread10((uint32_t)(py * kCells)) << 1) |
-              spread10((uint32_t)(pz * kCells));
+        key = kFaceCells + ((spread10((uint32_t)(px * kCells)) << 2) | (spread10((uint32_t)(py * kCells)) << 1) |
+                            spread10((uint32_t)(pz * kCells)));
+        if constexpr (kFaceBits > 0) {
+            // a ray that starts outside enters through a face: the entry point has two free coordinates, so 2^-kFaceBits
+            // cells of a face cost 6 x 4^kFaceBits counters where cells as fine in three dimensions cost 8^kFaceBits
+            if (t > 0.f) {
+                const float ex = fminf(px, 1.f - px), ey = fminf(py, 1.f - py), ez = fminf(pz, 1.f - pz);
+                const int a = (ex <= ey && ex <= ez) ? 0 : (ey <= ez ? 1 : 2);          // the axis the entry face is normal to
+                const float pa = a == 0 ? px : a == 1 ? py : pz;
+                const float u = a == 0 ? py : px, v = a == 2 ? py : pz;
+                constexpr float kF = (float)(1 << kFaceBits);
+                const uint32_t face = (uint32_t)(2 * a + (pa > 0.5f ? 1 : 0));
+                key = (face << (2 * kFaceBits)) | (spread2d((uint32_t)(u * kF)) << 1) | spread2d((uint32_t)(v * kF));
+            }
+        }
     }
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
@@ -125,7 +152,7 @@ gather_rays_kernel(RaysDev rays, const int32_t* __restrict__ perm, float* __rest
     v[i] = rays.vdirs[from];
 }
 
-constexpr size_t kOrderCells = ((size_t)1 << kOrderBits) + 1;    // one counter per cell, the last one for rays that miss the cube
+constexpr size_t kOrderCells = (size_t)kMissKey + 1;            // one counter per cell, the last one for rays that miss the cube
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
