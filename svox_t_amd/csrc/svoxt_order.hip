@@ -13,8 +13,8 @@
 // backward); rays drawn from 8 cameras: 1.70 -> 1.35 ms.
 //
 // No counterpart in the reference (which marches rays in the order given).
-// The sort is a counting sort on the 22-bit cell key: count (a returning atomic per ray gives its rank in
-// the cell), exclusive scan of the 4 M counters (rocPRIM, the vendor primitive), scatter -- 4 launches and
+// The sort is a counting sort on the cell key: count (a returning atomic per ray gives its rank in
+// the cell), exclusive scan of the 655 361 counters (rocPRIM, the vendor primitive), scatter -- 4 launches and
 // ~0.04 ms for 640 000 rays where a radix sort of (key, id) pairs takes 21 launches and 0.14 ms.
 
 #include <cstring>
@@ -26,11 +26,17 @@
 namespace svoxt {
 
 constexpr int kOrderBlock = 256;
+// (r04) Keys: a ray that starts outside the cube enters through a face -- (face, u, v) in cells of 1/256 (2-D Morton
+// within the face: 393 216 counters) --, one that starts inside is keyed by its origin's 3-D cell of 1/64 (262 144 more).
+// Until r04 every ray had a 3-D cell of 1/128 (2 M counters, most of them never touched: entry points lie on three faces):
+// the reference-API route of the headline 1 043-1 052 -> 1 080-1 093 Mrays/s (finer groups of 64 rays AND an eighth of
+// the counters to clear and scan); 3-D cells of 1/64 or 1/32 alone: 1 003 / 944; faces of 1/512 or 1/1024: 1 055-1 080 /
+// 1 009-1 020 (the scan again); faces of 1/128: 1 031-1 061.
 #ifndef SVOXT_ORDER_AXIS_BITS
-#define SVOXT_ORDER_AXIS_BITS 7
+#define SVOXT_ORDER_AXIS_BITS 6
 #endif
 #ifndef SVOXT_ORDER_FACE_BITS
-#define SVOXT_ORDER_FACE_BITS 0
+#define SVOXT_ORDER_FACE_BITS 8
 #endif
 constexpr int kAxisBits = SVOXT_ORDER_AXIS_BITS;     // cells of 2^-kAxisBits of the cube per axis
 constexpr int kFaceBits = SVOXT_ORDER_FACE_BITS;     // > 0: rays that enter through a face are keyed by (face, u, v), 2^-kFaceBits cells
