@@ -5,7 +5,7 @@
 // (training on rays drawn at random from many cameras) every lane goes its own way: each
 // step's loads hit 64 different cache lines and the wavefront lasts as long as its longest
 // ray.  svoxt_ray_order gives the permutation that sorts a batch by the Morton code of the
-// point where each ray enters the tree's cube (10 bits per axis; rays that miss the cube
+// point where each ray enters the tree's cube (the key: see SVOXT_ORDER_FACE_BITS below; rays that miss the cube
 // last).  The caller gathers origins / dirs / viewdirs with it, renders the sorted batch
 // (any entry point of include/svoxt.h) and scatters the output rows back -- results are per
 // ray and do not depend on the order; 800x800 shuffled rays of one camera, depth-8 SH9 tree:
