@@ -77,7 +77,12 @@ motion_render_kernel(TreeDev tr, RaysDev rays, Opts opt, int J, float* __restric
 // march then reads one aligned row per sample instead of n_bind scattered joint
 // rows.  (First version blended per sample: 64 dword gathers per sample, forward
 // 1.37 ms on the headline tree against 0.3 ms for a volume_render of that width.)
-template <int FMAX>
+// (r04) What the march needs of a blended value is a function of the row alone too: MODE 1 (forward) leaves
+// exp(-value) -- the forward's quotient weight / (1 + e) still depends on the sample --, MODE 2 (backward) the float
+// sigmoid itself (rt_kernel.cu:1047-1050: sigmoid * (1 - sigmoid) * weight * grad): the same operations on the same
+// operands, once per row instead of once per sample and channel (800 x 800 / depth 8 / 16 features: forward 0.58 ->
+// see profiles/r04_motion_timing.txt).
+template <int FMAX, int MODE>
 __global__ void __launch_bounds__(256)
 motion_blend_kernel(MotionDev mo, int64_t M, float* __restrict__ blended) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -96,6 +101,11 @@ motion_blend_kernel(MotionDev mo, int64_t M, float* __restrict__ blended) {
             for (int k = 0; k < FMAX; ++k)
                 if (k < mo.F) pjf[k] += w * jf[k];
         }
+    }
+#pragma unroll
+    for (int k = 0; k < FMAX; ++k) {
+        if constexpr (MODE == 1) pjf[k] = pexpf(-pjf[k]);
+        else if constexpr (MODE == 2) pjf[k] = (float)sigmoid_d(pjf[k]);
     }
     typedef float v4f __attribute__((ext_vector_type(4)));
     v4f* dst = reinterpret_cast<v4f*>(blended + row * FMAX);
@@ -135,7 +145,7 @@ motion_feature_fwd_kernel(TreeDev tr, int F, const float* __restrict__ blended, 
                 load_row<FMAX>(blended + (int64_t)s.idx * FMAX, pjf);
 #pragma unroll
                 for (int k = 0; k < FMAX; ++k)
-                    if (k < F) acc[k] = (float)((double)acc[k] + (double)weight / (1.0 + (double)pexpf(-pjf[k])));
+                    if (k < F) acc[k] = (float)((double)acc[k] + (double)weight / (1.0 + (double)pjf[k]));      // (pjf: exp(-value), MODE 1)
                 light *= att;
                 if (light <= opt.stop_thresh) {
                     const float scale = (float)(1.0 / (1.0 - (double)light));
@@ -207,7 +217,7 @@ motion_feature_bwd_kernel(TreeDev tr, int F, const float* __restrict__ blended, 
             float* st = stage + slot * KS;
 #pragma unroll
             for (int k = 0; k < FMAX; ++k) {
-                const float sg = (float)sigmoid_d(pjf[k]);
+                const float sg = pjf[k];                      // (the row's float sigmoid: motion_blend_kernel<..., 2>)
                 st[k] = weight * sg * (1.f - sg) * g[k];      // pad columns: g = 0
             }
         }
@@ -467,7 +477,7 @@ int svoxt_motion_feature_render_fwd(const svoxt_tree* tree, const svoxt_motion* 
     const unsigned nb = blocks_of(rays->Q, kMotionBlock);
     SVOXT_MOTION_DISPATCH(F,
         if (tree->M > 0)
-            hipLaunchKernelGGL((motion_blend_kernel<FMAX>), dim3(blocks_of(tree->M, 256)), dim3(256), 0, st, mo, tree->M, blended);
+            hipLaunchKernelGGL((motion_blend_kernel<FMAX, 1>), dim3(blocks_of(tree->M, 256)), dim3(256), 0, st, mo, tree->M, blended);
         if (tree->N == 2)
             hipLaunchKernelGGL((motion_feature_fwd_kernel<true, FMAX>), dim3(nb), dim3(kMotionBlock), 0, st, tr, F, blended, rd, od, out);
         else
@@ -503,7 +513,7 @@ int svoxt_motion_feature_render_bwd(const svoxt_tree* tree, const svoxt_motion* 
     const unsigned nbm = blocks_of(tree->M, 256);
     const bool lds = jbytes <= 65536;
     SVOXT_MOTION_DISPATCH(F,
-        hipLaunchKernelGGL((motion_blend_kernel<FMAX>), dim3(nbm), dim3(256), 0, st, mo, tree->M, blended);
+        hipLaunchKernelGGL((motion_blend_kernel<FMAX, 2>), dim3(nbm), dim3(256), 0, st, mo, tree->M, blended);
         if (tree->N == 2)
             hipLaunchKernelGGL((motion_feature_bwd_kernel<true, FMAX>), dim3(nb), dim3(kMotionBlock), 0, st, tr, F, blended, rd, od, grad_out, grad_blended);
         else
