@@ -54,6 +54,7 @@ timing motion scripts/motion_timing.py
 timing xform scripts/xform_timing.py
 timing opacity scripts/opacity_timing.py
 timing depth scripts/depth_timing.py
+timing query scripts/query_timing.py
 timing build scripts/build_timing.py
 timing ray_order scripts/ray_order_timing.py
 fi

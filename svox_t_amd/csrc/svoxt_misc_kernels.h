@@ -331,50 +331,78 @@ count_touched_kernel(TreeDev tr, RaysDev rays, Opts opt, uint8_t* __restrict__ r
 // Point query (svox_kernel.cu:45-94)
 // ---------------------------------------------------------------------------
 
+// (r04) The rows of a wavefront's 64 points, moved by the wavefront together: two points per instruction for rows of up
+// to 32 floats (lanes 0-31 the columns of one, 32-63 of the next), one for wider rows -- a point's row is then ONE
+// contiguous segment per load / store / atomic instruction, where a lane that walks its own row touches 64 different
+// rows with every instruction (the backward: 28 memory-side atomic requests per point instead of 2-3; 1 M points on the
+// depth-8 shell: query + backward 2.17 ms before: profiles/r04_query_timing.txt).  ridx: the lane's feature row, < 0: none.
+template <bool BWD>
+__device__ __forceinline__ void query_rows(const TreeDev& tr, int32_t ridx, int64_t q0, int64_t Q,
+                                           float* __restrict__ values, const float* __restrict__ grad_out,
+                                           float* __restrict__ grad) {
+    const int lane = threadIdx.x & 63;
+    const int K = tr.K;
+    const int per = K <= 32 ? 2 : 1;                 // points per instruction
+    const int lpr = 64 / per;                        // lanes per point
+    const int sub = per == 2 ? (lane >> 5) : 0, j0 = per == 2 ? (lane & 31) : lane;
+    for (int base = 0; base < 64; base += per) {     // (uniform: every lane takes part in the cross-lane read)
+        const int p = base + sub;
+        const int32_t r = __shfl(ridx, p, 64);
+        const int64_t qq = q0 + p;
+        if (qq >= Q) continue;
+        for (int col = j0; col < K; col += lpr) {
+            if constexpr (BWD) {
+                if (r >= 0) atomicAdd(grad + (int64_t)r * K + col, grad_out[qq * K + col]);
+            } else {
+                values[qq * K + col] = r >= 0 ? tr.features[(int64_t)r * K + col] : 0.f;
+            }
+        }
+    }
+}
+
+// the leaf of point q (q < Q): its slot, and its feature row or -1
 template <bool N2>
-__global__ void __launch_bounds__(kBlock)
-query_fwd_kernel(TreeDev tr, const float* __restrict__ points, int64_t Q,
-                 float* __restrict__ values, int64_t* __restrict__ node_ids,
-                 int64_t* __restrict__ data_ids, uint8_t* __restrict__ hit_mask) {
-    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (q >= Q) return;
+__device__ __forceinline__ int32_t query_locate(const TreeDev& tr, const float* __restrict__ points, int64_t q, uint32_t& slot) {
     const float* p = points + 3 * q;
     const float px = tr.offset[0] + tr.scaling[0] * p[0];
     const float py = tr.offset[1] + tr.scaling[1] * p[1];
     const float pz = tr.offset[2] + tr.scaling[2] * p[2];
     Leaf lf;
     locate<N2>(tr, px, py, pz, lf);
-    node_ids[q] = (int64_t)lf.slot;
-    if (hit_mask != nullptr) hit_mask[lf.slot] = 1;
+    slot = lf.slot;
     const int32_t idx = tr.data[lf.slot];
-    const int K = tr.K;
-    float* v = values + q * K;
-    if (idx >= 0 && (int64_t)idx < tr.M) {
+    return (idx >= 0 && (int64_t)idx < tr.M) ? idx : -1;
+}
+
+template <bool N2>
+__global__ void __launch_bounds__(kBlock)
+query_fwd_kernel(TreeDev tr, const float* __restrict__ points, int64_t Q,
+                 float* __restrict__ values, int64_t* __restrict__ node_ids,
+                 int64_t* __restrict__ data_ids, uint8_t* __restrict__ hit_mask) {
+    static_assert(kBlock == 64, "query_rows: one wavefront per workgroup");
+    const int64_t q0 = (int64_t)blockIdx.x * kBlock, q = q0 + threadIdx.x;
+    int32_t idx = -1;
+    if (q < Q) {
+        uint32_t slot;
+        idx = query_locate<N2>(tr, points, q, slot);
+        node_ids[q] = (int64_t)slot;
+        if (hit_mask != nullptr) hit_mask[slot] = 1;
         data_ids[q] = idx;
-        const float* row = tr.features + (int64_t)idx * K;
-        for (int i = 0; i < K; ++i) v[i] = row[i];
-    } else {
-        data_ids[q] = -1;
-        for (int i = 0; i < K; ++i) v[i] = 0.f;
     }
+    query_rows<false>(tr, idx, q0, Q, values, nullptr, nullptr);
 }
 
 template <bool N2>
 __global__ void __launch_bounds__(kBlock)
 query_bwd_kernel(TreeDev tr, const float* __restrict__ points, int64_t Q,
                  const float* __restrict__ grad_out, float* __restrict__ grad) {
-    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (q >= Q) return;
-    const float* p = points + 3 * q;
-    const float px = tr.offset[0] + tr.scaling[0] * p[0];
-    const float py = tr.offset[1] + tr.scaling[1] * p[1];
-    const float pz = tr.offset[2] + tr.scaling[2] * p[2];
-    Leaf lf;
-    locate<N2>(tr, px, py, pz, lf);
-    const int32_t idx = tr.data[lf.slot];
-    if (idx < 0 || (int64_t)idx >= tr.M) return;
-    const int K = tr.K;
-    for (int i = 0; i < K; ++i) atomicAdd(grad + (int64_t)idx * K + i, grad_out[q * K + i]);
+    const int64_t q0 = (int64_t)blockIdx.x * kBlock, q = q0 + threadIdx.x;
+    int32_t idx = -1;
+    if (q < Q) {
+        uint32_t slot;
+        idx = query_locate<N2>(tr, points, q, slot);
+    }
+    query_rows<true>(tr, idx, q0, Q, nullptr, grad_out, grad);
 }
 
 // ---------------------------------------------------------------------------
