@@ -13,7 +13,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import svox_t_amd as svox          # noqa: E402
+import svox_t_amd as svox
+import svox_t_amd.csrc as _C  # noqa: E402          # noqa: E402
 from svox_t_amd import synth       # noqa: E402
 
 
@@ -68,6 +69,8 @@ def main():
                      ("forward + backward with view rotations", lambda: step(mats))):
         ms = timed(fn, a.reps)
         print(f"{name:42s} {ms:8.3f} ms  {Q / ms / 1e3:7.1f} Mrays/s")
+        if "backward" in name:
+            print(f"    route: {_C.LAST_ROUTE['forward']} | {_C.LAST_ROUTE['backward']}")
 
 
 if __name__ == "__main__":

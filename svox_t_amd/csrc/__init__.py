@@ -955,6 +955,12 @@ def _volume_render(tree, rays, opt, record):
         coherent = tiled or bool(getattr(rays, "coherent", False))
         will_record = bool(BWD_EXACT and BWD_TERMS and BWD_FUSED and (BWD_GATHER == 2 or (BWD_GATHER == 1 and coherent)))
     lflags = _list_flags(native=NATIVE_MATH and wide)
+    # per-leaf view rotations, SH 1 / 4 / 9: march and shade in one launch too (no hand-over: their backward recomputes)
+    xf_roles = bool(will_record and ct.xform and FWD_SPLIT == "" and FWD_OVERLAP and LIST_POOL and BWD_XF_FUSED and ct.N == 2
+                    and ct.weight_accum is None and co.format == FORMAT_SH and co.basis_dim in (1, 4, 9)
+                    and ct.K == 3 * co.basis_dim + 1 and co.stop_thresh == 0.0)
+    if xf_roles:
+        lflags |= LISTS_FWD_TWO_KERNELS
     fills = _lib.svoxt_fwd_fills_terms(ctypes.byref(ct), ctypes.byref(co), lflags) \
         if (will_record and BWD_EXACT and BWD_TERMS and BWD_FUSED and BWD_GATHER) else 0
     # the march of the two-kernel forward reads a bit per row instead of gathering sigma -- where that
@@ -964,7 +970,7 @@ def _volume_render(tree, rays, opt, record):
     if will_record:
         with torch.cuda.device(dev):
             lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
-    if ((split or fills == 3) and FWD_SPLIT != "0") if will_record else (split and co.stop_thresh == 0.0):
+    if ((split or fills == 3 or xf_roles) and FWD_SPLIT != "0") if will_record else (split and co.stop_thresh == 0.0):
         # rows of 8 / 16 / 32 floats in exact mode: the same pass leaves the rows' exponentials for the shade kernel
         # (and, on the lists, for the per-tile backward of this feature content)
         etab = _attach_sigma_mask(tree, ct, float(co.sigma_thresh), keep=not will_record,
@@ -993,6 +999,8 @@ def _volume_render(tree, rays, opt, record):
             _call("svoxt_volume_render_fwd_record", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(out), ctypes.byref(cl), _stream(dev))
             lists.note_usage()
+            if xf_roles:
+                LAST_ROUTE["forward"] = "fwd_roles_kernel<XF> (march + shade_tile in one launch, a basis per record), recording sample lists"
             LAST_ROUTE["forward_terms"] = lists.terms_state in (2, 3)
             if lists.terms_state == 3 and FWD_SPLIT == "":
                 LAST_ROUTE["forward"] = ("fwd_roles_kernel (march + shade_tile in one launch)" if roles else

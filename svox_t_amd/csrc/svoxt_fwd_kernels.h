@@ -663,7 +663,7 @@ shade_tile_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
 // item 5).  A workgroup takes a contiguous run of tiles: its threads read the run's states at once and collect the
 // unshaded ones (none, normally), it shades those (shade_tile_body: the whole workgroup per tile), then -- one scalar
 // load says whether any ray of the batch overflowed -- its wavefronts walk the run's tiles with render_fwd_ray<RESUME>.
-template <int FMT, int BD, bool WTERMS, bool LOBES = false>
+template <int FMT, int BD, bool WTERMS, bool LOBES = false, bool XF = false>
 __global__ void __launch_bounds__(512)
 fwd_finish_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux, float* __restrict__ out,
                   int32_t* __restrict__ tile_state, int ntiles) {
@@ -688,13 +688,13 @@ fwd_finish_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restr
     if (n > CAP) {                                           // more than the list holds: the run, tile by tile
         for (int tile = t0; tile < t1; ++tile) {
             if (tile_state[tile] == kTileShaded) continue;   // (uniform)
-            shade_tile_body<FMT, BD, false, false, WTERMS, false, LOBES>(tr, rays, opt, L, aux, out, tile, terms);
+            shade_tile_body<FMT, BD, XF, false, WTERMS, false, LOBES>(tr, rays, opt, L, aux, out, tile, terms);
             if (threadIdx.x == 0) atomicAdd(fallback_ctr, 1);
             __syncthreads();
         }
     } else {
         for (int j = 0; j < n; ++j) {
-            shade_tile_body<FMT, BD, false, false, WTERMS, false, LOBES>(tr, rays, opt, L, aux, out, s_list[j], terms);
+            shade_tile_body<FMT, BD, XF, false, WTERMS, false, LOBES>(tr, rays, opt, L, aux, out, s_list[j], terms);
             if (threadIdx.x == 0) atomicAdd(fallback_ctr, 1);
             __syncthreads();
         }
@@ -702,7 +702,7 @@ fwd_finish_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restr
     if (no_ray_overflowed(L)) return;
     __syncthreads();                                         // (a tail resumes from what the shade of its tile left)
     for (int tile = t0 + (int)(threadIdx.x >> 6); tile < t1; tile += 8)
-        render_fwd_ray<FMT, 3, BD, true, false, false, true, LOBES>(tr, rays, opt, out, L, aux, (int64_t)tile * 64 + (threadIdx.x & 63));
+        render_fwd_ray<FMT, 3, BD, true, false, XF, true, LOBES>(tr, rays, opt, out, L, aux, (int64_t)tile * 64 + (threadIdx.x & 63));
 }
 
 // ---------------------------------------------------------------------------
@@ -805,7 +805,9 @@ __host__ __device__ inline int64_t roles_group_of(const RolesMap& m, int b) {   
     return (int64_t)m.full * 8 * m.gb + (int64_t)x * m.gb_last + (s - m.full * m.gb);
 }
 
-template <int FMT, int BD, int ACC, bool WTERMS, bool LOBES = false>
+// XF (r04; SH up to 9 basis functions, no hand-over): per-leaf view rotations -- the shading role evaluates a record's basis
+// from its leaf's matrix (shade_tile_body<..., XF>); the backward of such lists recomputes what it needs (grad_fused_kernel<..., XF>).
+template <int FMT, int BD, int ACC, bool WTERMS, bool LOBES = false, bool XF = false>
 __global__ void __launch_bounds__(512)
 fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux, float* __restrict__ out,
                  const uint32_t* __restrict__ sigma_mask, int32_t* __restrict__ tile_state, int n_march, int ntiles,
@@ -870,7 +872,8 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
     }
     if (agent_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     uint32_t ax = 0u;
-    const uint32_t part = shade_tile_body<FMT, BD, false, false, WTERMS, true, LOBES>(
+    static_assert(!XF || (FMT == FMT_SH && !WTERMS && !LOBES && BD <= 9), "view rotations: SH rows, no hand-over");
+    const uint32_t part = shade_tile_body<FMT, BD, XF, false, WTERMS, true, LOBES>(
         tr, rays, opt, L, aux, out, tile, reinterpret_cast<shade_v4f (*)[kShadeP][64]>(lds), (tflags & kRoleTestStale) && tile % 5 == 0, &ax);
     // what this workgroup loaded, folded like the march folded what it wrote: per ray first (the eight wavefronts'
     // words of a lane; the shade's double buffer is free behind its last barrier), then over the tile

@@ -416,7 +416,7 @@ bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float
 // payloads of at most 28 floats on N = 2 trees, no view rotations, no stop rule, the sigma bitmask at hand.
 template <bool N2, bool STOP>
 bool launch_fwd_roles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float* out, RecLists L, uint4* aux,
-                      hipStream_t st, const uint32_t* sigma_mask, int32_t* tile_state, int tflags) {
+                      hipStream_t st, const uint32_t* sigma_mask, int32_t* tile_state, int tflags, bool xf) {
     if constexpr (!N2 || STOP) {
         return false;
     } else {
@@ -445,6 +445,27 @@ bool launch_fwd_roles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
                                     tr, rays, opt, L, aux, out, tile_state, (int)nb);                             \
             return true;                                                                                          \
         }
+        if (xf) {
+            // (r04) per-leaf view rotations: SH 1 / 4 / 9 without hand-over (the lists' backward is grad_fused_kernel<..., XF>)
+            if (opt.format != FMT_SH || wt || opt.basis_dim > 9) return false;
+#define SVOXT_ROLES_XF(BB)                                                                                        \
+            {                                                                                                     \
+                if (acc) hipLaunchKernelGGL((fwd_roles_kernel<FMT_SH, BB, 1, false, false, true>), dim3(grid), dim3(512), 0, st, \
+                                            tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
+                else hipLaunchKernelGGL((fwd_roles_kernel<FMT_SH, BB, 0, false, false, true>), dim3(grid), dim3(512), 0, st, \
+                                        tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
+                hipLaunchKernelGGL((fwd_finish_kernel<FMT_SH, BB, false, false, true>), dim3(finish_grid(nb)), dim3(512), 0, st, \
+                                   tr, rays, opt, L, aux, out, tile_state, (int)nb);                              \
+                return true;                                                                                      \
+            }
+            switch (opt.basis_dim) {
+                case 1: SVOXT_ROLES_XF(1)
+                case 4: SVOXT_ROLES_XF(4)
+                case 9: SVOXT_ROLES_XF(9)
+            }
+#undef SVOXT_ROLES_XF
+            return false;
+        }
         if (opt.format == FMT_RGBA && tr.K == 4) SVOXT_ROLES(FMT_RGBA, 0)
         if (opt.format == FMT_SH) {
             switch (opt.basis_dim) {
@@ -466,8 +487,8 @@ bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
     const unsigned nb = nblocks(rays.Q);
     if (xf && !N2) return false;
     const bool acc = N2 && tr.accel != nullptr;
-    if (tile_state != nullptr && sigma_mask != nullptr && !xf && !STOP &&
-        launch_fwd_roles<N2, STOP>(tr, rays, opt, out, L, aux, st, sigma_mask, tile_state, tflags))
+    if (tile_state != nullptr && sigma_mask != nullptr && !STOP &&
+        launch_fwd_roles<N2, STOP>(tr, rays, opt, out, L, aux, st, sigma_mask, tile_state, tflags, xf))
         return true;
     if constexpr (!STOP) {
         if (sigma_mask != nullptr) {
