@@ -999,12 +999,12 @@ def _volume_render(tree, rays, opt, record):
             _call("svoxt_volume_render_fwd_record", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(out), ctypes.byref(cl), _stream(dev))
             lists.note_usage()
-            if xf_roles:
-                LAST_ROUTE["forward"] = "fwd_roles_kernel<XF> (march + shade_tile in one launch, a basis per record), recording sample lists"
             LAST_ROUTE["forward_terms"] = lists.terms_state in (2, 3)
             if lists.terms_state == 3 and FWD_SPLIT == "":
                 LAST_ROUTE["forward"] = ("fwd_roles_kernel (march + shade_tile in one launch)" if roles else
                                          "march_rec_kernel + shade_tile_kernel (two-kernel forward)") + ", recording sample lists"
+            if xf_roles:
+                LAST_ROUTE["forward"] = "fwd_roles_kernel<XF> (march + shade_tile in one launch, a basis per record), recording sample lists"
         elif split and FWD_LIST_SAMPLES > 0 and cr.Q > 0:
             # scratch for the two-kernel forward (march, then shade per tile; the library falls
             # back to the one-kernel forward for payloads it does not cover).  (r04: only where that forward is what

@@ -176,8 +176,12 @@ bool launch_bwd_gather(const TreeDev& tr, const RaysDev& rays, const Opts& opt, 
     {                                                                                                             \
         hipLaunchKernelGGL((render_bwd_kernel<FMT_SH, 3, BB, true, true, true>), dim3(nb), dim3(kBlock), 0, st,   \
                            tr, rays, opt, grad_out, grad, gstride, L, aux, fwd_out, reinterpret_cast<float4*>(kOnlyOverflowed)); \
-        hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 0, false, false, true>), dim3(nb), dim3(512), 0, st, \
-                           tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                              \
+        if (L.terms != nullptr && terms_state == 3)   /* the forward's hand-over: exponentials of each record's own basis */ \
+            hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 3, false, false, true>), dim3(nb), dim3(512), 0, st, \
+                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                          \
+        else                                                                                                      \
+            hipLaunchKernelGGL((grad_fused_kernel<FMT_SH, BB, true, false, 0, false, false, true>), dim3(nb), dim3(512), 0, st, \
+                               tr, rays, opt, grad_out, L, aux, fwd_out, grad, gstride);                          \
         return true;                                                                                              \
     }
     if (xf) {
@@ -338,7 +342,8 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
                                          reinterpret_cast<float4*>(lists->coef), true, st);
             else if (lists->coef == nullptr && lists->coef_bytes < 0 && tree->K <= 32 && fwd_out == nullptr && C == 3 && n2)
                 done = launch_bwd_gather(tr, rd, od, C, grad_out, grad_features, gs, lists_dev(lists, rays->Q),
-                                         reinterpret_cast<const uint4*>(lists->aux), fwd_out, nullptr, true, st);   // list walk + merge as one kernel
+                                         reinterpret_cast<const uint4*>(lists->aux), fwd_out, nullptr, true, st,
+                                         lists->terms_state == 3 ? 3 : 0);     // list walk + merge as one kernel (over the forward's hand-over, if it left one)
             if (!done)
                 done = launch_bwd_xform<true>(tr, rd, od, C, grad_out, grad_features, gs, lists_dev(lists, rays->Q),
                                               reinterpret_cast<const uint4*>(lists->aux), fwd_out, st);

@@ -884,7 +884,7 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
     static_assert(TERMS == 0 || TERMS == 2 || TERMS == 3, "hand-over layouts");
     static_assert(K <= 32 || (EXACT && TERMS >= 2), "wide rows: only with the forward's hand-over (no row in registers)");
     static_assert(!LOBES || (FMT == FMT_SH && EXACT && TERMS >= 2), "lobes: only over the forward's hand-over");
-    static_assert(!XF || (FMT == FMT_SH && EXACT && TERMS == 0 && !LOBES && BD <= 9), "view rotations: SH rows in registers, exact, no hand-over");
+    static_assert(!XF || (FMT == FMT_SH && EXACT && (TERMS == 0 || TERMS == 3) && !LOBES && BD <= 9), "view rotations: SH rows in registers, exact");
     __shared__ float vds[XF ? 64 * 3 : 1];       // XF: the 64 rays' view directions, for the reduce
     __shared__ int32_t keys[T];
     __shared__ int32_t cnt[T];
@@ -1010,6 +1010,16 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 if constexpr (TERMS >= 2) {
                     const float4 tv = tv_cur;
                     att = tv.x; ex[0] = tv.y; ex[1] = tv.z; ex[2] = tv.w;
+                    if constexpr (XF) {
+                        // (the forward's exponentials are those of each record's own basis; what this sweep still owes is
+                        // the basis of the ray's LAST record, for sweep 2's total_color)
+                        if (k == nrec - 1) {
+                            const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
+                            rotated_sh_basis<BD>(tr, SVOXT_CHK((int32_t)e.x, tr.M, 6), vsrc, basis);
+#pragma unroll
+                            for (int i = 0; i < NB; ++i) bases[lane * BDS + i] = basis[i];
+                        }
+                    }
                 } else {
                     const uint2 e = rec_get(L.rec + rec_index_in(blk, lane, k));
                     float row[K];
@@ -1136,6 +1146,8 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                 const float ex[C] = {tv.y, tv.z, tv.w};
                 att = tv.x;
                 tc = 0.f;
+                float row[XF ? K : 1];
+                if constexpr (XF) load_row<K>(tr.features + (int64_t)SVOXT_CHK((int32_t)e.x, tr.M, 6) * K, row);
 #pragma unroll
                 for (int c = 0; c < C; ++c) {                     // sample_terms from here on, operation for operation
                     const double sd = 1.0 / (1.0 + (double)ex[c]);
@@ -1145,7 +1157,15 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
                     } else {
                         cf[c] = (float)sd;
                     }
-                    tc = (float)((double)tc + sd * (double)g[c]);
+                    if constexpr (XF) {
+                        // total_color of the second pass: the basis the first pass ended with (coef_sample<..., XF>)
+                        float tmp2 = 0.f;
+#pragma unroll
+                        for (int i = 0; i < BD; ++i) tmp2 += bases[lane * BDS + i] * row[c * BD + i];
+                        tc = (float)((double)tc + sigmoid_d<true>(tmp2) * (double)g[c]);
+                    } else {
+                        tc = (float)((double)tc + sd * (double)g[c]);
+                    }
                 }
             } else {
                 float row[K];

@@ -805,8 +805,8 @@ __host__ __device__ inline int64_t roles_group_of(const RolesMap& m, int b) {   
     return (int64_t)m.full * 8 * m.gb + (int64_t)x * m.gb_last + (s - m.full * m.gb);
 }
 
-// XF (r04; SH up to 9 basis functions, no hand-over): per-leaf view rotations -- the shading role evaluates a record's basis
-// from its leaf's matrix (shade_tile_body<..., XF>); the backward of such lists recomputes what it needs (grad_fused_kernel<..., XF>).
+// XF (r04; SH up to 9 basis functions): per-leaf view rotations -- the shading role evaluates a record's basis from its
+// leaf's matrix (shade_tile_body<..., XF>) and its hand-over holds the exponentials of THAT basis (grad_fused_kernel<..., 3, ..., XF>).
 template <int FMT, int BD, int ACC, bool WTERMS, bool LOBES = false, bool XF = false>
 __global__ void __launch_bounds__(512)
 fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux, float* __restrict__ out,
@@ -872,7 +872,7 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
     }
     if (agent_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     uint32_t ax = 0u;
-    static_assert(!XF || (FMT == FMT_SH && !WTERMS && !LOBES && BD <= 9), "view rotations: SH rows, no hand-over");
+    static_assert(!XF || (FMT == FMT_SH && !LOBES && BD <= 9), "view rotations: SH rows");
     const uint32_t part = shade_tile_body<FMT, BD, XF, false, WTERMS, true, LOBES>(
         tr, rays, opt, L, aux, out, tile, reinterpret_cast<shade_v4f (*)[kShadeP][64]>(lds), (tflags & kRoleTestStale) && tile % 5 == 0, &ax);
     // what this workgroup loaded, folded like the march folded what it wrote: per ray first (the eight wavefronts'

@@ -349,8 +349,8 @@ bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float
                   bool xf, bool fast, unsigned nb, hipStream_t st) {
 #define SVOXT_SPLIT(F, BB, X)                                                                                 \
     {                                                                                                         \
-        if (!STOP && !X && L.terms != nullptr)                                                                \
-            hipLaunchKernelGGL((shade_tile_kernel<F, BB, false, STOP, !STOP>), dim3(nb), dim3(512), 0, st,    \
+        if (!STOP && L.terms != nullptr)                                                                      \
+            hipLaunchKernelGGL((shade_tile_kernel<F, BB, X, STOP, !STOP>), dim3(nb), dim3(512), 0, st,        \
                                tr, rays, opt, L, aux, out);                                                   \
         else                                                                                                  \
         hipLaunchKernelGGL((shade_tile_kernel<F, BB, X, STOP>), dim3(nb), dim3(512), 0, st, tr, rays, opt,    \
@@ -447,15 +447,18 @@ bool launch_fwd_roles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
         }
         if (xf) {
             // (r04) per-leaf view rotations: SH 1 / 4 / 9 without hand-over (the lists' backward is grad_fused_kernel<..., XF>)
-            if (opt.format != FMT_SH || wt || opt.basis_dim > 9) return false;
+            if (opt.format != FMT_SH || opt.basis_dim > 9) return false;
+#define SVOXT_ROLES_XF1(BB, AA, WW)                                                                               \
+                hipLaunchKernelGGL((fwd_roles_kernel<FMT_SH, BB, AA, WW, false, true>), dim3(grid), dim3(512), 0, st, \
+                                   tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap);
 #define SVOXT_ROLES_XF(BB)                                                                                        \
             {                                                                                                     \
-                if (acc) hipLaunchKernelGGL((fwd_roles_kernel<FMT_SH, BB, 1, false, false, true>), dim3(grid), dim3(512), 0, st, \
-                                            tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
-                else hipLaunchKernelGGL((fwd_roles_kernel<FMT_SH, BB, 0, false, false, true>), dim3(grid), dim3(512), 0, st, \
-                                        tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
-                hipLaunchKernelGGL((fwd_finish_kernel<FMT_SH, BB, false, false, true>), dim3(finish_grid(nb)), dim3(512), 0, st, \
-                                   tr, rays, opt, L, aux, out, tile_state, (int)nb);                              \
+                if (acc && wt) SVOXT_ROLES_XF1(BB, 1, true) else if (acc) SVOXT_ROLES_XF1(BB, 1, false)           \
+                else if (wt) SVOXT_ROLES_XF1(BB, 0, true) else SVOXT_ROLES_XF1(BB, 0, false)                      \
+                if (wt) hipLaunchKernelGGL((fwd_finish_kernel<FMT_SH, BB, true, false, true>), dim3(finish_grid(nb)), dim3(512), 0, st, \
+                                           tr, rays, opt, L, aux, out, tile_state, (int)nb);                      \
+                else hipLaunchKernelGGL((fwd_finish_kernel<FMT_SH, BB, false, false, true>), dim3(finish_grid(nb)), dim3(512), 0, st, \
+                                        tr, rays, opt, L, aux, out, tile_state, (int)nb);                         \
                 return true;                                                                                      \
             }
             switch (opt.basis_dim) {
@@ -464,6 +467,7 @@ bool launch_fwd_roles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
                 case 9: SVOXT_ROLES_XF(9)
             }
 #undef SVOXT_ROLES_XF
+#undef SVOXT_ROLES_XF1
             return false;
         }
         if (opt.format == FMT_RGBA && tr.K == 4) SVOXT_ROLES(FMT_RGBA, 0)
@@ -745,8 +749,10 @@ int svoxt_exp_table_build(const svoxt_tree* tree, float sigma_thresh, void* mask
 
 int svoxt_fwd_fills_terms(const svoxt_tree* tree, const svoxt_options* opt, int32_t list_flags) {
     if (tree == nullptr || opt == nullptr || !svoxt_can_record(tree, opt)) return 0;
-    if (uses_xform(tree, opt)) return 0;
     const int C = svoxt_out_data_dim(opt, tree->K) - 1;
+    if (uses_xform(tree, opt))      // (r04) view rotations: only the two-kernel / one-launch forward of SH 1 / 4 / 9 leaves a hand-over
+        return (C == 3 && tree->N == 2 && opt->format == SVOXT_FORMAT_SH && opt->basis_dim <= 9 && (list_flags & SVOXT_LISTS_FWD_TWO_KERNELS) &&
+                full_comp(opt) && fwd_split_payload(tree, opt, C) && xform_special(tree, opt)) ? 3 : 0;
     if (C != 3) return 0;
     if (lobes_payload(to_dev(opt), tree->K)) return 3;
     // 3: the two-kernel forward (tile shade kernel, position-major); 2: the one-kernel forward (lane-major lines)

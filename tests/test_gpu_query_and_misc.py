@@ -744,7 +744,8 @@ def test_acceleration_grid_never_goes_stale(gpu):
     ("SH4", 13, 5, "lists"),
     ("SH9", 28, 5, "two_kernel"),     # ... list walk + per-tile merge (rotated directions travel with the records)
     ("SH4", 13, 6, "two_kernel_overflow"),
-    ("SH9", 28, 5, "fused"),          # ... as ONE kernel (grad_fused_kernel<..., XF>: a basis per record, r04)
+    ("SH9", 28, 5, "fused"),          # ... as ONE kernel (grad_fused_kernel<..., XF>: a basis per record, r04) over the forward's hand-over
+    ("SH9", 28, 5, "fused_noterms"),  # ... without hand-over: both sweeps gather the rows and form every record's basis
     ("SH9", 28, 6, "fused_overflow"), # ... rays whose list overflowed go whole through the per-ray kernel in front
     ("SH4", 13, 6, "fused"),
     ("SH1", 4, 5, "fused"),
@@ -773,6 +774,8 @@ def test_transformation_matrices(gpu, monkeypatch, fmt, K, depth, mode):
         monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", 8)
     monkeypatch.setattr(_C, "BWD_GATHER", 2 if mode.startswith(("two_kernel", "fused")) else 0)
     monkeypatch.setattr(_C, "BWD_XF_FUSED", mode.startswith("fused"))
+    if mode == "fused_noterms":
+        monkeypatch.setattr(_C, "BWD_TERMS", False)
     if mode == "exact":
         monkeypatch.setattr(_C, "BWD_EXACT", True)
     r = svox.VolumeRenderer(tree)
@@ -798,6 +801,8 @@ def test_transformation_matrices(gpu, monkeypatch, fmt, K, depth, mode):
         assert_grads_close(tree.features.grad.cpu().numpy(), gw, ab)
         if mode.startswith("fused"):
             assert _C.LAST_ROUTE["backward"].startswith("grad_fused_kernel<EXACT, XF>"), _C.LAST_ROUTE
+            assert _C.LAST_ROUTE["forward"].startswith("fwd_roles_kernel<XF>"), _C.LAST_ROUTE
+            assert _C.LAST_ROUTE["forward_terms"] == (mode != "fused_noterms")
         elif mode.startswith("two_kernel"):
             assert _C.LAST_ROUTE["backward"].startswith("render_bwd_kernel<GATHER>"), _C.LAST_ROUTE
     if fmt != "SH9" or mode != "lists":
