@@ -38,14 +38,10 @@ constexpr int kOrderBlock = 256;
 #ifndef SVOXT_ORDER_FACE_BITS
 #define SVOXT_ORDER_FACE_BITS 8
 #endif
-#ifndef SVOXT_ORDER_DIR_BITS
-#define SVOXT_ORDER_DIR_BITS 0
-#endif
-constexpr int kDirBits = SVOXT_ORDER_DIR_BITS;       // > 0: face keys lead with the direction's two in-face components, 2^kDirBits buckets each
 constexpr int kAxisBits = SVOXT_ORDER_AXIS_BITS;     // cells of 2^-kAxisBits of the cube per axis
 constexpr int kFaceBits = SVOXT_ORDER_FACE_BITS;     // > 0: rays that enter through a face are keyed by (face, u, v), 2^-kFaceBits cells
 constexpr int kOrderBits = 3 * kAxisBits;   // Morton bits of the 3-D key
-constexpr uint32_t kFaceCells = kFaceBits > 0 ? 6u << (2 * kFaceBits + 2 * kDirBits) : 0u;      // the face keys come first
+constexpr uint32_t kFaceCells = kFaceBits > 0 ? 6u << (2 * kFaceBits) : 0u;      // the face keys come first
 constexpr uint32_t kMissKey = kFaceCells + (1u << kOrderBits);
 
 __device__ __forceinline__ uint32_t spread2d(uint32_t x) {      // 16 bits -> every second bit
@@ -97,16 +93,6 @@ ray_key_kernel(TreeDev tr, RaysDev rays, Opts opt, uint32_t* __restrict__ keys, 
                 constexpr float kF = (float)(1 << kFaceBits);
                 const uint32_t face = (uint32_t)(2 * a + (pa > 0.5f ? 1 : 0));
                 key = (face << (2 * kFaceBits)) | (spread2d((uint32_t)(u * kF)) << 1) | spread2d((uint32_t)(v * kF));
-                if constexpr (kDirBits > 0) {
-                    // rays of different cameras that enter through the same cell part ways inside: the direction's in-face
-                    // components (of the unit direction in tree space: in [-1, 1]) lead the key, the cell follows
-                    const float nrm = rsqrtf(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz);
-                    const float du = (a == 0 ? r.dy : r.dx) * nrm, dv = (a == 2 ? r.dy : r.dz) * nrm;
-                    constexpr float kD = (float)(1 << kDirBits);
-                    const uint32_t bu = (uint32_t)fminf(fmaxf((du * 0.5f + 0.5f) * kD, 0.f), kD - 1.f);
-                    const uint32_t bv = (uint32_t)fminf(fmaxf((dv * 0.5f + 0.5f) * kD, 0.f), kD - 1.f);
-                    key = (((face << kDirBits | bu) << kDirBits | bv) << (2 * kFaceBits)) | (key & ((1u << (2 * kFaceBits)) - 1u));
-                }
             }
         }
     }
