@@ -467,6 +467,26 @@ def _pack_tree_accel(tree: TreeSpec) -> _CTree:
 # forward 1.29 -> 1.05 ms; depth 8 / 66 MB, where the gather still hits the Infinity Cache,
 # forward+backward 955 -> 972 Mrays/s with the rebuild inside the step.)
 _SIGMA_CACHE: dict = {}
+_FEATURES_HELD = [0]      # > 0: inside features_held()
+
+
+class features_held:
+    """`with features_held():` -- the caller promises that no feature tensor changes inside the block (several cameras
+    rendered from one feature state: parallel.render_cameras).  What this module derives from the CONTENT of a feature
+    tensor -- the sigma bitmask, the exponentials table of rows of 8 / 16 / 32 floats -- is then built once per tensor
+    instead of once per forward (eight cameras at 1024 x 1024 / depth 9 / K = 32: seven passes of 0.18 ms and seven
+    tables of 578 MiB less); everything built inside is dropped when the outermost block ends."""
+
+    def __enter__(self):
+        _FEATURES_HELD[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _FEATURES_HELD[0] -= 1
+        if _FEATURES_HELD[0] == 0:
+            for k in [k for k, v in _SIGMA_CACHE.items() if len(v) > 5 and v[5]]:
+                _SIGMA_CACHE.pop(k, None)
+        return False
 
 
 def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool, table: bool = False, begin=None):
@@ -481,7 +501,8 @@ def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool, ta
     table = bool(table and EXP_TABLE and f.dim() == 2 and f.is_contiguous() and f.dtype == torch.float32)
     key = id(f)
     mask = etab = None
-    keep = keep and bool(getattr(tree, "static_features", False))
+    held = _FEATURES_HELD[0] > 0
+    keep = (keep and bool(getattr(tree, "static_features", False))) or held
     if keep:
         ent = _SIGMA_CACHE.get(key)
         if ent is not None and ent[0]() is f and ent[1] == (f._version, f.data_ptr()) and ent[2] == thresh \
@@ -502,7 +523,7 @@ def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool, ta
                 _call("svoxt_sigma_mask_build", ctypes.byref(ct), ctypes.c_float(thresh), _ptr(mask), _stream(dev))
         if keep:
             _SIGMA_CACHE[key] = (weakref.ref(f, lambda _r, _k=key: _SIGMA_CACHE.pop(_k, None)),
-                                 (f._version, f.data_ptr()), thresh, mask, etab)
+                                 (f._version, f.data_ptr()), thresh, mask, etab, held)
     ct.sigma_mask = mask.data_ptr()
     ct.sigma_mask_thresh = thresh
     ct._keepalive_mask = mask

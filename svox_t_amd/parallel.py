@@ -137,6 +137,14 @@ def render_sharded(renderer_or_fn, features: torch.Tensor, rays,
     return _ShardedRender.apply(features, fn, rays, group, image_shape)
 
 
+def _held():
+    """csrc.features_held() where the operator layer is loaded (a rank's cameras share one feature state), else nothing."""
+    import contextlib
+    import sys
+    mod = sys.modules.get("svox_t_amd.csrc")
+    return mod.features_held() if mod is not None and hasattr(mod, "features_held") else contextlib.nullcontext()
+
+
 class _CameraSet(autograd.Function):
     """features -> [n_cam, H, W, C+1]: camera i is rendered by rank i % world
     (image mode: the kernels generate the rays, nothing but the pose travels);
@@ -148,7 +156,8 @@ class _CameraSet(autograd.Function):
         n_cam = c2ws.shape[0]
         mine = list(range(rank, n_cam, world))
         per_rank = (n_cam + world - 1) // world
-        with torch.enable_grad():
+        with torch.enable_grad(), _held():
+            # (one feature state for all of this rank's cameras: its sigma bitmask / exponentials table are built once)
             feats = features.detach().requires_grad_(True)
             local = [render_fn(feats, c2ws[i]) for i in mine]
         ctx.feats, ctx.local, ctx.group, ctx.mine = feats, local, group, mine
