@@ -73,12 +73,41 @@ struct RaysDev {
 // iterations, better cache reuse, more gradient rows merged before the
 // atomics).  Only the assignment of rays to lanes changes; every ray's result
 // is the same and is written at the ray's own index.
+#ifndef SVOXT_SUPER_TILE
+#define SVOXT_SUPER_TILE 8
+#endif
 __device__ __forceinline__ int64_t ray_of_thread(const RaysDev& rays, int64_t tid) {
     if (rays.order != nullptr) return tid < rays.Q ? (int64_t)rays.order[tid] : rays.Q;
     if (rays.tiles_per_row <= 0) return tid;
     const int64_t tile = tid >> 6;
     const int within = (int)(tid & 63);
-    const int64_t ty = tile / rays.tiles_per_row, tx = tile - ty * rays.tiles_per_row;
+    int64_t ty = tile / rays.tiles_per_row, tx = tile - ty * rays.tiles_per_row;
+    if constexpr (SVOXT_SUPER_TILE > 0) {
+        // (r04) The tiles are walked in SUPER-TILES of S x S tiles (64 x 64 pixels), row-major inside and between them,
+        // the last column / row of super-tiles as narrow / low as the image leaves them: workgroups that are resident
+        // together then render a few compact patches of the image instead of a band eight pixels high across all of
+        // it, and what they gather and add to lies close together.  1024 x 1024 / depth 9 / K = 32 (the tree's 578 MiB
+        // of features do not fit the caches): forward+backward 2.64 -> 2.40 ms (exp/tile_order_probe.py); 800 x 800 /
+        // depth 8, which fits: unchanged.  A tile is the same 8 x 8 pixels as before; only which launch index has it changes.
+        constexpr int S = SVOXT_SUPER_TILE;
+        const int T = rays.tiles_per_row;
+        const int TR = (int)((rays.Q >> 6) / T);                 // tile rows (an image: Q = 64 T TR)
+        const int t = (int)tile;
+        if (t < T * TR) {
+            const int srow = t / (S * T), u = t - srow * S * T;
+            const int h = min(S, TR - srow * S);                 // tile rows of this row of super-tiles
+            const int full = T / S, wl = T - full * S;           // full-width super-tiles per row, width of the last one
+            if (u < full * h * S) {
+                const int sc = u / (h * S), v = u - sc * h * S;
+                ty = srow * S + v / S;
+                tx = sc * S + v % S;
+            } else {
+                const int v = u - full * h * S;
+                ty = srow * S + v / wl;
+                tx = full * S + v % wl;
+            }
+        }
+    }
     return ((ty << 3) + (within >> 3)) * ((int64_t)rays.tiles_per_row << 3) + (tx << 3) + (within & 7);
 }
 
