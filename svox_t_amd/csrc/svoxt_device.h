@@ -63,6 +63,7 @@ struct RaysDev {
     float fx, fy;
     int width, height;
     const int32_t* __restrict__ order;   // != null: launch thread i works on ray order[i] (svoxt_rays.order)
+    int super_tiles;     // != 0 (images only): the 8 x 8 pixel tiles are walked in super-tiles (ray_of_thread)
 };
 
 // Which ray a thread works on.  By default thread i takes ray i (a wavefront =
@@ -82,13 +83,16 @@ __device__ __forceinline__ int64_t ray_of_thread(const RaysDev& rays, int64_t ti
     const int64_t tile = tid >> 6;
     const int within = (int)(tid & 63);
     int64_t ty = tile / rays.tiles_per_row, tx = tile - ty * rays.tiles_per_row;
-    if constexpr (SVOXT_SUPER_TILE > 0) {
+    if (SVOXT_SUPER_TILE > 0 && rays.super_tiles != 0) {
         // (r04) The tiles are walked in SUPER-TILES of S x S tiles (64 x 64 pixels), row-major inside and between them,
         // the last column / row of super-tiles as narrow / low as the image leaves them: workgroups that are resident
         // together then render a few compact patches of the image instead of a band eight pixels high across all of
         // it, and what they gather and add to lies close together.  1024 x 1024 / depth 9 / K = 32 (the tree's 578 MiB
-        // of features do not fit the caches): forward+backward 2.64 -> 2.40 ms (exp/tile_order_probe.py); 800 x 800 /
-        // depth 8, which fits: unchanged.  A tile is the same 8 x 8 pixels as before; only which launch index has it changes.
+        // of features do not fit the caches): forward+backward 2.64 -> 2.44 ms, the per-tile backward 1.55 -> 1.35;
+        // super-tiles of 4 / 16 tiles: 2.46 / 2.48.  800 x 800 / depth 8, whose 71 MiB fit the Infinity Cache, LOSES 1.7 %
+        // (its busy tiles -- one in three -- then come in clusters): the host sets super_tiles only for feature tables
+        // that do not fit (to_dev(rays, tree): a function of the tree's M and K alone, so that the forward that records
+        // lists and the backward that walks them agree).  A tile is the same 8 x 8 pixels either way.
         constexpr int S = SVOXT_SUPER_TILE;
         const int T = rays.tiles_per_row;
         const int TR = (int)((rays.Q >> 6) / T);                 // tile rows (an image: Q = 64 T TR)

@@ -140,7 +140,11 @@ TreeDev to_dev(const svoxt_tree* t) {
     return d;
 }
 
-RaysDev to_dev(const svoxt_rays* r) {
+// Feature tables above this size do not stay in the Infinity Cache (256 MiB, shared with lists and gradient): their
+// images are walked in super-tiles (RaysDev.super_tiles)
+constexpr int64_t kSuperTileBytes = (int64_t)128 << 20;
+
+RaysDev to_dev(const svoxt_rays* r, const svoxt_tree* t) {
     RaysDev d;
     d.origins = r->origins; d.dirs = r->dirs; d.vdirs = r->vdirs; d.Q = r->Q;
     // image hint: usable only if the batch is exactly a W x H image of 8x8 tiles
@@ -151,6 +155,7 @@ RaysDev to_dev(const svoxt_rays* r) {
     d.c2w = r->c2w; d.fx = r->fx; d.fy = r->fy;
     d.order = r->order;
     d.width = r->image_width; d.height = r->image_height;
+    d.super_tiles = (tiled && t != nullptr && t->M * (int64_t)t->K * (int64_t)sizeof(float) > kSuperTileBytes) ? 1 : 0;
     return d;
 }
 
@@ -577,7 +582,7 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
     hipStream_t st = (hipStream_t)stream;
     if (lists != nullptr && (rc = lists_begin(lists, rays->Q, st, fn))) return rc;
     const TreeDev tr = to_dev(tree);
-    const RaysDev rd = to_dev(rays);
+    const RaysDev rd = to_dev(rays, tree);
     const Opts od = to_dev(opt);
     const bool n2 = tree->N == 2;
     bool done = false;
@@ -817,8 +822,8 @@ int svoxt_opacity_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
     if (out == nullptr) return fail(SVOXT_ERR_INVALID, "%s: out is NULL", fn);
     hipStream_t st = (hipStream_t)stream;
     const unsigned nb = nblocks(rays->Q);
-    if (tree->N == 2) hipLaunchKernelGGL((opacity_fwd_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), out);
-    else hipLaunchKernelGGL((opacity_fwd_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), out);
+    if (tree->N == 2) hipLaunchKernelGGL((opacity_fwd_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays, tree), to_dev(opt), out);
+    else hipLaunchKernelGGL((opacity_fwd_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays, tree), to_dev(opt), out);
     return check_launch(fn);
 }
 
@@ -842,8 +847,8 @@ int svoxt_opacity_render_fwd_record(const svoxt_tree* tree, const svoxt_rays* ra
     if ((rc = lists_begin(lists, rays->Q, st, fn))) return rc;
     const RecLists L = lists_dev(lists, rays->Q);
     uint4* aux = reinterpret_cast<uint4*>(lists->aux);
-    if (tree->N == 2) hipLaunchKernelGGL((opacity_fwd_kernel<true, true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), out, L, aux);
-    else hipLaunchKernelGGL((opacity_fwd_kernel<false, true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), out, L, aux);
+    if (tree->N == 2) hipLaunchKernelGGL((opacity_fwd_kernel<true, true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays, tree), to_dev(opt), out, L, aux);
+    else hipLaunchKernelGGL((opacity_fwd_kernel<false, true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays, tree), to_dev(opt), out, L, aux);
     return check_launch(fn);
 }
 
@@ -865,7 +870,7 @@ int svoxt_opacity_render_bwd_replay(const svoxt_tree* tree, const svoxt_rays* ra
     }
     if (rays->Q == 0 || tree->M == 0) return SVOXT_OK;
     const unsigned nb = nblocks(rays->Q);
-    const RaysDev rd = to_dev(rays);
+    const RaysDev rd = to_dev(rays, tree);
     const RecLists L = lists_dev(lists, rays->Q);
     uint4* aux = reinterpret_cast<uint4*>(lists->aux);
     if (tree->N == 2) hipLaunchKernelGGL((opacity_walk_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), rd, to_dev(opt), grad_out, grad_features, gs, L, aux);
@@ -884,8 +889,8 @@ int svoxt_render_depth(const svoxt_tree* tree, const svoxt_rays* rays,
     if (depth == nullptr) return fail(SVOXT_ERR_INVALID, "%s: depth is NULL", fn);
     hipStream_t st = (hipStream_t)stream;
     const unsigned nb = nblocks(rays->Q);
-    if (tree->N == 2) hipLaunchKernelGGL((depth_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), depth);
-    else hipLaunchKernelGGL((depth_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), depth);
+    if (tree->N == 2) hipLaunchKernelGGL((depth_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays, tree), to_dev(opt), depth);
+    else hipLaunchKernelGGL((depth_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays, tree), to_dev(opt), depth);
     return check_launch(fn);
 }
 
@@ -939,8 +944,8 @@ int svoxt_count_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
     unsigned long long* c = reinterpret_cast<unsigned long long*>(counters);
     TreeDev tr = to_dev(tree);
     tr.accel = nullptr;   // the counters are the reference's: levels of the plain root descent
-    if (tree->N == 2) hipLaunchKernelGGL((count_fwd_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, to_dev(rays), to_dev(opt), c);
-    else hipLaunchKernelGGL((count_fwd_kernel<false>), dim3(nb), dim3(kBlock), 0, st, tr, to_dev(rays), to_dev(opt), c);
+    if (tree->N == 2) hipLaunchKernelGGL((count_fwd_kernel<true>), dim3(nb), dim3(kBlock), 0, st, tr, to_dev(rays, tree), to_dev(opt), c);
+    else hipLaunchKernelGGL((count_fwd_kernel<false>), dim3(nb), dim3(kBlock), 0, st, tr, to_dev(rays, tree), to_dev(opt), c);
     return check_launch(fn);
 }
 
@@ -957,8 +962,8 @@ int svoxt_count_touched(const svoxt_tree* tree, const svoxt_rays* rays, const sv
     const unsigned nb = nblocks(rays->Q);
     const uint32_t n_slots = (uint32_t)(tree->n_internal * tree->N * tree->N * tree->N);
     unsigned long long* lg = reinterpret_cast<unsigned long long*>(longest);
-    if (tree->N == 2) hipLaunchKernelGGL((count_touched_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), row_mask, tree_mask, n_slots, lg);
-    else hipLaunchKernelGGL((count_touched_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays), to_dev(opt), row_mask, tree_mask, n_slots, lg);
+    if (tree->N == 2) hipLaunchKernelGGL((count_touched_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays, tree), to_dev(opt), row_mask, tree_mask, n_slots, lg);
+    else hipLaunchKernelGGL((count_touched_kernel<false>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays, tree), to_dev(opt), row_mask, tree_mask, n_slots, lg);
     return check_launch(fn);
 }
 

@@ -435,10 +435,10 @@ int svoxt_motion_render(const svoxt_tree* tree, const svoxt_rays* rays, const sv
     const unsigned nb = blocks_of(rays->Q, kMotionBlock);
     if (tree->N == 2)
         hipLaunchKernelGGL((motion_render_kernel<true>), dim3(nb), dim3(kMotionBlock), 0, (hipStream_t)stream,
-                           tr, to_dev(rays), to_dev(opt), (int)tree->extra_rows, out, depth, hit_point, data_idx);
+                           tr, to_dev(rays, tree), to_dev(opt), (int)tree->extra_rows, out, depth, hit_point, data_idx);
     else
         hipLaunchKernelGGL((motion_render_kernel<false>), dim3(nb), dim3(kMotionBlock), 0, (hipStream_t)stream,
-                           tr, to_dev(rays), to_dev(opt), (int)tree->extra_rows, out, depth, hit_point, data_idx);
+                           tr, to_dev(rays, tree), to_dev(opt), (int)tree->extra_rows, out, depth, hit_point, data_idx);
     return check_launch(fn);
 }
 
@@ -471,7 +471,7 @@ int svoxt_motion_feature_render_fwd(const svoxt_tree* tree, const svoxt_motion* 
     hipStream_t st = (hipStream_t)stream;
     const TreeDev tr = to_dev(tree);
     const MotionDev mo = to_dev(motion);
-    const RaysDev rd = to_dev(rays);
+    const RaysDev rd = to_dev(rays, tree);
     const Opts od = to_dev(opt);
     const int F = motion->feature_dim;
     const unsigned nb = blocks_of(rays->Q, kMotionBlock);
@@ -507,7 +507,7 @@ int svoxt_motion_feature_render_bwd(const svoxt_tree* tree, const svoxt_motion* 
     if (e != hipSuccess) return set_error(SVOXT_ERR_HIP, "%s: %s", fn, hipGetErrorString(e));
     const TreeDev tr = to_dev(tree);
     const MotionDev mo = to_dev(motion);
-    const RaysDev rd = to_dev(rays);
+    const RaysDev rd = to_dev(rays, tree);
     const Opts od = to_dev(opt);
     const unsigned nb = blocks_of(rays->Q, kMotionBlock);
     const unsigned nbm = blocks_of(tree->M, 256);

@@ -201,7 +201,7 @@ int svoxt_ray_order(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_
     if (e != hipSuccess) return set_error(SVOXT_ERR_HIP, "%s: hipMemsetAsync: %s", fn, hipGetErrorString(e));
     TreeDev tr = to_dev(tree);
     const unsigned nb = (unsigned)((n + kOrderBlock - 1) / kOrderBlock);
-    hipLaunchKernelGGL(ray_key_kernel, dim3(nb), dim3(kOrderBlock), 0, st, tr, to_dev(rays), to_dev(opt), keys, ranks, counts);
+    hipLaunchKernelGGL(ray_key_kernel, dim3(nb), dim3(kOrderBlock), 0, st, tr, to_dev(rays, tree), to_dev(opt), keys, ranks, counts);
     if ((rc = check_launch(fn))) return rc;
     e = rocprim::exclusive_scan(temp, temp_bytes, counts, starts, 0u, kOrderCells, rocprim::plus<uint32_t>(), st);
     if (e != hipSuccess) return set_error(SVOXT_ERR_HIP, "%s: scan: %s", fn, hipGetErrorString(e));
@@ -219,7 +219,7 @@ int svoxt_gather_rays(const svoxt_rays* rays, const int32_t* perm, float* origin
         return set_error(SVOXT_ERR_INVALID, "%s: NULL argument", fn);
     const int64_t n = rays->Q * 3;
     hipLaunchKernelGGL(gather_rays_kernel, dim3((unsigned)((n + kOrderBlock - 1) / kOrderBlock)), dim3(kOrderBlock), 0,
-                       (hipStream_t)stream, to_dev(rays), perm, origins, dirs, vdirs);
+                       (hipStream_t)stream, to_dev(rays, nullptr), perm, origins, dirs, vdirs);
     return check_launch(fn);
 }
 

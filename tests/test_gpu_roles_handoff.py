@@ -24,23 +24,14 @@ pytestmark = pytest.mark.gpu
 
 
 def _ray_of(tiles, shape, Q, dev):
-    """[tiles, 64] ray index of (tile, lane) -- ray_of_thread of svoxt_device.h -- or -1 past the batch."""
+    """[tiles, 64] ray index of (tile, lane) -- ray_of_thread of svoxt_device.h -- or -1 past the batch.  (Row-major
+    tile order: the cases of this file have feature tables that fit the Infinity Cache; larger ones walk their tiles
+    in super-tiles: RaysDev.super_tiles.)"""
     t = torch.arange(tiles, device=dev)[:, None]
     lane = torch.arange(64, device=dev)[None, :]
     if shape is not None and shape[0] % 8 == 0 and shape[1] % 8 == 0 and shape[0] * shape[1] == Q:
         H, W = shape
-        T, TR, S = W // 8, H // 8, 8                       # tiles per row, tile rows, tiles per side of a super-tile
-        srow = t // (S * T)
-        u = t - srow * S * T
-        h = torch.clamp(TR - srow * S, max=S)
-        full, wl = T // S, T - (T // S) * S
-        in_full = u < full * h * S
-        sc = u // (h * S)
-        v = u - sc * h * S
-        v2 = u - full * h * S
-        ty = torch.where(in_full, srow * S + v // S, srow * S + v2 // max(wl, 1))
-        tx = torch.where(in_full, sc * S + v % S, full * S + v2 % max(wl, 1))
-        q = (ty * 8 + lane // 8) * W + tx * 8 + lane % 8
+        q = ((t // (W // 8)) * 8 + lane // 8) * W + (t % (W // 8)) * 8 + lane % 8
     else:
         q = t * 64 + lane
     return torch.where(q < Q, q, torch.full_like(q, -1))
