@@ -117,7 +117,10 @@ typedef struct svoxt_rays {
     int64_t      Q;
     int32_t      image_width;    /* optional hint (no counterpart in the reference): if the batch is a   */
     int32_t      image_height;   /* row-major W x H image (Q == W*H, both multiples of 8) the kernels walk
-                                    it in 8x8 pixel tiles; 0 = no hint.  Results do not depend on it. */
+                                    it in 8x8 pixel tiles -- row-major, or in super-tiles of 8 x 8 tiles where the
+                                    tree's feature table exceeds 128 MiB (a rule of M and K alone: a forward that
+                                    records sample lists and the backward that walks them use the same walk);
+                                    0 = no hint.  Results do not depend on it. */
     const float* c2w;            /* camera mode when non-NULL: device camera-to-world matrix, rows of 4 floats
                                     ([3,4] or [4,4] contiguous).  Ray q is then pixel (q % image_width,
                                     q / image_width) of a pinhole camera, generated inside the kernels as
