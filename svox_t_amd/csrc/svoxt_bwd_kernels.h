@@ -16,6 +16,9 @@
 #ifndef SVOXT_WIDE_STAGE_ROWS
 #define SVOXT_WIDE_STAGE_ROWS 2          // rows per lane and stage of grad_wide_kernel's reduce (1: 1.59 ms, 2: 1.55, 3: 1.77, 4: 1.82 backward)
 #endif
+#ifndef SVOXT_WIDE_XCD_ROWS
+#define SVOXT_WIDE_XCD_ROWS 1
+#endif
 #ifndef SVOXT_WIDE_ETAB_WAVES
 #define SVOXT_WIDE_ETAB_WAVES 8          // wavefronts per SIMD the table instance of grad_wide_kernel is compiled for (8: four workgroups per CU)
 #endif
@@ -1313,7 +1316,13 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
     static_assert(K == 8 || K == 16 || K == 32, "row widths with an instance");
     static_assert(!(ETAB && FAST), "the table holds the exact exponentials");
     const float* __restrict__ const rows = ETAB ? tr.etab : tr.features;
-    if (tile_never_recorded(L, blockIdx.x)) return;          // (r03: before anything else is requested)
+    // (r04) Which tile: workgroup b runs on XCD b mod 8; of every 64 consecutive tiles -- a super-tile when the image is
+    // walked in super-tiles, else 64 neighbours of a tile row -- XCD x takes tiles 8 x .. 8 x + 7, eight neighbours in a
+    // row behind ONE L2, instead of every eighth tile (SVOXT_WIDE_XCD_ROWS 0: tile = workgroup)
+    unsigned wtile = blockIdx.x;
+    if (SVOXT_WIDE_XCD_ROWS != 0 && (blockIdx.x | 63u) < gridDim.x)
+        wtile = (blockIdx.x & ~63u) | ((blockIdx.x & 7u) << 3) | ((blockIdx.x >> 3) & 7u);
+    if (tile_never_recorded(L, wtile)) return;               // (r03: before anything else is requested)
 #define SVOXT_CHK(i, n, site) chk<CHECK>(i, n, counters, site)
     constexpr int C = K - 1, W = 8, NT = 64 * W, T = 1024, R = 1024, RPP = R / (64 * W);
     constexpr int KG = K | 1;                                // odd stride: conflict-free gradient rows
@@ -1332,8 +1341,8 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
     __shared__ int32_t s_nb, s_ns;
     float2* __restrict__ tot2 = reinterpret_cast<float2*>(L.terms);      // (attenuation, second-pass total_color) per record
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int32_t tabreg = rec_tab_reg(L, blockIdx.x, lane);
-    const int64_t q = ray_of_thread(rays, (int64_t)blockIdx.x * 64 + lane);
+    const int32_t tabreg = rec_tab_reg(L, wtile, lane);
+    const int64_t q = ray_of_thread(rays, (int64_t)wtile * 64 + lane);
     uint4 a = make_uint4(0u, 0u, 0u, 0u);
     if (q < rays.Q) a = aux[q];
     const int nrec = (int)(a.x & ~kRecOverflow);
@@ -1370,7 +1379,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                 const int k = k0 + rd * W + wave;
                 have[rd] = k < nrec;
                 e[rd] = make_uint2(0u, 0u);
-                if (have[rd]) e[rd] = rec_get(L.rec + rec_index_in(SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 16), lane, k));
+                if (have[rd]) e[rd] = rec_get(L.rec + rec_index_in(SVOXT_CHK(rec_block_u(L, tabreg, wtile, k >> 3), L.pool_blocks, 16), lane, k));
             }
 #pragma unroll
             for (int rd = 0; rd < RPP; ++rd) {
@@ -1495,7 +1504,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
         for (int rd = 0; rd < RPP; ++rd) {
             const int k = k0 + rd * W + wave;
             if (k < nrec) {
-                const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 16);
+                const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, wtile, k >> 3), L.pool_blocks, 16);
                 const int sl = (rd * W + wave) * 64 + lane;
                 tot2[terms_index_pm(blk, lane, k)] = make_float2(r_w[sl], r_sg[sl]);
             }
@@ -1549,7 +1558,7 @@ grad_wide_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ g
                 e[rd] = make_uint2(0u, 0u);
                 h[rd] = make_float2(0.f, 0.f);
                 if (have[rd]) {
-                    const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, blockIdx.x, k >> 3), L.pool_blocks, 16);
+                    const int64_t blk = SVOXT_CHK(rec_block_u(L, tabreg, wtile, k >> 3), L.pool_blocks, 16);
                     e[rd] = rec_get(L.rec + rec_index_in(blk, lane, k));
                     h[rd] = tot2[terms_index_pm(blk, lane, k)];
                 }
