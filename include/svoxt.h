@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 18
+#define SVOXT_ABI_VERSION 19
 
 enum {
     SVOXT_OK = 0,
@@ -462,6 +462,11 @@ int svoxt_set_bwd_counters(int64_t* counters);
  * instances worked on (0: the route taken has no checked instance).  Results are those of the production
  * instances.  Process-wide; meant for tests (the memory fault of round 3). */
 int svoxt_set_bwd_check(int64_t* words);
+/* (ABI v19) Images of trees whose feature table (M * K * 4 bytes) exceeds `bytes` are walked in super-tiles of 8 x 8
+ * tiles instead of row-major (svoxt_rays.image_width); default 128 MiB; < 0 restores the default.  Process-wide; a
+ * forward that records sample lists and the backward that walks them must run under the same value (tests use 0 to
+ * exercise the super-tile walk on small, ragged images).  Returns the value in force before the call. */
+int64_t svoxt_set_super_tile_bytes(int64_t bytes);
 
 /* Acceleration grid (no counterpart in the reference).  A 2^g x 2^g x 2^g table
  * that caches, per cell, where the root->leaf descent of common.cuh:63-100

@@ -143,6 +143,7 @@ TreeDev to_dev(const svoxt_tree* t) {
 // Feature tables above this size do not stay in the Infinity Cache (256 MiB, shared with lists and gradient): their
 // images are walked in super-tiles (RaysDev.super_tiles)
 constexpr int64_t kSuperTileBytes = (int64_t)128 << 20;
+static int64_t g_super_tile_bytes = kSuperTileBytes;      // svoxt_set_super_tile_bytes
 
 RaysDev to_dev(const svoxt_rays* r, const svoxt_tree* t) {
     RaysDev d;
@@ -155,7 +156,7 @@ RaysDev to_dev(const svoxt_rays* r, const svoxt_tree* t) {
     d.c2w = r->c2w; d.fx = r->fx; d.fy = r->fy;
     d.order = r->order;
     d.width = r->image_width; d.height = r->image_height;
-    d.super_tiles = (tiled && t != nullptr && t->M * (int64_t)t->K * (int64_t)sizeof(float) > kSuperTileBytes) ? 1 : 0;
+    d.super_tiles = (tiled && t != nullptr && t->M * (int64_t)t->K * (int64_t)sizeof(float) > g_super_tile_bytes) ? 1 : 0;
     return d;
 }
 
@@ -517,6 +518,12 @@ bool launch_fwd_split(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
 extern "C" {
 
 int svoxt_abi_version(void) { return SVOXT_ABI_VERSION; }
+
+int64_t svoxt_set_super_tile_bytes(int64_t bytes) {
+    const int64_t before = g_super_tile_bytes;
+    g_super_tile_bytes = bytes < 0 ? kSuperTileBytes : bytes;
+    return before;
+}
 
 const char* svoxt_last_error(void) { return g_err; }
 
