@@ -118,7 +118,7 @@ typedef struct svoxt_rays {
     int32_t      image_width;    /* optional hint (no counterpart in the reference): if the batch is a   */
     int32_t      image_height;   /* row-major W x H image (Q == W*H, both multiples of 8) the kernels walk
                                     it in 8x8 pixel tiles -- row-major, or in super-tiles of 8 x 8 tiles where the
-                                    tree's feature table exceeds 128 MiB (a rule of M and K alone: a forward that
+                                    tree has more than 2^21 feature rows (a rule of M alone: a forward that
                                     records sample lists and the backward that walks them use the same walk);
                                     0 = no hint.  Results do not depend on it. */
     const float* c2w;            /* camera mode when non-NULL: device camera-to-world matrix, rows of 4 floats
@@ -462,11 +462,11 @@ int svoxt_set_bwd_counters(int64_t* counters);
  * instances worked on (0: the route taken has no checked instance).  Results are those of the production
  * instances.  Process-wide; meant for tests (the memory fault of round 3). */
 int svoxt_set_bwd_check(int64_t* words);
-/* (ABI v19) Images of trees whose feature table (M * K * 4 bytes) exceeds `bytes` are walked in super-tiles of 8 x 8
- * tiles instead of row-major (svoxt_rays.image_width); default 128 MiB; < 0 restores the default.  Process-wide; a
- * forward that records sample lists and the backward that walks them must run under the same value (tests use 0 to
- * exercise the super-tile walk on small, ragged images).  Returns the value in force before the call. */
-int64_t svoxt_set_super_tile_bytes(int64_t bytes);
+/* (ABI v19) Images of trees with more than `rows` feature rows (M) are walked in super-tiles of 8 x 8 tiles instead of
+ * row-major (svoxt_rays.image_width); default 2^21 rows; < 0 restores the default.  Process-wide; a forward that
+ * records sample lists and the backward that walks them must run under the same value (tests use 0 to exercise the
+ * super-tile walk on small, ragged images).  Returns the value in force before the call. */
+int64_t svoxt_set_super_tile_rows(int64_t rows);
 
 /* Acceleration grid (no counterpart in the reference).  A 2^g x 2^g x 2^g table
  * that caches, per cell, where the root->leaf descent of common.cuh:63-100

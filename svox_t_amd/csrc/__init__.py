@@ -141,7 +141,7 @@ EXPORTS = {
     "svoxt_count_touched": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp, _vp]),
     "svoxt_set_bwd_counters": (ctypes.c_int, [_vp]),
     "svoxt_set_bwd_check": (ctypes.c_int, [_vp]),
-    "svoxt_set_super_tile_bytes": (_i64, [_i64]),
+    "svoxt_set_super_tile_rows": (_i64, [_i64]),
     "svoxt_ray_order_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "svoxt_ray_order": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, ctypes.c_int64, _vp]),
     "svoxt_gather_rays": (ctypes.c_int, [_P(_CRays), _vp, _vp, _vp, _vp, _vp]),

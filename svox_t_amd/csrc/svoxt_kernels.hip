@@ -140,10 +140,12 @@ TreeDev to_dev(const svoxt_tree* t) {
     return d;
 }
 
-// Feature tables above this size do not stay in the Infinity Cache (256 MiB, shared with lists and gradient): their
-// images are walked in super-tiles (RaysDev.super_tiles)
-constexpr int64_t kSuperTileBytes = (int64_t)128 << 20;
-static int64_t g_super_tile_bytes = kSuperTileBytes;      // svoxt_set_super_tile_bytes
+// Images of trees with more feature rows than this are walked in super-tiles (RaysDev.super_tiles).  The rule is the
+// TREE'S size, not its features' bytes (measured r04, forward+backward, row-major -> super-tiles): depth 9 (4.7 M rows) at
+// 1024 x 1024: K = 32 2.63 -> 2.40 ms, SH9 1.99 -> 1.71, K = 4 (72 MiB of features!) 1.15 -> 0.95; at 800 x 800 unchanged
+// (+-0.5 %); depth 8 (0.67 M rows): SH9 800 x 800 +1.7 %, K = 32 800 x 800 +6 %, SH9 1600 x 1600 +1 % -- never a gain.
+constexpr int64_t kSuperTileRows = (int64_t)1 << 21;
+static int64_t g_super_tile_rows = kSuperTileRows;        // svoxt_set_super_tile_rows
 
 RaysDev to_dev(const svoxt_rays* r, const svoxt_tree* t) {
     RaysDev d;
@@ -156,7 +158,7 @@ RaysDev to_dev(const svoxt_rays* r, const svoxt_tree* t) {
     d.c2w = r->c2w; d.fx = r->fx; d.fy = r->fy;
     d.order = r->order;
     d.width = r->image_width; d.height = r->image_height;
-    d.super_tiles = (tiled && t != nullptr && t->M * (int64_t)t->K * (int64_t)sizeof(float) > g_super_tile_bytes) ? 1 : 0;
+    d.super_tiles = (tiled && t != nullptr && t->M > g_super_tile_rows) ? 1 : 0;
     return d;
 }
 
@@ -519,9 +521,9 @@ extern "C" {
 
 int svoxt_abi_version(void) { return SVOXT_ABI_VERSION; }
 
-int64_t svoxt_set_super_tile_bytes(int64_t bytes) {
-    const int64_t before = g_super_tile_bytes;
-    g_super_tile_bytes = bytes < 0 ? kSuperTileBytes : bytes;
+int64_t svoxt_set_super_tile_rows(int64_t rows) {
+    const int64_t before = g_super_tile_rows;
+    g_super_tile_rows = rows < 0 ? kSuperTileRows : rows;
     return before;
 }
 

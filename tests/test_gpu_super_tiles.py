@@ -1,5 +1,5 @@
-"""The super-tile walk of image batches (svoxt_set_super_tile_bytes): which launch tile renders
-which 8 x 8 pixels changes, nothing a caller sees may.  The library switches it on for feature tables above 128 MiB
+"""The super-tile walk of image batches (svoxt_set_super_tile_rows): which launch tile renders
+which 8 x 8 pixels changes, nothing a caller sees may.  The library switches it on for trees of more than 2^21 feature rows
 only -- config 4's full-size tests run under it -- so here the threshold is set to 0 and small images whose tile grid
 is ragged against the 8 x 8 tiles of a super-tile (25 x 9, 8 x 8, 3 x 17 tiles) go through every image route."""
 import numpy as np
@@ -17,9 +17,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def super_tiles_everywhere():
-    before = _C._lib.svoxt_set_super_tile_bytes(0)
+    before = _C._lib.svoxt_set_super_tile_rows(0)
     yield
-    _C._lib.svoxt_set_super_tile_bytes(before)
+    _C._lib.svoxt_set_super_tile_rows(before)
 
 
 @pytest.mark.parametrize("fmt,K,depth,W,H", [("SH9", 28, 6, 200, 72), ("RGBA", 4, 5, 64, 64), ("SH4", 13, 6, 24, 136),
@@ -46,4 +46,4 @@ def test_super_tile_walk_changes_nothing(gpu, super_tiles_everywhere, fmt, K, de
         np.testing.assert_array_equal(r.opacity_render(tree.features, rays, image_shape=(H, W)).cpu().numpy(),
                                       O.opacity_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts()))
     # the setter reports what was in force
-    assert _C._lib.svoxt_set_super_tile_bytes(0) == 0
+    assert _C._lib.svoxt_set_super_tile_rows(0) == 0
