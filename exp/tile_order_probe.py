@@ -13,7 +13,7 @@ def morton2(x, y, bits=8):
         r |= ((x >> b) & 1) << (2 * b + 1)
         r |= ((y >> b) & 1) << (2 * b)
     return r
-for kw, size in ((dict(depth=9, K=32, data_format="RGBA"), 1024), (dict(depth=8, K=28, data_format="SH9"), 800)):
+for kw, size in ((dict(depth=9, K=32, data_format="RGBA"), 1024),):
     c = Case(width=size, height=size, **kw)
     tree = c.tree(dev); r = svox.VolumeRenderer(tree); rays = c.rays_gpu(dev)
     f = tree.features.detach().clone().requires_grad_(True)
@@ -28,7 +28,10 @@ for kw, size in ((dict(depth=9, K=32, data_format="RGBA"), 1024), (dict(depth=8,
         q = ((tyy[:, None] * 8 + wy.reshape(-1)[None, :]) * size + txx[:, None] * 8 + wx.reshape(-1)[None, :])
         return q.reshape(-1).to(torch.int32).to(dev)
     variants = {"row-major tiles (rays.order)": perm_for(ty * T + tx), "Morton tiles (rays.order)": perm_for(morton2(tx, ty)),
-                "tiles in 8x8 super-tiles": perm_for(((ty // 8) * (T // 8 + 1) + tx // 8) * 64 + (ty % 8) * 8 + tx % 8)}
+                "tiles in 8x8 super-tiles": perm_for(((ty // 8) * (T // 8 + 1) + tx // 8) * 64 + (ty % 8) * 8 + tx % 8),
+                "super-tiles in Morton order": perm_for(morton2(tx // 8, ty // 8) * 64 + (ty % 8) * 8 + tx % 8),
+                "super-tiles in 4x4 blocks": perm_for((((ty // 32) * (T // 32 + 1) + tx // 32) * 16 + ((ty // 8) % 4) * 4 + (tx // 8) % 4) * 64 + (ty % 8) * 8 + tx % 8),
+                "super-tiles in 2x2 blocks": perm_for((((ty // 16) * (T // 16 + 1) + tx // 16) * 4 + ((ty // 8) % 2) * 2 + (tx // 8) % 2) * 64 + (ty % 8) * 8 + tx % 8)}
     def run(rs):
         def step():
             out, lists = _C.volume_render(spec, rs, opt, record=True)

@@ -64,6 +64,9 @@ struct RaysDev {
     int width, height;
     const int32_t* __restrict__ order;   // != null: launch thread i works on ray order[i] (svoxt_rays.order)
     int super_tiles;     // != 0 (images only): the 8 x 8 pixel tiles are walked in super-tiles (ray_of_thread)
+    int tile_rows;       // super_tiles: rows of tiles (H / 8) ...
+    float inv_st;        // ... and 1 / (8 tiles_per_row): the walk's one division by a number that is not a power of two
+    float inv_t;         // images of fewer than 2^22 tiles: 1 / tiles_per_row (else 0: ray_of_thread divides)
 };
 
 // Which ray a thread works on.  By default thread i takes ray i (a wavefront =
@@ -82,7 +85,15 @@ __device__ __forceinline__ int64_t ray_of_thread(const RaysDev& rays, int64_t ti
     if (rays.tiles_per_row <= 0) return tid;
     const int64_t tile = tid >> 6;
     const int within = (int)(tid & 63);
-    int64_t ty = tile / rays.tiles_per_row, tx = tile - ty * rays.tiles_per_row;
+    int64_t ty, tx;
+    if (rays.inv_t != 0.f) {                                     // (a 64-bit division per thread of every image kernel otherwise)
+        const int t32 = (int)tile, T = rays.tiles_per_row;
+        int y = (int)((float)t32 * rays.inv_t), x = t32 - y * T;
+        if (x < 0) { --y; x += T; } else if (x >= T) { ++y; x -= T; }
+        ty = y; tx = x;
+    } else {
+        ty = tile / rays.tiles_per_row; tx = tile - ty * rays.tiles_per_row;
+    }
     if (SVOXT_SUPER_TILE > 0 && rays.super_tiles != 0) {
         // (r04) The tiles are walked in SUPER-TILES of S x S tiles (64 x 64 pixels), row-major inside and between them,
         // the last column / row of super-tiles as narrow / low as the image leaves them: workgroups that are resident
@@ -93,18 +104,28 @@ __device__ __forceinline__ int64_t ray_of_thread(const RaysDev& rays, int64_t ti
         // (its busy tiles -- one in three -- then come in clusters): the host sets super_tiles only for feature tables
         // that do not fit (to_dev(rays, tree): a function of the tree's M and K alone, so that the forward that records
         // lists and the backward that walks them agree).  A tile is the same 8 x 8 pixels either way.
+        // (every thread of every image kernel comes through here -- the 32 channel lanes of a ray in shade_chan_kernel
+        // each -- so: the division by 8 T as a multiplication by the host's reciprocal with a correction, shifts and masks
+        // inside a full super-tile, real divisions only in the last, ragged row and column of super-tiles.  With four
+        // plain divisions the shade kernel of config 4 lost 0.03 ms to this mapping alone.)
         constexpr int S = SVOXT_SUPER_TILE;
-        const int T = rays.tiles_per_row;
-        const int TR = (int)((rays.Q >> 6) / T);                 // tile rows (an image: Q = 64 T TR)
+        static_assert(S == 8 || S == 0, "the shifts below");
+        const int T = rays.tiles_per_row, TR = rays.tile_rows, ST = S * T;
         const int t = (int)tile;
         if (t < T * TR) {
-            const int srow = t / (S * T), u = t - srow * S * T;
+            int srow = (int)((float)t * rays.inv_st);            // t < 2^22 (the host's condition): off by one at most
+            int u = t - srow * ST;
+            if (u < 0) { --srow; u += ST; } else if (u >= ST) { ++srow; u -= ST; }
             const int h = min(S, TR - srow * S);                 // tile rows of this row of super-tiles
-            const int full = T / S, wl = T - full * S;           // full-width super-tiles per row, width of the last one
-            if (u < full * h * S) {
+            const int full = T >> 3, wl = T & 7;                 // full-width super-tiles per row, width of the last one
+            if (h == S && u < full * (S * S)) {                  // inside a full super-tile: the common case
+                const int v = u & (S * S - 1);
+                ty = srow * S + (v >> 3);
+                tx = (u >> 6) * S + (v & 7);
+            } else if (u < full * h * S) {
                 const int sc = u / (h * S), v = u - sc * h * S;
-                ty = srow * S + v / S;
-                tx = sc * S + v % S;
+                ty = srow * S + (v >> 3);
+                tx = sc * S + (v & 7);
             } else {
                 const int v = u - full * h * S;
                 ty = srow * S + v / wl;

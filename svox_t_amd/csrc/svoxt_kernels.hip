@@ -158,7 +158,10 @@ RaysDev to_dev(const svoxt_rays* r, const svoxt_tree* t) {
     d.c2w = r->c2w; d.fx = r->fx; d.fy = r->fy;
     d.order = r->order;
     d.width = r->image_width; d.height = r->image_height;
-    d.super_tiles = (tiled && t != nullptr && t->M > g_super_tile_rows) ? 1 : 0;
+    d.super_tiles = (tiled && t != nullptr && t->M > g_super_tile_rows && r->Q < ((int64_t)1 << 28)) ? 1 : 0;   // (tiles < 2^22: inv_st)
+    d.tile_rows = tiled ? r->image_height / 8 : 0;
+    d.inv_st = tiled ? 1.0f / (8.0f * (float)d.tiles_per_row) : 0.f;
+    d.inv_t = (tiled && r->Q < ((int64_t)1 << 28)) ? 1.0f / (float)d.tiles_per_row : 0.f;
     return d;
 }
 
