@@ -57,8 +57,50 @@ WORKLOADS = {
 }
 
 
-ROUND = "r04"        # which round's committed profiles the line quotes (profiles/<ROUND>_*)
-PREWARM_STEPS = 30   # untimed, before the --warmup steps: printed in the line
+ROUND = "r05"        # which round's committed profiles the line quotes (profiles/<ROUND>_*)
+# Untimed steps before the --warmup steps the contract asks for: full steps (forward AND backward) for at least
+# PREWARM_MIN_S of wall time and until the last PREWARM_WINDOW forward and backward event intervals each lie within
+# PREWARM_TOL of their median, at most PREWARM_MAX_S.  (r04: a fixed count of 30 + 5 steps, ~25 ms of GPU work, left
+# the first process on a fresh box with backwards at 0.41-0.45 ms against 0.26 ms in steady state -- BENCH_r04.json,
+# gpurun_out/r4b/bench_d8_1.json vs _2.json: the memory side of a cold device; BASELINE.md "fresh box".)
+PREWARM_MIN_S, PREWARM_MAX_S, PREWARM_WINDOW, PREWARM_TOL, PREWARM_BATCH = 0.5, 3.0, 10, 0.05, 20
+
+
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return 0.0 if n == 0 else (xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2]))
+
+
+def _spread(xs):
+    """{min, median, max, mean} of a list of milliseconds."""
+    return {"min": round(min(xs), 4), "median": round(_median(xs), 4), "max": round(max(xs), 4),
+            "mean": round(sum(xs) / len(xs), 4)} if xs else None
+
+
+def self_launch(args, argv):
+    """`python3 bench.py --gpus N` as typed (no WORLD_SIZE in the environment): start the N ranks as CHILD processes --
+    `python3 -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    ...`, exactly the command the driver would have typed -- before this process has made any GPU call (a process
+    that has initialised the GPU must never be replaced), relay rank 0's one JSON line and the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (dmabuf IPC: what RCCL needs on this pool)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and ln.rstrip().endswith("}")]
+    for ln in p.stdout.splitlines():
+        if ln not in lines[-1:]:
+            print(ln, file=sys.stderr)                    # (whatever else the ranks wrote to stdout: not the contract's line)
+    if lines:
+        print(lines[-1], flush=True)
+    return p.returncode if (p.returncode or lines) else 1
 
 
 def kernel_stats_ms(workload, forward_only):
@@ -110,7 +152,7 @@ def reference_equivalent_bytes(cnt, Q, M, K, C):
     return fwd, bwd
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -128,15 +170,19 @@ def main():
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--exchange", default="auto", choices=["auto", "all_reduce", "direct"],
                     help="N > 1: the gradient all-reduce (auto: both are timed on a gradient-sized buffer first, the faster is used)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: rehearse launch, rendezvous, pixel gather, gradient exchange, timing and the JSON line on CPU "
+                         "tensors over gloo with a stand-in for the renderer (tests/test_bench_launch.py); the number means nothing")
+    args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, sys.argv[1:] if argv is None else argv)       # (before anything touches the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world                     # (under a launcher the launcher's world size is the truth)
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if args.share_device:
@@ -253,10 +299,13 @@ def main():
     reducer = parallel.OverlappedGradReducer(dist, backend=args.backend, mode=exchange["used"] if exchange else "all_reduce") \
         if dist is not None else None
     gathered = torch.empty((world * Q, C + 1), dtype=torch.float32, device=dev) if dist is not None else None
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    def new_events(n):
+        return [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
 
-    def step(i=None, route=args.route, accumulate=False):
-        e = ev[i] if i is not None else None
+    ev = new_events(args.steps)
+
+    def step(i=None, route=args.route, accumulate=False, events=None):
+        e = (events if events is not None else ev)[i] if i is not None else None
         features.grad = None              # (a gradient still travelling is held by the reducer)
         # (two events per step, not three: a step's forward starts where the step before ended -- its last event; each
         # record costs the timed loop ~4 us, 0.012 ms per step with three: measured r03, 0.519 against 0.531 ms)
@@ -288,6 +337,12 @@ def main():
                 gather.wait()
         return out
 
+    def intervals(events, n):
+        """(forward ms, backward ms) per step from the events of n steps (after a synchronize)."""
+        fwd = [(events[i][0] if (i == 0 or dist is not None) else events[i - 1][2]).elapsed_time(events[i][1]) for i in range(n)]
+        bwd = [events[i][1].elapsed_time(events[i][2]) for i in range(n)]
+        return fwd, bwd
+
     def timed(n, **kw):
         """Mean seconds per step of n steps, bracketed by barrier + synchronize, max over ranks."""
         if reducer is not None:
@@ -312,22 +367,58 @@ def main():
             el = float(t.item())
         return el
 
-    # Setup, not measurement: the first process on a fresh box has been seen to run its first
-    # dozens of steps far below steady state (allocator growth, code-object loads, clocks).
-    # Bring the device there before the W warm-up steps the contract asks for (PREWARM_STEPS is
-    # printed in the line as `prewarm`).
-    for _ in range(PREWARM_STEPS):
-        step()
-    torch.cuda.synchronize()
+    # Setup, not measurement: bring the device to its steady state before the W warm-up steps the contract asks for.
+    # By time and convergence, not by count (see PREWARM_* above): batches of full steps with per-step events, until at
+    # least PREWARM_MIN_S have passed AND the last PREWARM_WINDOW forward and backward intervals each lie within
+    # PREWARM_TOL of their median -- or PREWARM_MAX_S are over, which the line then shows (`prewarm.converged` false).
+    # Every rank runs the same number of batches (the decision is all-reduced): the collectives stay matched.
+    pre_ev = new_events(PREWARM_BATCH)
+    pre_fwd, pre_bwd, pre_steps, converged = [], [], 0, False
+    t_pre = time.perf_counter()
+    while True:
+        for i in range(PREWARM_BATCH):
+            step(i, events=pre_ev)
+        if reducer is not None:
+            reducer.wait()
+        torch.cuda.synchronize()
+        f_, b_ = intervals(pre_ev, PREWARM_BATCH)
+        pre_fwd += f_; pre_bwd += b_; pre_steps += PREWARM_BATCH
+        el_pre = time.perf_counter() - t_pre
+
+        def settled(xs):
+            w = xs[-PREWARM_WINDOW:]
+            m = _median(w)
+            return m > 0 and all(abs(x - m) <= PREWARM_TOL * m for x in w)
+        converged = settled(pre_fwd) and (args.forward_only or settled(pre_bwd))
+        done = (el_pre >= PREWARM_MIN_S and converged) or el_pre >= PREWARM_MAX_S
+        if dist is not None:
+            t = torch.tensor([1.0 if done else 0.0, 1.0 if converged else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            done, converged = bool(t[0].item() == 1.0), bool(t[1].item() == 1.0)
+        if done:
+            break
+    prewarm = {"steps": pre_steps, "seconds": round(el_pre, 3), "converged": converged,
+               "first_batch_ms": {"forward": round(_median(pre_fwd[:PREWARM_BATCH]), 4),
+                                  "backward": round(_median(pre_bwd[:PREWARM_BATCH]), 4)},
+               "last_batch_ms": {"forward": round(_median(pre_fwd[-PREWARM_BATCH:]), 4),
+                                 "backward": round(_median(pre_bwd[-PREWARM_BATCH:]), 4)},
+               "rule": f">= {PREWARM_MIN_S} s of full steps and the last {PREWARM_WINDOW} forward and backward intervals within "
+                       f"{PREWARM_TOL:.0%} of their median, at most {PREWARM_MAX_S} s (untimed; medians of the first / last "
+                       f"{PREWARM_BATCH} steps shown: a cold device shows up as first >> last)"}
+    if hasattr(_C, "freeze_pools"):
+        _C.freeze_pools(True)      # the lists' pool sizes stay what the warm-up settled on: no re-sizing inside the timed steps
     for _ in range(args.warmup):
         step()
     elapsed = timed(args.steps, events=True)
+    if hasattr(_C, "freeze_pools"):
+        _C.freeze_pools(False)
 
     route_fwd, route_bwd = _C.LAST_ROUTE["forward"], (None if args.forward_only else _C.LAST_ROUTE["backward"])
     forward_terms = bool(_C.LAST_ROUTE.get("forward_terms"))       # (of the timed route: the runs below take others)
-    fwd_ms = sum((ev[i][0] if (i == 0 or dist is not None) else ev[i - 1][2]).elapsed_time(ev[i][1])
-                 for i in range(args.steps)) / args.steps
-    bwd_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    fwd_steps, bwd_steps = intervals(ev, args.steps)
+    step_steps = [a + b for a, b in zip(fwd_steps, bwd_steps)]
+    fwd_ms = sum(fwd_steps) / args.steps
+    bwd_ms = sum(bwd_steps) / args.steps
 
     # N > 1: the gradient-accumulation arrangement (one gradient in flight under the next step) beside the
     # timed every-step-update one, same process, same number of steps
@@ -519,8 +610,15 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "prewarm": PREWARM_STEPS,
+            "prewarm": prewarm,
             "ms_per_step": round(ms_per_step, 4),
+            # the same K steps, per step, from the HIP events on the launch stream (forward: previous step's end -> this
+            # step's forward end; backward: -> this step's backward end): one hiccup and K slow steps read differently here
+            "value_median": round(world * Q / (_median(step_steps) * 1e-3) / 1e6, 3),
+            "per_step_ms": {"forward": [round(x, 4) for x in fwd_steps], "backward": [round(x, 4) for x in bwd_steps],
+                            "summary": {"forward": _spread(fwd_steps), "backward": _spread(bwd_steps), "step": _spread(step_steps)},
+                            "note": "`value` = rays / mean WALL time per step of the barrier-bracketed region (what the driver's "
+                                    "clock sees); `value_median` = rays / median of the per-step event times (forward + backward)"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -542,7 +640,8 @@ def main():
                 "features": "declared static (inference: the sigma bitmask is built once)" if args.forward_only
                             else "updated every step (nothing derived from them is cached between steps)",
             },
-            "kernel_ms": {"forward": round(fwd_ms, 4), "backward": round(bwd_ms, 4)},
+            "kernel_ms": {"forward": round(fwd_ms, 4), "backward": round(bwd_ms, 4),
+                          "forward_median": round(_median(fwd_steps), 4), "backward_median": round(_median(bwd_steps), 4)},
             "kernels": {"forward": route_fwd, "backward": route_bwd},
             "counters": dict(zip(("rays_hit", "steps", "levels", "valid", "active"), cnt)),
             "touched": touched,
@@ -640,5 +739,94 @@ def cpu_baseline(st, feats, o, d, v, fmt, K, gout, forward_only):
     }
 
 
+def dry_run(args, world, rank):
+    """--dry-run: everything of the N-rank bench that is not a kernel, on CPU tensors over gloo -- rendezvous from the
+    launcher's environment, one camera per rank, the pixel gather started after the forward, the gradient exchange
+    (OverlappedGradReducer, both arrangements), the barrier-bracketed timed loop with the MAX over ranks, the one JSON
+    line on rank 0.  The renderer is replaced by a differentiable stand-in of the same shapes (features [M, K], rays
+    [Q, 3] -> [Q, C+1]); `value` therefore measures nothing and the line says so in `data`."""
+    import datetime
+    from svox_t_amd import parallel
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+    torch.manual_seed(0)
+    M, K, C, Q = 3344, 4, 3, 64 * 64
+    features = torch.randn(M, K, requires_grad=True)
+    dirs = torch.nn.functional.normalize(torch.randn(Q, 3) + torch.tensor([0.0, 0.0, float(rank)]), dim=1)
+    sel = torch.randint(0, M, (Q,))
+    gout = torch.randn(Q, C + 1)
+
+    def render():
+        rows = features[sel]                                   # a gather of feature rows, a per-ray weight, a sigmoid
+        w = 1.0 - torch.exp(-torch.relu(rows[:, K - 1:]) * dirs[:, 2:].abs())
+        return torch.cat([w * torch.sigmoid(rows[:, :C]), w], dim=1)
+
+    reducer = parallel.OverlappedGradReducer(dist, backend="gloo") if dist is not None else None
+    gathered = torch.empty((world * Q, C + 1)) if dist is not None else None
+
+    def step(accumulate=False):
+        features.grad = None
+        out = render()
+        gather = parallel.gather_pixels_async(dist, gathered, out.detach(), backend="gloo") if dist is not None else None
+        out.backward(gout)
+        if dist is not None:
+            reducer.start(features.grad)
+            if not accumulate:
+                reducer.wait()
+            gather.wait()
+
+    def timed(n, **kw):
+        if reducer is not None:
+            reducer.wait()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(**kw)
+        if reducer is not None:
+            reducer.wait()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    for _ in range(args.warmup):
+        step()
+    elapsed = timed(args.steps)
+    acc = timed(args.steps, accumulate=True) if dist is not None else None
+    ok = True
+    if dist is not None:
+        # the reduced gradient is the same on every rank, and the gathered pixels hold every rank's block
+        g = features.grad.detach().clone()
+        ref = g.clone()
+        dist.broadcast(ref, src=0)
+        ok = bool(torch.equal(g, ref)) and bool(torch.equal(gathered[rank * Q:(rank + 1) * Q], render().detach()))
+        t = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item() == 1.0)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "dry run (no GPU, stand-in renderer): launch / rendezvous / collectives / timing only",
+            "value": round(world * Q / (elapsed / args.steps) / 1e6, 3), "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "dry-run: CPU tensors, gloo, stand-in renderer -- not a measurement",
+            "config": {"workload": f"stand-in: features [{M}, {K}], {Q} rays per rank", "rays_per_gpu": Q},
+            "collectives_consistent": ok,
+            "accumulation_arrangement": None if acc is None else {"ms_per_step": round(acc * 1e3 / args.steps, 4)},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 19
+#define SVOXT_ABI_VERSION 20
 
 enum {
     SVOXT_OK = 0,
@@ -266,6 +266,15 @@ int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
  *                                in every word already (svoxt_sigma_mask_build_fill on the same stream): the call
  *                                does not fill them again. */
 #define SVOXT_LISTS_BEGUN 32
+/*   SVOXT_LISTS_WALK_ROWMAJOR    (ABI v20) the order in which an image's 8 x 8 tiles are walked when these lists are written
+ *   SVOXT_LISTS_WALK_SUPER       and read (svoxt_rays.image_width): lists are indexed by (tile, lane), so the backward that
+ *                                replays them must walk the image the way the recording forward did.  Neither bit: the
+ *                                library's rule (a function of tree->M and svoxt_set_super_tile_rows) at the time of EACH
+ *                                call -- the caller answers for both calls seeing the same rule.  One bit set (what
+ *                                svoxt_image_walk returns for the recording call: pass it to both): that walk, whatever
+ *                                the rule says by the time of the backward. */
+#define SVOXT_LISTS_WALK_ROWMAJOR 64
+#define SVOXT_LISTS_WALK_SUPER 128
 /* Test and measurement switches of the one-launch forward (fwd_roles_kernel; ABI v17), all result-neutral: its shading
  * workgroups drop every third tile they take / give up after one poll / treat what they load for every fifth tile as a
  * stale read would look -- the fallback launch must then deliver the same pixels, lists and hand-over -- and
@@ -325,7 +334,8 @@ typedef struct svoxt_sample_lists {
     void*   pool_next;
     int32_t terms_state;   /* see terms */
     int32_t flags;         /* 0 or an OR of SVOXT_LISTS_* (above) */
-    void*   tile_state;    /* optional (pooled lists only): device int32 [17 * ceil(Q / 64) + 514], 8-byte aligned, scratch.  Given, the two-kernel
+    void*   tile_state;    /* optional (pooled lists only): device int32 [17 * ceil(Q / 64) + 514], 8-byte aligned (its ready
+                              queues hold 64-bit entries; a misaligned pointer is SVOXT_ERR_INVALID), scratch.  Given, the two-kernel
                               forward of 3-channel payloads (N = 2, no view rotations, sigma bitmask at hand) runs its march
                               and its shade as ONE launch: tiles are shaded in the order their marches finish, beside the
                               marches still running (per-tile states, then per-XCD ready queues of 64-bit entries -- tile id and a
@@ -467,6 +477,10 @@ int svoxt_set_bwd_check(int64_t* words);
  * records sample lists and the backward that walks them must run under the same value (tests use 0 to exercise the
  * super-tile walk on small, ragged images).  Returns the value in force before the call. */
 int64_t svoxt_set_super_tile_rows(int64_t rows);
+/* (ABI v20) The walk the rule above gives this tree / ray batch right now: SVOXT_LISTS_WALK_ROWMAJOR or
+ * SVOXT_LISTS_WALK_SUPER for a batch declared an image of 8 x 8 tiles, 0 otherwise (-1: NULL argument).  OR it into
+ * svoxt_sample_lists.flags of a recording forward and of the backward over the same lists. */
+int32_t svoxt_image_walk(const svoxt_tree* tree, const svoxt_rays* rays);
 
 /* Acceleration grid (no counterpart in the reference).  A 2^g x 2^g x 2^g table
  * that caches, per cell, where the root->leaf descent of common.cuh:63-100

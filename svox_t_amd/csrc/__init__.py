@@ -43,7 +43,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -142,6 +142,7 @@ EXPORTS = {
     "svoxt_set_bwd_counters": (ctypes.c_int, [_vp]),
     "svoxt_set_bwd_check": (ctypes.c_int, [_vp]),
     "svoxt_set_super_tile_rows": (_i64, [_i64]),
+    "svoxt_image_walk": (_i32, [_P(_CTree), _P(_CRays)]),
     "svoxt_ray_order_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "svoxt_ray_order": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, ctypes.c_int64, _vp]),
     "svoxt_gather_rays": (ctypes.c_int, [_P(_CRays), _vp, _vp, _vp, _vp, _vp]),
@@ -656,43 +657,69 @@ def get_out_data_dim(opt: RenderOptions, K: int) -> int:
 # Pooled lists (include/svoxt.h, svoxt_sample_lists.blocktab): the records live in 4 KB blocks handed
 # out per (tile, 8 list positions) from a pool, so memory follows the samples that exist instead of
 # cap x rays (800x800, depth-8 SH9: 47 MB of records in a 491 MB dense buffer).  How large a pool a
-# batch needs is learned from the forward before it: its block counter is copied to pinned host
-# memory without waiting, and the next lists of the same shape are sized 1.25x what was used (twice
-# the pool if it ran dry -- a ray that finds no block stops recording and marches the rest, so a pool
-# that is too small costs time, never correctness).  LIST_POOL (SVOXT_LIST_POOL=0) False: dense lists.
-# (r04) The hint is kept per KIND of forward (recording / scratch: a no-grad forward between training steps of the same
-# shape needs a different pool, and one shared hint sent the next 16 training steps through the tails at 2.3x their
-# time: scripts/persp_timing.py), and a pool that ran dry is looked at again after EVERY forward until it no longer does.
-# (A pool that shrinks a quarter per look instead of at once: every look a new allocation size -- measured, not kept.)
-_POOL_HINT: dict = {}       # (tiles, S, kind) -> [blocks to allocate, pending (event, pinned counter, capacity) or None, forwards seen, ran dry]
+# batch needs is learned from the forwards before it: now and then ("a look") the 32 block counters are
+# copied to pinned host memory without waiting -- ONE 2 KB copy, no kernel -- and read when the copy has
+# landed.  A ray that finds no block stops recording and marches the rest, so a pool that is too small
+# costs time, never correctness.  LIST_POOL (SVOXT_LIST_POOL=0) False: dense lists.
+#   The size is STICKY (r05): it changes only when a look leaves the band
+#   [POOL_LOW, POOL_HIGH] of the current capacity -- above (or dry): grow at once; below: shrink after
+#   POOL_SHRINK_LOOKS such looks in a row -- and sizes are rounded up to 1/16 of a power of two, so the
+#   steady state of a training loop asks the allocator for the same block sizes step after step (r04 sized
+#   to 1.25x the last eight looks: a new size at almost every look, a new cudaMalloc behind it).
+#   The first two forwards of a shape are looked at right away and set the size directly.
+#   freeze_pools(True): no look is started and none is applied (bench.py around its timed steps).
+# The hint is kept per KIND of forward (recording / scratch: a no-grad forward between training steps of the
+# same shape needs a different pool: scripts/persp_timing.py).
+_POOL_HINT: dict = {}       # (tiles, S, kind) -> [blocks, pending (event, pinned counters, capacity) or None, forwards seen, ran dry, low looks]
+POOL_LOW, POOL_HIGH, POOL_SHRINK_LOOKS, POOL_LOOK_EVERY = 0.5, 0.85, 4, 16
+_POOL_FROZEN = [False]
+
+
+def freeze_pools(on: bool = True) -> None:
+    """While on, the pooled lists keep the sizes they have: no usage look is started, none is applied."""
+    _POOL_FROZEN[0] = bool(on)
+
+
+def _pool_quant(n: int) -> int:
+    """n rounded up to a multiple of 1/16 of the power of two below it (at least 32)."""
+    q = max(32, 1 << max(0, int(n).bit_length() - 5))
+    return (int(n) + q - 1) // q * q
 
 
 def _pool_blocks_for(tiles: int, S: int, kind: str = "record") -> int:
     full = tiles * (S // 8)
-    ent = _POOL_HINT.setdefault((tiles, S, kind), [min(full, tiles * 12), None, 0, False, []])
+    ent = _POOL_HINT.setdefault((tiles, S, kind), [min(full, tiles * 12), None, 0, False, 0])
+    if _POOL_FROZEN[0]:
+        return max(1, ent[0])
     # (a pool known to have run dry: the look that is under way is waited for -- a dry pool costs more than the wait)
     if ent[1] is not None and (ent[1][0].query() or ent[3]):
         if ent[3]:
             ent[1][0].synchronize()
-        used, cap = int(ent[1][1].item()), ent[1][2]
+        used = (int(ent[1][1].view(32, 16)[:, 0].max().item()) + 1) * 32        # the fullest of the 32 parts sets the need
+        cap = ent[1][2]
         ent[1] = None
         ent[3] = used >= cap
-        # sized by the largest of the last eight looks (~128 forwards): batches of one shape that alternate -- a sorted
-        # and an unsorted ray order, two cameras -- keep the pool of the one that needs more
-        hist = ent[4]
-        hist.append(min(full, cap * 2) if ent[3] else used)
-        del hist[:-8]
-        ent[0] = min(full, cap * 2) if ent[3] else min(full, max(tiles, int(max(hist) * 1.25) + 64))
+        want = min(full, max(tiles, _pool_quant(int(used * 1.25) + 64)))
+        if ent[3]:
+            ent[0], ent[4] = min(full, cap * 2), 0
+        elif ent[2] <= 2 or used > POOL_HIGH * cap:
+            ent[0], ent[4] = (want if (ent[2] <= 2 or want > cap) else cap), 0
+        elif used < POOL_LOW * cap:
+            ent[4] += 1
+            if ent[4] >= POOL_SHRINK_LOOKS:
+                ent[0], ent[4] = want, 0
+        else:
+            ent[4] = 0
     return max(1, ent[0])
 
 
 _PINNED: list = []
 
 
-def _pinned_counter():
-    """A pinned int32[1] (a small ring: pinned allocations are slow to make)."""
+def _pinned_counters():
+    """A pinned int32[512] (a small ring: pinned allocations are slow to make)."""
     if len(_PINNED) < 8:
-        _PINNED.append(torch.empty((1,), dtype=torch.int32, pin_memory=True))
+        _PINNED.append(torch.empty((512,), dtype=torch.int32, pin_memory=True))
         return _PINNED[-1]
     _PINNED.append(_PINNED.pop(0))
     return _PINNED[-1]
@@ -711,7 +738,7 @@ class SampleLists:
         self.kind = kind
         if self.pooled:
             self.pool_blocks = (_pool_blocks_for(tiles, S, kind) + 31) // 32 * 32      # 32 equal parts, a counter each
-            nt = tiles * (S // 8)
+            nt = (tiles * (S // 8) + 1) // 2 * 2      # (even: tile_state behind it holds 64-bit queue entries -- 8-byte aligned)
             # table, then the 32 counters, then the tile states, ready queues and their counters (march and shade in one launch): one fill
             # (rounded up to whole 16-byte words: svoxt_sigma_mask_build_fill can then do lists_begin's fill)
             both = torch.empty(((nt + 32 * 16 + 17 * tiles + 514 + 3) // 4 * 4,), dtype=torch.int32, device=device)
@@ -738,13 +765,13 @@ class SampleLists:
         if not self.pooled:
             return
         ent = _POOL_HINT.get((self.tiles, self.S, self.kind))
-        if ent is None or ent[1] is not None:
+        if ent is None or ent[1] is not None or _POOL_FROZEN[0]:
             return
         ent[2] += 1
-        if ent[2] > 2 and ent[2] % 16 and not ent[3]:   # the first forwards of a shape, then every 16th (every one while the pool runs dry): three tiny launches each
+        if ent[2] > 2 and ent[2] % POOL_LOOK_EVERY and not ent[3]:   # the first forwards of a shape, then every 16th (every one while the pool runs dry)
             return
-        host = _pinned_counter()
-        host.copy_((self.pool_next.view(32, 16)[:, 0].max().view(1) + 1) * 32, non_blocking=True)   # the fullest part sets the need
+        host = _pinned_counters()
+        host.copy_(self.pool_next, non_blocking=True)             # one 2 KB copy: the 32 counters, 64 bytes apart
         ev = torch.cuda.Event()
         ev.record()
         ent[1] = (ev, host, self.pool_blocks)
@@ -1011,7 +1038,9 @@ def _volume_render(tree, rays, opt, record):
     with torch.cuda.device(dev):
         out = torch.empty((cr.Q, get_out_data_dim(opt, ct.K)), dtype=torch.float32, device=dev)
         if will_record:
-            lists.flags = lflags
+            # (the walk of an image's tiles goes on the lists: the backward replays them the way they were recorded,
+            # whatever svoxt_set_super_tile_rows says by then)
+            lists.flags = lflags | max(0, _lib.svoxt_image_walk(ctypes.byref(ct), ctypes.byref(cr)))
             lists.exp_table = etab
             if fills:
                 # the exact per-tile backward will want (att, e0, e1, e2) of every sample: this forward has them
@@ -1228,6 +1257,7 @@ def _opacity_render(tree, rays, opt, record):
         out = torch.empty((cr.Q, 1), dtype=torch.float32, device=dev)
         if record and BWD_LIST_SAMPLES > 0 and cr.Q > 0 and co.sigma_thresh == 0.0 and co.stop_thresh == 0.0:
             lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
+            lists.flags = max(0, _lib.svoxt_image_walk(ctypes.byref(ct), ctypes.byref(cr)))
             cl = lists.c_struct()
             _call("svoxt_opacity_render_fwd_record", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
                   _ptr(out), ctypes.byref(cl), _stream(dev))

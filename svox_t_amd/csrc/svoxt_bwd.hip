@@ -325,7 +325,7 @@ int bwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_optio
     }
     if (rays->Q == 0 || tree->M == 0) return SVOXT_OK;
     const TreeDev tr = to_dev(tree);
-    const RaysDev rd = to_dev(rays, tree);
+    const RaysDev rd = to_dev(rays, tree, lists);
     const Opts od = to_dev(opt);
     const bool n2 = tree->N == 2;
     bool done = false;

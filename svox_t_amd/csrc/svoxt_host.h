@@ -21,7 +21,8 @@ int check_opts(const svoxt_options* o, const svoxt_tree* t, const char* fn, bool
 
 // C structs -> what the kernels take by value
 TreeDev to_dev(const svoxt_tree* t);
-RaysDev to_dev(const svoxt_rays* r, const svoxt_tree* t);      // t (may be NULL): decides the walk order of an image's tiles
+// t (may be NULL) decides the walk order of an image's tiles -- unless the lists (may be NULL) name the walk they were recorded with
+RaysDev to_dev(const svoxt_rays* r, const svoxt_tree* t, const svoxt_sample_lists* l = nullptr);
 Opts to_dev(const svoxt_options* o);
 
 }  // namespace svoxt

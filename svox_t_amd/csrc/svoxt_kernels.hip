@@ -147,7 +147,7 @@ TreeDev to_dev(const svoxt_tree* t) {
 constexpr int64_t kSuperTileRows = (int64_t)1 << 21;
 static int64_t g_super_tile_rows = kSuperTileRows;        // svoxt_set_super_tile_rows
 
-RaysDev to_dev(const svoxt_rays* r, const svoxt_tree* t) {
+RaysDev to_dev(const svoxt_rays* r, const svoxt_tree* t, const svoxt_sample_lists* l) {
     RaysDev d;
     d.origins = r->origins; d.dirs = r->dirs; d.vdirs = r->vdirs; d.Q = r->Q;
     // image hint: usable only if the batch is exactly a W x H image of 8x8 tiles
@@ -158,7 +158,10 @@ RaysDev to_dev(const svoxt_rays* r, const svoxt_tree* t) {
     d.c2w = r->c2w; d.fx = r->fx; d.fy = r->fy;
     d.order = r->order;
     d.width = r->image_width; d.height = r->image_height;
-    d.super_tiles = (tiled && t != nullptr && t->M > g_super_tile_rows && r->Q < ((int64_t)1 << 28)) ? 1 : 0;   // (tiles < 2^22: inv_st)
+    // the walk of an image's tiles: what the lists were recorded with where they say so (SVOXT_LISTS_WALK_*), else the rule
+    const int32_t forced = l != nullptr ? (l->flags & (SVOXT_LISTS_WALK_ROWMAJOR | SVOXT_LISTS_WALK_SUPER)) : 0;
+    const bool super = forced ? (forced & SVOXT_LISTS_WALK_SUPER) != 0 : (t != nullptr && t->M > g_super_tile_rows);
+    d.super_tiles = (tiled && super && r->Q < ((int64_t)1 << 28)) ? 1 : 0;   // (tiles < 2^22: inv_st)
     d.tile_rows = tiled ? r->image_height / 8 : 0;
     d.inv_st = tiled ? 1.0f / (8.0f * (float)d.tiles_per_row) : 0.f;
     d.inv_t = (tiled && r->Q < ((int64_t)1 << 28)) ? 1.0f / (float)d.tiles_per_row : 0.f;
@@ -530,6 +533,13 @@ int64_t svoxt_set_super_tile_rows(int64_t rows) {
     return before;
 }
 
+int32_t svoxt_image_walk(const svoxt_tree* tree, const svoxt_rays* rays) {
+    if (tree == nullptr || rays == nullptr) return -1;
+    const RaysDev d = to_dev(rays, tree);
+    if (d.tiles_per_row == 0) return 0;
+    return d.super_tiles ? SVOXT_LISTS_WALK_SUPER : SVOXT_LISTS_WALK_ROWMAJOR;
+}
+
 const char* svoxt_last_error(void) { return g_err; }
 
 int svoxt_out_data_dim(const svoxt_options* opt, int32_t K) {
@@ -549,6 +559,9 @@ static int check_lists(const svoxt_sample_lists* l, const svoxt_options* opt, co
                                    l->max_samples > kMaxRecBlocks * kRecBlock))
         return fail(SVOXT_ERR_INVALID, "%s: pooled lists need pool_next, pool_blocks a positive multiple of 32 and max_samples <= 512", fn);
     if (((uintptr_t)l->rec & 63u) != 0) return fail(SVOXT_ERR_INVALID, "%s: lists.rec must be 64-byte aligned", fn);
+    if (((uintptr_t)l->tile_state & 7u) != 0) return fail(SVOXT_ERR_INVALID, "%s: lists.tile_state must be 8-byte aligned (64-bit queue entries)", fn);
+    if ((l->flags & SVOXT_LISTS_WALK_ROWMAJOR) && (l->flags & SVOXT_LISTS_WALK_SUPER))
+        return fail(SVOXT_ERR_INVALID, "%s: lists.flags name two tile walks", fn);
     if (opt->sigma_thresh != 0.f || opt->stop_thresh != 0.f)
         return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists require sigma_thresh == stop_thresh == 0", fn);
     return SVOXT_OK;
@@ -594,7 +607,7 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
     hipStream_t st = (hipStream_t)stream;
     if (lists != nullptr && (rc = lists_begin(lists, rays->Q, st, fn))) return rc;
     const TreeDev tr = to_dev(tree);
-    const RaysDev rd = to_dev(rays, tree);
+    const RaysDev rd = to_dev(rays, tree, lists);
     const Opts od = to_dev(opt);
     const bool n2 = tree->N == 2;
     bool done = false;
@@ -859,8 +872,8 @@ int svoxt_opacity_render_fwd_record(const svoxt_tree* tree, const svoxt_rays* ra
     if ((rc = lists_begin(lists, rays->Q, st, fn))) return rc;
     const RecLists L = lists_dev(lists, rays->Q);
     uint4* aux = reinterpret_cast<uint4*>(lists->aux);
-    if (tree->N == 2) hipLaunchKernelGGL((opacity_fwd_kernel<true, true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays, tree), to_dev(opt), out, L, aux);
-    else hipLaunchKernelGGL((opacity_fwd_kernel<false, true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays, tree), to_dev(opt), out, L, aux);
+    if (tree->N == 2) hipLaunchKernelGGL((opacity_fwd_kernel<true, true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays, tree, lists), to_dev(opt), out, L, aux);
+    else hipLaunchKernelGGL((opacity_fwd_kernel<false, true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), to_dev(rays, tree, lists), to_dev(opt), out, L, aux);
     return check_launch(fn);
 }
 
@@ -882,7 +895,7 @@ int svoxt_opacity_render_bwd_replay(const svoxt_tree* tree, const svoxt_rays* ra
     }
     if (rays->Q == 0 || tree->M == 0) return SVOXT_OK;
     const unsigned nb = nblocks(rays->Q);
-    const RaysDev rd = to_dev(rays, tree);
+    const RaysDev rd = to_dev(rays, tree, lists);
     const RecLists L = lists_dev(lists, rays->Q);
     uint4* aux = reinterpret_cast<uint4*>(lists->aux);
     if (tree->N == 2) hipLaunchKernelGGL((opacity_walk_kernel<true>), dim3(nb), dim3(kBlock), 0, st, to_dev(tree), rd, to_dev(opt), grad_out, grad_features, gs, L, aux);

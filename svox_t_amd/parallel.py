@@ -31,6 +31,12 @@ import torch.distributed as dist
 from torch import autograd
 
 
+# Test switch: run every collective even in a group of ONE rank (where each is the identity and is normally skipped), so
+# that a one-GPU box exercises the real backend's calls -- RCCL all-reduce / all-gather / broadcast launches, the side
+# stream hand-offs, async work handles -- exactly as an N-rank job issues them (tests/test_gpu_nccl_world1.py).
+FORCE_COLLECTIVES = False
+
+
 def shard_bounds(Q: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous, balanced [lo, hi) of `Q` items for `rank` of `world`: the
     first Q % world ranks get one extra item."""
@@ -60,7 +66,7 @@ def _gather_shards(local: torch.Tensor, bounds, group) -> torch.Tensor:
     """All-gather row shards of unequal length (bounds[r] = [lo, hi) of rank r, contiguous
     and in rank order) into the full tensor."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         return local
     cap = max(hi - lo for lo, hi in bounds)           # rows per rank, padded
     tail = local.shape[1:]
@@ -115,7 +121,7 @@ class _ShardedRender(autograd.Function):
         else:
             g = torch.zeros_like(ctx.feats)
         g = g.contiguous()
-        if dist.get_world_size(ctx.group) > 1:
+        if dist.get_world_size(ctx.group) > 1 or FORCE_COLLECTIVES:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
         return g, None, None, None, None
 
@@ -161,7 +167,7 @@ class _CameraSet(autograd.Function):
             feats = features.detach().requires_grad_(True)
             local = [render_fn(feats, c2ws[i]) for i in mine]
         ctx.feats, ctx.local, ctx.group, ctx.mine = feats, local, group, mine
-        if world == 1:
+        if world == 1 and not FORCE_COLLECTIVES:
             return torch.stack([im.detach() for im in local])
         # ranks with fewer cameras pad with zero images so that the gather is regular;
         # the image shape is taken from a rendered camera (ranks without any learn it
@@ -184,7 +190,7 @@ class _CameraSet(autograd.Function):
         for im, i in zip(ctx.local, ctx.mine):
             (gi,) = torch.autograd.grad(im, ctx.feats, grad_full[i].contiguous())
             g += gi
-        if dist.get_world_size(ctx.group) > 1:
+        if dist.get_world_size(ctx.group) > 1 or FORCE_COLLECTIVES:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
         return g, None, None, None
 
@@ -242,7 +248,7 @@ def direct_all_reduce(dist_module, grad: torch.Tensor, group=None) -> torch.Tens
     the gradient: ranges are views, ragged splits are fine.  Adds happen in rank order on the owner (own, then peers
     ascending): the result is the same on every rank, bit for bit."""
     W, me = dist_module.get_world_size(group), dist_module.get_rank(group)
-    if W == 1 or grad.numel() == 0:
+    if (W == 1 and not FORCE_COLLECTIVES) or grad.numel() == 0:
         return grad
     assert grad.is_contiguous()
     M = grad.shape[0]
@@ -285,9 +291,10 @@ def sparse_all_reduce(dist_module, grad: torch.Tensor, group=None, block_rows: i
         2  every owner sends each peer the blocks of its range that ANYONE touched.
     Bytes per link: (what the rank touched of a range) one way, (the union over ranks of a range) the other, instead
     of S / W each way.  Returns (grad, stats) with stats = blocks sent in round 1 / round 2 / a dense exchange's.
-    The adds are in rank order on the owner, as in direct_all_reduce: equal to it bit for bit."""
+    The adds are in rank order on the owner, as in direct_all_reduce: equal to it as floats (==; a row whose only
+    contributions are -0.0 keeps its sign here, where the dense exchange's + 0.0 turns it into +0.0)."""
     W, me = dist_module.get_world_size(group), dist_module.get_rank(group)
-    if W == 1 or grad.numel() == 0:
+    if (W == 1 and not FORCE_COLLECTIVES) or grad.numel() == 0:
         return grad, {"round1_blocks": 0, "round2_blocks": 0, "dense_blocks": 0}
     assert grad.is_contiguous() and grad.dim() == 2
     M, K = grad.shape
@@ -408,7 +415,7 @@ class OverlappedGradReducer:
 
     def start(self, grad: torch.Tensor) -> None:
         self.wait()
-        if grad is None or grad.numel() == 0 or self.dist.get_world_size(self.group) == 1:
+        if grad is None or grad.numel() == 0 or (self.dist.get_world_size(self.group) == 1 and not FORCE_COLLECTIVES):
             return
         assert grad.is_contiguous()
         self._grad = grad                                   # stays alive while it travels
@@ -457,7 +464,7 @@ def gather_pixels_async(dist_module, gathered: torch.Tensor, local: torch.Tensor
     (the backward).  dst = r: only rank r needs the image (a viewer, a logger): a gather to that
     rank moves 1/world of what the all-gather moves over every other rank's links."""
     world = dist_module.get_world_size(group)
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         gathered.copy_(local)
         return _Done()
     if dst is not None:

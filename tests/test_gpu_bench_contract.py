@@ -37,6 +37,21 @@ def test_bench_json_contract(gpu):
     assert abs(ref["gbps"] - ref["bytes_per_step"] / (r["ms_per_step"] * 1e-3) / 1e9) < 0.01 * ref["gbps"]
     assert 4.9e9 < ref["bytes_per_step"] < 5.2e9                                        # 1.225 GB forward + 3.811 GB backward
     assert 0 < r["value_plain"] <= r["value"] * 1.05
+    # the line says what happened step by step: the K intervals, their spread, the median's value,
+    # and what the untimed warm-up saw -- by time and convergence, not by count
+    ps = r["per_step_ms"]
+    assert len(ps["forward"]) == len(ps["backward"]) == r["steps"] and min(ps["forward"] + ps["backward"]) > 0
+    for g in ("forward", "backward", "step"):
+        sm = ps["summary"][g]
+        assert sm["min"] <= sm["median"] <= sm["max"]
+    assert abs(r["kernel_ms"]["backward"] - sum(ps["backward"]) / r["steps"]) < 2e-3
+    assert ps["summary"]["backward"]["max"] <= 1.5 * ps["summary"]["backward"]["median"], ps["backward"]
+    assert ps["summary"]["forward"]["max"] <= 1.5 * ps["summary"]["forward"]["median"], ps["forward"]
+    assert abs(r["value_median"] - 0.64 / ps["summary"]["step"]["median"] * 1e3) / r["value_median"] < 2e-3
+    assert r["value_median"] >= 0.9 * r["value"]                 # events on the stream never see more than the wall clock
+    pw = r["prewarm"]
+    assert pw["seconds"] >= 0.5 and pw["steps"] >= 20 and pw["converged"] is True, pw
+    assert pw["last_batch_ms"]["backward"] <= 1.1 * ps["summary"]["backward"]["median"]    # the timed steps are the settled ones
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert r["counters"]["steps"] == 18919396                                           # the workload is the one named
