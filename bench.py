@@ -168,6 +168,8 @@ def main(argv=None):
     ap.add_argument("--share-device", action="store_true",
                     help="dry run: put every rank on cuda:0 (to rehearse the N>1 code path on a 1-GPU box)")
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--fast", action="store_true",
+                    help="sigma_thresh = stop_thresh = 1e-2 (svox_t/renderer.py:428-430): SURVEY.md 8(d)'s extra row; the headline is thresholds 0")
     ap.add_argument("--exchange", default="auto", choices=["auto", "all_reduce", "direct"],
                     help="N > 1: the gradient all-reduce (auto: both are timed on a gradient-sized buffer first, the faster is used)")
     ap.add_argument("--dry-run", action="store_true",
@@ -214,7 +216,7 @@ def main(argv=None):
     rays = svox.Rays(o.to(dev), d.to(dev), v.to(dev))
     features = tree.features
     M = features.shape[0]
-    opt = renderer._get_options()
+    opt = renderer._get_options(args.fast)
     C = _C.get_out_data_dim(opt, K) - 1
     gout = synth.grad_output(Q, C + 1).to(dev)
 
@@ -244,8 +246,8 @@ def main(argv=None):
             rs.origins, rs.dirs, rs.vdirs = rays.origins, rays.dirs, rays.viewdirs
             return _ReferenceShaped.apply(features, tree._spec(features), rs, opt)
         if route == "camera":
-            return renderer.render_persp(features, c2w, width=W, height=H, fx=fx).view(Q, -1)
-        return renderer(features, rays, image_shape=(H, W))
+            return renderer.render_persp(features, c2w, width=W, height=H, fx=fx, fast=args.fast).view(Q, -1)
+        return renderer(features, rays, image_shape=(H, W), fast=args.fast)
 
     # ---- one-off device-side counts (before the timed region) -------------------------------
     rs_hint = _rays_spec_from_rays(rays, (H, W))
@@ -544,14 +546,15 @@ def main(argv=None):
             dom, dom_kernel, dom_ms, dom_bytes, dom_ref = "backward", route_bwd, bwd_ms, bwd_bytes, ref_bwd
             dom_kernel += " + grad memset + row compaction"
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic, traffic_note = pmc_traffic(args.workload, args.forward_only, dom) if world == 1 else \
-            (None, "PMC profiles exist for N=1 only")
+        prof_ok = world == 1 and not args.fast            # (committed profiles: N = 1, thresholds 0)
+        traffic, traffic_note = pmc_traffic(args.workload, args.forward_only, dom) if prof_ok else \
+            (None, "PMC profiles exist for N=1, thresholds 0 only")
         # Like with like: the chain floor of the STEPPING against the march kernel's own time (from the committed
         # kernel statistics of this command) when the forward is march + shade; the floor of stepping + shading
         # in one chain against the whole forward when it is one kernel.
         two_kernel = "march_rec" in (route_fwd or "")
         chain = "march" if two_kernel else "march+shade"
-        kstats = kernel_stats_ms(args.workload, args.forward_only) if world == 1 else {}
+        kstats = kernel_stats_ms(args.workload, args.forward_only) if prof_ok else {}
         march_ms = next((v for k, v in kstats.items() if k.startswith("march_rec_kernel")), None)
         shade_ms = next((v for k, v in kstats.items() if k.startswith("shade_")), None)
         limits = {"forward": {
@@ -603,8 +606,8 @@ def main(argv=None):
         step_ref = ref_fwd + (0 if args.forward_only else ref_bwd)
         res = {
             "metric": "Mrays/s fwd+bwd, 800×800 render, depth-8 SH9 N3Tree, 1→8 MI355X"
-                      if args.workload == "d8_sh9_800" and not args.forward_only
-                      else f"Mrays/s {'fwd' if args.forward_only else 'fwd+bwd'}, {args.workload}",
+                      if args.workload == "d8_sh9_800" and not args.forward_only and not args.fast
+                      else f"Mrays/s {'fwd' if args.forward_only else 'fwd+bwd'}, {args.workload}" + (", fast=True (thresholds 1e-2)" if args.fast else ""),
             "value": round(value, 3),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -628,7 +631,7 @@ def main(argv=None):
                 "workload": f"depth-{depth} shell N3Tree (n_internal {st.n_internal}, M {M}), "
                             f"{fmt} data_dim {K}, {W}x{H} pinhole rays per GPU, "
                             f"{'forward' if args.forward_only else 'forward+backward'}, "
-                            f"step_size 1e-3, thresholds 0",
+                            f"step_size 1e-3, thresholds {'1e-2 (fast=True)' if args.fast else '0'}",
                 "rays_per_gpu": Q,
                 "route": args.route,
                 "backward_arithmetic": None if args.forward_only else
@@ -678,7 +681,7 @@ def main(argv=None):
                 # two are within 2 % of each other and take turns)
                 "groups": {g: {"ms": round(ms_, 4), "compulsory_bytes": b_, "achieved": round(b_ / (ms_ * 1e-3) / 1e9, 2),
                                "frac": round(b_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                               "traffic": (pmc_traffic(args.workload, args.forward_only, g)[0] if world == 1 else None)}
+                               "traffic": (pmc_traffic(args.workload, args.forward_only, g)[0] if prof_ok else None)}
                            for g, ms_, b_ in (("forward", fwd_ms, fwd_bytes), ("backward", bwd_ms, bwd_bytes)) if ms_ > 0.02 and b_ > 0},
             },
             "limits": limits,

@@ -225,9 +225,12 @@ int svoxt_volume_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
  * resume point, final transmittance) -- and the backward then replays
  * those samples instead of traversing the tree again (twice, in the reference:
  * rt_kernel.cu:365-494).  Rays with more than max_samples composited samples
- * march the remainder, so the result does not depend on max_samples.  Needs
- * sigma_thresh == stop_thresh == 0 (the reference's backward ignores both) and
- * one of the specialised payloads (svoxt_can_record returns 1; with tree->xform
+ * march the remainder, so the result does not depend on max_samples.  The lists hold EVERY
+ * sample with sigma > 0 to the end of the ray -- what the reference's backward takes, which ignores
+ * both thresholds (rt_kernel.cu:382, 456) -- and the recording forward applies its own rules while it
+ * composites (ABI v20: sigma > sigma_thresh, :279; nothing after T <= stop_thresh, :313-319), so any
+ * thresholds are served (`fast=True`); a sigma bitmask handed to a recording forward must be the one of
+ * threshold 0.  Needs one of the specialised payloads (svoxt_can_record returns 1; with tree->xform
  * set: SH payloads on N = 2 trees); the lists are valid for the tree, features'
  * sign of sigma, rays and options they were recorded with.
  * svoxt_can_record returns 2 (r03) for SG / ASG payloads with 1 / 4 / 9 / 16 / 25 lobes and three channels on
@@ -398,7 +401,8 @@ int svoxt_opacity_render_bwd(const svoxt_tree* tree, const svoxt_rays* rays,
                              const svoxt_options* opt, const float* grad_out,
                              float* grad_features, void* stream);
 
-/* The same pair with sample lists (both thresholds 0): the forward records each ray's
+/* The same pair with sample lists (any thresholds since ABI v20: recorded is every sample with sigma > 0,
+ * composited what the forward's thresholds leave): the forward records each ray's
  * samples, the backward walks the lists instead of marching twice and adds the
  * contributions up per 8x8 tile before they go to memory (rec and aux are rewritten:
  * the lists serve one backward).  Every contribution is the reference's

@@ -801,7 +801,7 @@ def _list_cap(ct: "_CTree", base: int) -> int:
 
 def can_record(tree: TreeSpec, opt: RenderOptions) -> bool:
     """True when volume_render(..., record=True) can hand sample lists to the backward
-    (a specialised payload, both thresholds 0; include/svoxt.h svoxt_can_record)."""
+    (a specialised payload, all components; any thresholds since r05: include/svoxt.h svoxt_can_record)."""
     ct, co = _pack_tree(tree), _pack_opts(opt)
     return bool(_lib.svoxt_can_record(ctypes.byref(ct), ctypes.byref(co)))
 
@@ -978,8 +978,8 @@ def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bo
 
     `record=True` (not in the reference) asks for the sample lists a following
     volume_render_backward can replay; the call then returns (out, lists), with
-    lists = None when recording does not apply (non-zero thresholds, a payload
-    without a specialised kernel, SVOXT_BWD_LIST=0)."""
+    lists = None when recording does not apply (a payload without a specialised
+    kernel, a component sub-range, SVOXT_BWD_LIST=0)."""
     if not record and AUTO_PLAN:
         return _planned_forward("volume", lambda t, r, o, rec: _volume_render(t, r, o, rec), tree, rays, opt)
     return _volume_render(tree, rays, opt, record)
@@ -1007,7 +1007,7 @@ def _volume_render(tree, rays, opt, record):
     # per-leaf view rotations, SH 1 / 4 / 9: march and shade in one launch too (no hand-over: their backward recomputes)
     xf_roles = bool(will_record and ct.xform and FWD_SPLIT == "" and FWD_OVERLAP and LIST_POOL and BWD_XF_FUSED and ct.N == 2
                     and ct.weight_accum is None and co.format == FORMAT_SH and co.basis_dim in (1, 4, 9)
-                    and ct.K == 3 * co.basis_dim + 1 and co.stop_thresh == 0.0)
+                    and ct.K == 3 * co.basis_dim + 1)
     if xf_roles:
         lflags |= LISTS_FWD_TWO_KERNELS
     fills = _lib.svoxt_fwd_fills_terms(ctypes.byref(ct), ctypes.byref(co), lflags) \
@@ -1022,7 +1022,8 @@ def _volume_render(tree, rays, opt, record):
     if ((split or fills == 3 or xf_roles) and FWD_SPLIT != "0") if will_record else (split and co.stop_thresh == 0.0):
         # rows of 8 / 16 / 32 floats in exact mode: the same pass leaves the rows' exponentials for the shade kernel
         # (and, on the lists, for the per-tile backward of this feature content)
-        etab = _attach_sigma_mask(tree, ct, float(co.sigma_thresh), keep=not will_record,
+        # (lists for a backward hold every sample with sigma > 0 whatever the forward's threshold: the mask of threshold 0)
+        etab = _attach_sigma_mask(tree, ct, 0.0 if will_record else float(co.sigma_thresh), keep=not will_record,
                                   table=wide and split and not NATIVE_MATH, begin=lists)
     LAST_ROUTE["forward_terms"] = False
     # march and shade of a 3-channel payload as ONE launch (fwd_roles_kernel): the conditions of the library's launch_fwd_roles
@@ -1144,7 +1145,8 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
             if lists.aux.shape[0] != cr.Q or lists.aux.device != dev:
                 raise RuntimeError("sample lists do not belong to this ray batch")
             fo = None
-            if fwd_output is not None and not BWD_EXACT:
+            # (the single-march tolerance mode differentiates the forward's own sum: only without thresholds)
+            if fwd_output is not None and not BWD_EXACT and co.sigma_thresh == 0.0 and co.stop_thresh == 0.0:
                 _check_input(fwd_output, "fwd_output")
                 if fwd_output.shape != grad_output.shape or fwd_output.dtype != torch.float32:
                     raise RuntimeError("fwd_output must match grad_output")
@@ -1243,7 +1245,7 @@ def render_depth(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Te
 
 def opacity_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bool = False):
     """rt_kernel.cu:1574-1591.  `record=True` (not in the reference): also return the
-    sample lists opacity_render_backward can walk (None when thresholds are non-zero)."""
+    sample lists opacity_render_backward can walk."""
     if not record and AUTO_PLAN:
         return _planned_forward("opacity", lambda t, r, o, rec: _opacity_render(t, r, o, rec), tree, rays, opt)
     return _opacity_render(tree, rays, opt, record)
@@ -1255,7 +1257,7 @@ def _opacity_render(tree, rays, opt, record):
     lists = None
     with torch.cuda.device(dev):
         out = torch.empty((cr.Q, 1), dtype=torch.float32, device=dev)
-        if record and BWD_LIST_SAMPLES > 0 and cr.Q > 0 and co.sigma_thresh == 0.0 and co.stop_thresh == 0.0:
+        if record and BWD_LIST_SAMPLES > 0 and cr.Q > 0:
             lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
             lists.flags = max(0, _lib.svoxt_image_walk(ctypes.byref(ct), ctypes.byref(cr)))
             cl = lists.c_struct()

@@ -58,7 +58,7 @@ __device__ __forceinline__ void render_fwd_ray(const TreeDev& tr, const RaysDev&
     float t_start = 0.f;
     if constexpr (RESUME) {
         const uint4 a = aux[q];
-        if ((a.x & kRecOverflow) == 0u) return;
+        if ((a.x & kRecOverflow) == 0u || a.w == kAuxStopped) return;   // (no tail, or the shade ended the ray: stop rule)
         t_start = __uint_as_float(a.y);
     }
 
@@ -94,9 +94,15 @@ __device__ __forceinline__ void render_fwd_ray(const TreeDev& tr, const RaysDev&
     }
     bool stopped = false;
     // One composited sample (rt_kernel.cu:279-319); true: the ray ends here (early termination)
+    // REC (r05): the lists serve the backward, which takes every sample with sigma > 0 and never stops early
+    // (rt_kernel.cu:382, 456) -- so every such sample is RECORDED (and its hand-over formed), while it is COMPOSITED
+    // only if the forward's own rules say so (sigma > sigma_thresh, :279; not after T <= stop_thresh, :313-319): the
+    // march goes on to the end of the ray, `stopped` only ends the compositing.  With both thresholds 0 nothing
+    // changes: the two sets are the same, and the stop rule then fires at T == 0 exactly, where every later weight is 0.
     auto shade = [&](const float (&row)[K], int32_t idx, float delta_t, float t_cur, uint32_t slot) -> bool {
         const float sigma = row[K - 1];
-        if (!(sigma > opt.sigma_thresh)) return false;
+        if (!(sigma > (REC ? 0.f : opt.sigma_thresh))) return false;
+        const bool comp = !REC || (sigma > opt.sigma_thresh && !stopped);
         bool recorded = false;
         if constexpr (REC) {
             bool room = nrec < S;
@@ -121,13 +127,13 @@ __device__ __forceinline__ void render_fwd_ray(const TreeDev& tr, const RaysDev&
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 ex[c] = pexpf(neg_sh_dot<BD>(basis, row + c * BD));
-                acc[c] = (float)((double)acc[c] + (double)weight / (1.0 + (double)ex[c]));
+                if (comp) acc[c] = (float)((double)acc[c] + (double)weight / (1.0 + (double)ex[c]));
             }
         } else {
 #pragma unroll
             for (int j = 0; j < C; ++j) {
                 ex[j] = pexpf(-row[j]);
-                acc[j] = (float)((double)acc[j] + (double)weight / (1.0 + (double)ex[j]));
+                if (comp) acc[j] = (float)((double)acc[j] + (double)weight / (1.0 + (double)ex[j]));
             }
         }
         if constexpr (REC && C == 3 && !XF) {
@@ -142,10 +148,13 @@ __device__ __forceinline__ void render_fwd_ray(const TreeDev& tr, const RaysDev&
                 if ((k & 3) == 3) terms_flush(tstage, (int)threadIdx.x, L.terms, cur_block, k);
             }
         }
-        light *= att;
-        if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + leaf_slot<N2>(tr, r, t_cur, slot), weight);
-        if constexpr (!REC) {
-            if (light <= opt.stop_thresh) return true;
+        if (comp) {
+            light *= att;
+            if (tr.weight_accum != nullptr) atomicAdd(tr.weight_accum + leaf_slot<N2>(tr, r, t_cur, slot), weight);
+            if (light <= opt.stop_thresh) {
+                if constexpr (!REC) return true;
+                stopped = true;                  // (REC: the march goes on recording)
+            }
         }
         return false;
     };
@@ -415,7 +424,8 @@ __device__ __forceinline__ uint32_t march_rec_tile(const TreeDev& tr, const Rays
     uint32_t p_word = 0u;
     auto pending = [&]() -> bool {
         if constexpr (MASK) return ((p_word >> (p_idx & 31)) & 1u) != 0u;
-        else return p_sigma > opt.sigma_thresh;
+        // (!STOP without a bitmask: lists for a backward -- every sample with sigma > 0, whatever the forward's threshold)
+        else return p_sigma > (STOP ? opt.sigma_thresh : 0.f);
     };
     while (t < r.tmax) {
         Sample s;
@@ -559,6 +569,10 @@ __device__ __forceinline__ uint32_t shade_tile_body(const TreeDev& tr, const Ray
                 load_row<K>(tr.features + (int64_t)idx * K, row);
                 v4f tv;
                 tv.x = pexpf(-__uint_as_float(e.y) * delta_scale * row[K - 1]);
+                // (r05) lists that hold every sigma > 0 (a backward follows): a sample the forward's own threshold leaves
+                // out (rt_kernel.cu:279) goes through the chain as one that does nothing -- att = 1: weight = T (1 - 1) = 0,
+                // acc + 0 / (1 + e) = acc, T * 1 = T, bit for bit -- while its hand-over below is the backward's, untouched
+                const bool below = !(row[K - 1] > opt.sigma_thresh);
                 if constexpr (FMT == FMT_SH) {
                     if constexpr (XF) rotated_sh_basis<BD>(tr, idx, vd, basis);
                     float ex[C];
@@ -570,7 +584,11 @@ __device__ __forceinline__ uint32_t shade_tile_body(const TreeDev& tr, const Ray
                 } else {
                     tv.y = pexpf(-row[0]); tv.z = pexpf(-row[1]); tv.w = pexpf(-row[2]);
                 }
-                terms[rd & 1][wave - 1][lane] = tv;
+                {
+                    v4f tl = tv;
+                    tl.x = below ? 1.f : tv.x;
+                    terms[rd & 1][wave - 1][lane] = tl;
+                }
                 if constexpr (WTERMS) {
                     typedef float v4g __attribute__((ext_vector_type(4)));
                     const float att_b = pexpf(-__uint_as_float(e.y) * row[K - 1] * delta_scale);
@@ -589,9 +607,10 @@ __device__ __forceinline__ uint32_t shade_tile_body(const TreeDev& tr, const Ray
                     acc[1] = (float)((double)acc[1] + (double)weight / (1.0 + (double)tv.z));
                     acc[2] = (float)((double)acc[2] + (double)weight / (1.0 + (double)tv.w));
                     light *= tv.x;
-                    if constexpr (STOP) {
-                        if (light <= opt.stop_thresh) stopped = true;
-                    }
+                    // (the stop rule, rt_kernel.cu:313-319 -- also where the march did not apply it (!STOP: lists for a
+                    // backward, or a threshold of 0): it then ends the COMPOSITING here; at 0 it fires at T == 0 exactly,
+                    // where every later weight is 0 and the rescale is by 1)
+                    if (light <= opt.stop_thresh) stopped = true;
                 }
             }
         }
@@ -607,7 +626,9 @@ __device__ __forceinline__ uint32_t shade_tile_body(const TreeDev& tr, const Ray
 #pragma unroll
             for (int j = 0; j < C; ++j) o[j] = acc[j] * scale;
             o[C] = 1.f - light;
-            aw[0] = a_x & ~kRecOverflow;             // nothing left for the tail launch
+            // nothing left for the FORWARD's tail launch: scratch lists (the march stopped with the ray) drop the flag;
+            // lists for a backward keep it -- the backward's tail marches what the list could not hold -- and say so in .w
+            if constexpr (STOP) aw[0] = a_x & ~kRecOverflow;
         } else if (a_x & kRecOverflow) {             // state for render_fwd_kernel<..., RESUME>
 #pragma unroll
             for (int j = 0; j < C; ++j) o[j] = acc[j];
@@ -619,6 +640,7 @@ __device__ __forceinline__ uint32_t shade_tile_body(const TreeDev& tr, const Ray
             o[C] = 1.f - light;
         }
         aw[2] = __float_as_uint(light);              // the final transmittance, for the single-march backward
+        if constexpr (!STOP) aw[3] = stopped ? kAuxStopped : 0u;
     }
     return cs;
 }
@@ -923,7 +945,7 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
 template <int K, bool STOP, bool FAST, bool ETAB = false>
 __global__ void __launch_bounds__(256)
 shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
-                  uint4* __restrict__ aux, float* __restrict__ out) {
+                  uint4* __restrict__ aux, float* __restrict__ out, int keep_over = 0) {
     static_assert(K == 8 || K == 16 || K == 32, "row widths with a channel-lane instance");
     static_assert(!(ETAB && FAST), "the table holds the exact exponentials");
     constexpr int RPW = 64 / K;                                  // rays per wavefront
@@ -1013,7 +1035,9 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
                 sg = jm == j ? sj : sg;
                 dm = jm == j ? dt[j] : dm;
             }
-            att_mine = pexpf(jm < n_here ? -dm * ds * sg : 0.f);
+            // (r05: sg > sigma_thresh -- lists that hold every sigma > 0 for a backward: a sample below the forward's own
+            // threshold is one that does nothing, like a position past the list)
+            att_mine = pexpf((jm < n_here && sg > opt.sigma_thresh) ? -dm * ds * sg : 0.f);
 #pragma unroll
             for (int j = 0; j < kRecBlock; ++j) ex[j] = j < n_here ? x[j] : 1.f;      // (a position past the list: e = 1, as pexpf(0))
         } else {
@@ -1021,9 +1045,9 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
         for (int j = 0; j < kRecBlock; ++j) {
             if constexpr (FAST) {
                 const float e2 = x[j] * __builtin_fmaf(dt[j], sc_mult, sc_base);
-                ex[j] = __builtin_amdgcn_exp2f(j < n_here ? e2 : 0.f);
+                ex[j] = __builtin_amdgcn_exp2f((j < n_here && !(is_sig && !(x[j] > opt.sigma_thresh))) ? e2 : 0.f);
             } else {
-                const float arg = is_sig ? -dt[j] * ds * x[j] : -x[j];
+                const float arg = is_sig ? ((x[j] > opt.sigma_thresh) ? -dt[j] * ds * x[j] : 0.f) : -x[j];
                 ex[j] = pexpf(j < n_here ? arg : 0.f);
             }
         }
@@ -1053,8 +1077,11 @@ shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
         else v = acc + light * opt.background_brightness;
     } else {
         v = over ? light : 1.f - light;
-        if (stopped) a.x &= ~kRecOverflow;
+        // (keep_over: lists for a backward -- the stop rule ended the forward's compositing only; the backward's tail
+        // still marches what the list could not hold, the forward's tail is told to leave the ray alone)
+        if (stopped && !keep_over) a.x &= ~kRecOverflow;
         a.z = __float_as_uint(light);
+        a.w = (stopped && keep_over) ? kAuxStopped : 0u;
         aux[q] = a;
     }
     out[q * K + c] = v;
@@ -1078,7 +1105,8 @@ tail_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, uint4* __restrict__ aux, fl
     const int64_t tile = (int64_t)blockIdx.x + rays.tile0;
     if (wave == 0) {
         const int64_t q0 = ray_of_thread(rays, tile * 64 + lane);
-        const bool ov = q0 < rays.Q && (aux[q0].x & kRecOverflow) != 0u;
+        bool ov = false;
+        if (q0 < rays.Q) { const uint4 a0 = aux[q0]; ov = (a0.x & kRecOverflow) != 0u && a0.w != kAuxStopped; }
         const bool a0 = __any(ov);
         if (lane == 0) any_over = a0 ? 1 : 0;
     }
@@ -1091,7 +1119,8 @@ tail_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, uint4* __restrict__ aux, fl
         const int64_t q = ray_of_thread(rays, t0);
         uint4 a = make_uint4(0u, 0u, 0u, 0u);
         if (q < rays.Q) a = aux[q];
-        bool alive = (a.x & kRecOverflow) != 0u;
+        const bool tail = (a.x & kRecOverflow) != 0u && a.w != kAuxStopped;     // (kAuxStopped: the shade ended the ray by the stop rule)
+        bool alive = tail;
         if (!__any(alive)) continue;
         Ray r;
         float light = 1.f, acc = 0.f, t = 0.f, tmax = -1.f;
@@ -1131,7 +1160,7 @@ tail_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, uint4* __restrict__ aux, fl
                 if (light <= opt.stop_thresh) { stopped = true; alive = false; }
             }
         }
-        if ((a.x & kRecOverflow) == 0u) continue;
+        if (!tail) continue;
         float v;
         if (c < K - 1) {
             v = stopped ? acc * (float)(1.0 / (1.0 - (double)light)) : acc + light * opt.background_brightness;

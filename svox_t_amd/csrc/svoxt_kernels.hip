@@ -378,13 +378,25 @@ bool launch_shade(const TreeDev& tr, const RaysDev& rays, const Opts& opt, float
 #define SVOXT_CHAN(KK)                                                                                        \
         {                                                                                                     \
             const unsigned nbc = (unsigned)(((int64_t)nb * 64 / (64 / KK) + 3) / 4);                          \
+            /* (r05) lists for a backward (!STOP) under a stop threshold: the instance that applies the rule, told to  \
+               keep the overflow flags (the march did not stop: the backward's tail still needs them) */             \
+            const bool stop_rt = !STOP && opt.stop_thresh > 0.f;                                               \
+            if (stop_rt) {                                                                                     \
+                if (fast) hipLaunchKernelGGL((shade_chan_kernel<KK, true, true>), dim3(nbc), dim3(256), 0, st, \
+                                             tr, rays, opt, L, aux, out, 1);                                   \
+                else if (tr.etab != nullptr)                                                                   \
+                    hipLaunchKernelGGL((shade_chan_kernel<KK, true, false, true>), dim3(nbc), dim3(256), 0, st, \
+                                       tr, rays, opt, L, aux, out, 1);                                         \
+                else hipLaunchKernelGGL((shade_chan_kernel<KK, true, false>), dim3(nbc), dim3(256), 0, st,     \
+                                        tr, rays, opt, L, aux, out, 1);                                        \
+            } else                                                                                             \
             if (fast) hipLaunchKernelGGL((shade_chan_kernel<KK, STOP, true>), dim3(nbc), dim3(256), 0, st,    \
-                                         tr, rays, opt, L, aux, out);                                    \
+                                         tr, rays, opt, L, aux, out, 0);                                 \
             else if (tr.etab != nullptr)                                                                      \
                 hipLaunchKernelGGL((shade_chan_kernel<KK, STOP, false, true>), dim3(nbc), dim3(256), 0, st,   \
-                                   tr, rays, opt, L, aux, out);                                          \
+                                   tr, rays, opt, L, aux, out, 0);                                       \
             else hipLaunchKernelGGL((shade_chan_kernel<KK, STOP, false>), dim3(nbc), dim3(256), 0, st,        \
-                                    tr, rays, opt, L, aux, out);                                         \
+                                    tr, rays, opt, L, aux, out, 0);                                      \
             if (fast) hipLaunchKernelGGL((tail_chan_kernel<KK, N2, true>), dim3(nb), dim3(256), 0, st,        \
                                          tr, rays, opt, aux, out, L);                                         \
             else hipLaunchKernelGGL((tail_chan_kernel<KK, N2, false>), dim3(nb), dim3(256), 0, st,            \
@@ -562,8 +574,8 @@ static int check_lists(const svoxt_sample_lists* l, const svoxt_options* opt, co
     if (((uintptr_t)l->tile_state & 7u) != 0) return fail(SVOXT_ERR_INVALID, "%s: lists.tile_state must be 8-byte aligned (64-bit queue entries)", fn);
     if ((l->flags & SVOXT_LISTS_WALK_ROWMAJOR) && (l->flags & SVOXT_LISTS_WALK_SUPER))
         return fail(SVOXT_ERR_INVALID, "%s: lists.flags name two tile walks", fn);
-    if (opt->sigma_thresh != 0.f || opt->stop_thresh != 0.f)
-        return fail(SVOXT_ERR_UNSUPPORTED, "%s: sample lists require sigma_thresh == stop_thresh == 0", fn);
+    // (r05: any thresholds -- the lists hold every sample with sigma > 0, the forward's thresholds decide what it composites)
+    (void)opt;
     return SVOXT_OK;
 }
 
@@ -622,7 +634,7 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
         // SG / ASG with sample lists: only as march + tile shade that leaves the backward's hand-over (svoxt_can_record)
         if (!want_terms || !full_comp(opt) || uses_xform(tree, opt) || tree->weight_accum != nullptr)
             return fail(SVOXT_ERR_UNSUPPORTED, "%s: SG / ASG payloads record sample lists only with lists.terms (the exact per-tile backward's hand-over), all components, no transformation_matrices, no weight accumulation", fn);
-        const uint32_t* smask = (tree->sigma_mask != nullptr && tree->sigma_mask_thresh == opt->sigma_thresh)
+        const uint32_t* smask = (tree->sigma_mask != nullptr && tree->sigma_mask_thresh == 0.f)      // (lists: every sigma > 0)
                                     ? reinterpret_cast<const uint32_t*>(tree->sigma_mask) : nullptr;
         uint4* aux = reinterpret_cast<uint4*>(lists->aux);
         int32_t* states = (lists->blocktab != nullptr && !(lflags & SVOXT_LISTS_FWD_NO_OVERLAP))
@@ -635,8 +647,9 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
     if (fwd_split_enabled(tree, opt, want_terms, lflags) && full_comp(opt) && fwd_split_payload(tree, opt, C) &&
         (!uses_xform(tree, opt) || xform_special(tree, opt))) {
         const bool xf = uses_xform(tree, opt);
-        // one bit per feature row, built for this feature table and this sigma_thresh (else ignored)
-        const uint32_t* smask = (tree->sigma_mask != nullptr && tree->sigma_mask_thresh == opt->sigma_thresh)
+        // one bit per feature row, built for this feature table and this sigma_thresh (else ignored); lists for a
+        // backward hold every sample with sigma > 0: their march wants the mask of threshold 0
+        const uint32_t* smask = (tree->sigma_mask != nullptr && tree->sigma_mask_thresh == (lists != nullptr ? 0.f : opt->sigma_thresh))
                                     ? reinterpret_cast<const uint32_t*>(tree->sigma_mask) : nullptr;
         // (tile states: march and shade as ONE launch; pooled lists only -- their fill clears the states too)
         auto states = [&](const svoxt_sample_lists* l) -> int32_t* {
@@ -791,7 +804,7 @@ int svoxt_fwd_fills_terms(const svoxt_tree* tree, const svoxt_options* opt, int3
 
 int svoxt_can_record(const svoxt_tree* tree, const svoxt_options* opt) {
     if (tree == nullptr || opt == nullptr) return 0;
-    if (opt->sigma_thresh != 0.f || opt->stop_thresh != 0.f || !full_comp(opt)) return 0;
+    if (!full_comp(opt)) return 0;        // (r05: any thresholds)
     if (uses_xform(tree, opt)) return xform_special(tree, opt) ? 1 : 0;
     const int C = svoxt_out_data_dim(opt, tree->K) - 1;
     if (opt->format == SVOXT_FORMAT_RGBA) return (C == 3 || C == 7 || C == 15 || C == 31) ? 1 : 0;
@@ -821,6 +834,9 @@ int svoxt_volume_render_bwd_replay(const svoxt_tree* tree, const svoxt_rays* ray
     if (grad_cols < 2) return fail(SVOXT_ERR_INVALID, "%s: grad_cols must be C+1 >= 2", fn);
     if (opt == nullptr) return fail(SVOXT_ERR_INVALID, "%s: options is NULL", fn);
     if ((rc = check_lists(lists, opt, fn))) return rc;
+    if (fwd_out != nullptr && (opt->sigma_thresh != 0.f || opt->stop_thresh != 0.f))
+        return fail(SVOXT_ERR_UNSUPPORTED, "%s: fwd_out (the single-march backward) needs sigma_thresh == stop_thresh == 0: "
+                    "with thresholds the forward's output is not the sum the backward differentiates", fn);
     return bwd_common(tree, rays, opt, grad_out, grad_cols, grad_features, grad_stride, nullptr, 0, lists, fwd_out,
                       stream, fn);
 }

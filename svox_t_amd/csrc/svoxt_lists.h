@@ -27,11 +27,16 @@ constexpr int kBlock = 64;
 // REC: also record every composited sample as (feature row, delta_t) in
 // rec[k][q] (k < S) and, per ray, aux[q] = {count | overflow << 31, t at which
 // the first unrecorded sample starts}, for svoxt_volume_render_bwd_replay.
-// REC requires sigma_thresh == stop_thresh == 0 (the backward ignores both,
-// rt_kernel.cu:382,456); the march is then not cut short when the
+// REC records every sample with sigma > 0 whatever the thresholds (the backward ignores both,
+// rt_kernel.cu:382,456; r05: the forward's thresholds then only decide what is COMPOSITED); the march is then not cut short when the
 // transmittance underflows to exactly 0 -- the remaining samples have weight
 // 0 and leave the output bits unchanged, but they belong in the list.
 constexpr uint32_t kRecOverflow = 0x80000000u;
+// (r05) aux[q].w between a recording forward's shade and its tail launch: the shade ended the ray's COMPOSITING by the
+// stop rule (T <= stop_thresh, rt_kernel.cu:313-319) and has written the pixel; the forward's tail leaves the ray alone,
+// the overflow flag stays for the backward's tail (which marches every sample with sigma > 0 the list could not hold).
+// 0 otherwise; the backward's tail-only launch later overwrites .z / .w of overflowed rays with its pass-1 results.
+constexpr uint32_t kAuxStopped = 1u;
 
 // Records are written once and read once or twice, much later: non-temporal
 // accesses keep them from displacing the tree and the feature table in L2 /

@@ -42,14 +42,16 @@ opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
     const int K = tr.K;
     float light = 1.f, t = r.tmin;
     int nrec = 0;
-    bool over = false;
+    bool over = false, stopped = false;
     float t_resume = 0.f;
     while (t < r.tmax) {
         Sample s;
         march_step<N2>(tr, r, opt.step_size, t, s);
         if (s.valid) {
             const float sigma = tr.features[(int64_t)s.idx * K + (K - 1)];
-            if (sigma > opt.sigma_thresh) {
+            // (REC, r05: every sigma > 0 is recorded -- the backward's set, rt_kernel.cu:382 -- and composited only by the
+            // forward's own rules: sigma > sigma_thresh, not after T <= stop_thresh)
+            if (sigma > (REC ? 0.f : opt.sigma_thresh)) {
                 if constexpr (REC) {
                     bool room = nrec < S;
                     if (room && (nrec & 7) == 0) {
@@ -64,9 +66,12 @@ opacity_fwd_kernel(TreeDev tr, RaysDev rays, Opts opt, float* __restrict__ out,
                         t_resume = t;
                     }
                 }
-                light *= pexpf(-s.delta_t * r.delta_scale * sigma);
-                if constexpr (!REC) {
-                    if (light <= opt.stop_thresh) break;
+                if (!REC || (sigma > opt.sigma_thresh && !stopped)) {
+                    light *= pexpf(-s.delta_t * r.delta_scale * sigma);
+                    if (light <= opt.stop_thresh) {
+                        if constexpr (!REC) break;
+                        stopped = true;
+                    }
                 }
             }
         }

@@ -976,6 +976,7 @@ def test_overflow_word_of_pooled_lists(gpu, monkeypatch):
     gw, ab = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.numpy(), want_abs=True)
     for cap, word in ((96, -1), (8, 1)):
         monkeypatch.setattr(_C, "BWD_LIST_SAMPLES", cap)
+        _C._POOL_HINT.clear()       # (a pool sized by another test's batch of this shape may run dry: that is an overflow too)
         out, lists = _C.volume_render(spec, rs, opt, record=True)
         torch.cuda.synchronize()
         over = int((lists.aux[:, 0] < 0).sum())                    # bit 31 of aux.x: the ray's list overflowed
