@@ -5,7 +5,7 @@
 #   scripts/profile_round.sh <outdir under gpurun_out> [a|b|all]     then copy what is to be judged into profiles/
 #   (a: the headline config and the f-rows; b: configs[3], exact and native math)
 set -u
-ROUND=r04      # = bench.py's ROUND
+ROUND=r05      # = bench.py's ROUND
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-prof}
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -45,7 +45,6 @@ bench d8_sh9_800_fwd --forward-only
 bench d8_sh9_800_camera --route camera --no-plain
 stats d8_sh9_800_plain --route plain
 SVOXT_BWD_EXACT=0 bench d8_sh9_800_single_march --no-plain
-SVOXT_LIST_POOL=0 bench d8_sh9_800_dense_lists --no-plain
 # configs[0]: the reference's own CPU-runnable case
 bench d5_rgba_64_fwd --workload d5_rgba_64 --forward-only
 # the rows SURVEY.md 8(f) added around the path, on this round's kernels

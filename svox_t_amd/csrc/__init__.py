@@ -32,177 +32,29 @@ import weakref
 
 import torch
 
-_HERE = os.path.dirname(os.path.abspath(__file__))
-# SVOXT_LIB: load another build of the same ABI (kernel experiments); default in-tree.
-LIB_PATH = os.environ.get("SVOXT_LIB") or os.path.join(_HERE, "libsvoxt_hip.so")
-
-if not os.path.exists(LIB_PATH):
-    raise ImportError(
-        f"{LIB_PATH} not found: the HIP extension is not built. "
-        "Run `python svox_t_amd/build.py` (needs hipcc; cross-compiles for gfx950).")
-
-_lib = ctypes.CDLL(LIB_PATH)
-
-ABI_VERSION = 20
-FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
-
-
-class _CTree(ctypes.Structure):          # struct svoxt_tree
-    _fields_ = [
-        ("features", ctypes.c_void_p), ("M", ctypes.c_int64),
-        ("K", ctypes.c_int32), ("N", ctypes.c_int32),
-        ("data", ctypes.c_void_p), ("child", ctypes.c_void_p),
-        ("n_internal", ctypes.c_int64),
-        ("offset", ctypes.c_void_p), ("scaling", ctypes.c_void_p),
-        ("extra_data", ctypes.c_void_p),
-        ("extra_rows", ctypes.c_int32), ("extra_cols", ctypes.c_int32),
-        ("weight_accum", ctypes.c_void_p), ("xform", ctypes.c_void_p),
-        ("accel", ctypes.c_void_p), ("accel_log2", ctypes.c_int32),
-        ("xform_dim", ctypes.c_int32),
-        ("sigma_mask", ctypes.c_void_p), ("sigma_mask_thresh", ctypes.c_float), ("reserved0", ctypes.c_int32),
-        ("exp_table", ctypes.c_void_p),
-    ]
-
-
-class _CRays(ctypes.Structure):          # struct svoxt_rays
-    _fields_ = [("origins", ctypes.c_void_p), ("dirs", ctypes.c_void_p),
-                ("vdirs", ctypes.c_void_p), ("Q", ctypes.c_int64),
-                ("image_width", ctypes.c_int32), ("image_height", ctypes.c_int32),
-                ("c2w", ctypes.c_void_p), ("fx", ctypes.c_float), ("fy", ctypes.c_float),
-                ("order", ctypes.c_void_p)]
-
-
-class _CMotion(ctypes.Structure):        # struct svoxt_motion
-    _fields_ = [("joint_features", ctypes.c_void_p), ("n_joints", ctypes.c_int32),
-                ("feature_dim", ctypes.c_int32), ("skinning_weights", ctypes.c_void_p),
-                ("joint_index", ctypes.c_void_p), ("n_bind", ctypes.c_int32)]
-
-
-class _COptions(ctypes.Structure):       # struct svoxt_options
-    _fields_ = [
-        ("step_size", ctypes.c_float), ("background_brightness", ctypes.c_float),
-        ("format", ctypes.c_int32), ("basis_dim", ctypes.c_int32),
-        ("ndc_width", ctypes.c_int32), ("ndc_height", ctypes.c_int32),
-        ("ndc_focal", ctypes.c_float),
-        ("min_comp", ctypes.c_int32), ("max_comp", ctypes.c_int32),
-        ("sigma_thresh", ctypes.c_float), ("stop_thresh", ctypes.c_float),
-    ]
-
-
-class _CLists(ctypes.Structure):         # struct svoxt_sample_lists
-    _fields_ = [("rec", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("max_samples", ctypes.c_int32),
-                ("coef", ctypes.c_void_p), ("coef_bytes", ctypes.c_int64),
-                ("terms", ctypes.c_void_p), ("terms_bytes", ctypes.c_int64),
-                ("blocktab", ctypes.c_void_p), ("pool_blocks", ctypes.c_int64), ("pool_next", ctypes.c_void_p),
-                ("terms_state", ctypes.c_int32), ("flags", ctypes.c_int32), ("tile_state", ctypes.c_void_p)]
-
-
-# svoxt_sample_lists.flags (include/svoxt.h)
-LISTS_NATIVE_MATH, LISTS_FWD_ONE_KERNEL, LISTS_FWD_TWO_KERNELS, LISTS_FWD_NO_OVERLAP, LISTS_GRAD_ZEROED, LISTS_BEGUN = 1, 2, 4, 8, 16, 32
-LISTS_TEST_DROP, LISTS_TEST_NOPOLL, LISTS_TEST_STALE, LISTS_FWD_AGENT_FENCE = 256, 512, 1024, 2048
-
-
-_P = ctypes.POINTER
-_vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
-
-# Every symbol include/svoxt.h declares, with its signature.
-EXPORTS = {
-    "svoxt_abi_version": (ctypes.c_int, []),
-    "svoxt_last_error": (ctypes.c_char_p, []),
-    "svoxt_out_data_dim": (ctypes.c_int, [_P(_COptions), _i32]),
-    "svoxt_volume_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
-    "svoxt_fwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
-    "svoxt_volume_render_fwd_ws": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _i64, _i32, _vp]),
-    "svoxt_volume_render_fwd_scratch": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _P(_CLists), _i32, _vp]),
-    "svoxt_volume_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _vp, _i64, _vp]),
-    "svoxt_bwd_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
-    "svoxt_can_record": (ctypes.c_int, [_P(_CTree), _P(_COptions)]),
-    "svoxt_fwd_fills_terms": (ctypes.c_int, [_P(_CTree), _P(_COptions), _i32]),
-    "svoxt_sigma_mask_bytes": (ctypes.c_int64, [ctypes.c_int64]),
-    "svoxt_sigma_mask_build": (ctypes.c_int, [_P(_CTree), ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
-    "svoxt_sigma_mask_build_fill": (ctypes.c_int, [_P(_CTree), ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, _i64,
-                                                   ctypes.c_void_p]),
-    "svoxt_exp_table_build": (ctypes.c_int, [_P(_CTree), ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
-    "svoxt_compact_rows": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
-    "svoxt_compact_rows_clear": (ctypes.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
-    "svoxt_query_leaves_workspace_bytes": (ctypes.c_int64, [_i64]),
-    "svoxt_query_leaves": (ctypes.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
-    "svoxt_volume_render_fwd_record": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _P(_CLists), _vp]),
-    "svoxt_volume_render_bwd_replay": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _i32, _vp, _i32, _P(_CLists), _vp, _vp]),
-    "svoxt_opacity_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
-    "svoxt_opacity_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp]),
-    "svoxt_opacity_render_fwd_record": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _P(_CLists), _vp]),
-    "svoxt_opacity_render_bwd_replay": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp,
-                                                        ctypes.c_int32, _P(_CLists), _vp]),
-    "svoxt_render_depth": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
-    "svoxt_query_fwd": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "svoxt_query_bwd": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp, _vp, _vp]),
-    "svoxt_count_fwd": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp]),
-    "svoxt_count_touched": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp, _vp]),
-    "svoxt_set_bwd_counters": (ctypes.c_int, [_vp]),
-    "svoxt_set_bwd_check": (ctypes.c_int, [_vp]),
-    "svoxt_set_super_tile_rows": (_i64, [_i64]),
-    "svoxt_image_walk": (_i32, [_P(_CTree), _P(_CRays)]),
-    "svoxt_ray_order_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64]),
-    "svoxt_ray_order": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, ctypes.c_int64, _vp]),
-    "svoxt_gather_rays": (ctypes.c_int, [_P(_CRays), _vp, _vp, _vp, _vp, _vp]),
-    "svoxt_permute_rows": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _vp]),
-    "svoxt_accel_bytes": (ctypes.c_int64, [_i32, ctypes.c_int64]),
-    "svoxt_accel_build": (ctypes.c_int, [_P(_CTree), _i32, _vp, _vp]),
-    "svoxt_build_workspace_bytes": (ctypes.c_int64, [_i32]),
-    "svoxt_build_count": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp]),
-    "svoxt_build_emit": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
-    "svoxt_construct_tree": (ctypes.c_int, [_P(_CTree), _vp, _i64, _vp]),
-    "svoxt_refine": (ctypes.c_int, [_vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "svoxt_motion_render": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _vp, _vp, _vp]),
-    "svoxt_warp_vertices": (ctypes.c_int, [_vp, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
-    "svoxt_warp_vertices_bwd": (ctypes.c_int, [_vp, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "svoxt_motion_workspace_bytes": (ctypes.c_int64, [_i64, _i32]),
-    "svoxt_motion_feature_render_fwd": (ctypes.c_int, [_P(_CTree), _P(_CMotion), _P(_CRays), _P(_COptions), _vp, _vp, _i64, _vp]),
-    "svoxt_motion_feature_render_bwd": (ctypes.c_int, [_P(_CTree), _P(_CMotion), _P(_CRays), _P(_COptions), _vp, _vp, _vp, _i64, _vp]),
-}
-for _name, (_res, _args) in EXPORTS.items():
-    _fn = getattr(_lib, _name)       # AttributeError here = library/header mismatch
-    _fn.restype = _res
-    _fn.argtypes = _args
-
-if _lib.svoxt_abi_version() != ABI_VERSION:
-    raise ImportError(f"{LIB_PATH}: ABI version {_lib.svoxt_abi_version()} != {ABI_VERSION}; rebuild")
+from ._abi import (ABI_VERSION, EXPORTS, FORMAT_ASG, FORMAT_RGBA, FORMAT_SG, FORMAT_SH, LIB_PATH, LISTS_BEGUN, LISTS_FWD_AGENT_FENCE,
+                   LISTS_FWD_NO_OVERLAP, LISTS_FWD_ONE_KERNEL, LISTS_FWD_TWO_KERNELS, LISTS_GRAD_ZEROED, LISTS_NATIVE_MATH,
+                   LISTS_TEST_DROP, LISTS_TEST_NOPOLL, LISTS_TEST_STALE, _CLists, _CMotion, _COptions, _CRays, _CTree, _lib)
+from ._marshal import (ACCEL_LOG2, CameraSpec, RaysSpec, RenderOptions, TreeSpec, _ACCEL_CACHE, _accel_for, _accel_log2_for,
+                       _call, _check_input, _numel, _pack_camera, _pack_opts, _pack_rays, _pack_tree, _pack_tree_accel, _ptr,
+                       _stream, get_out_data_dim)
 
 
 # ---------------------------------------------------------------------------
-# Switches.  Every SVOXT_* environment variable this package knows is read HERE, once, at import (the
-# library itself reads none); the module attributes below are what the code consults, so a test or a
-# caller changes behaviour by assigning to them.  README.md has the table (default, result-neutral or not).
+# Switches.  Five environment variables, read HERE once at import (the library itself reads none): SVOXT_LIB
+# (_abi.py: another build of the same ABI), SVOXT_ACCEL_LOG2 (_marshal.py), SVOXT_SORT_RAYS, and the two TOLERANCE modes
+# SVOXT_BWD_EXACT / SVOXT_NATIVE_MATH.  Everything else below is a module attribute that tests assign to take a
+# route the defaults do not (a cross-check of one kernel family against another: all result-neutral) -- r05: they were
+# environment switches too until then, fifteen in all.  README.md has the table.
 # ---------------------------------------------------------------------------
 def _env_flag(name: str, default: str) -> bool:
     return os.environ.get(name, default) not in ("", "0")
 
 
-# acceleration-grid resolution: None = chosen from the tree size, 0 = no grid, g = 2^g cells per axis (<= 8)
-ACCEL_LOG2 = (lambda v: None if v is None else max(0, min(8, int(v))))(os.environ.get("SVOXT_ACCEL_LOG2"))
-# SVOXT_SIGMA_MASK=0: the two-kernel forward's march gathers sigma instead of reading a bit per feature row
-SIGMA_MASK = _env_flag("SVOXT_SIGMA_MASK", "1")
-# Samples kept per ray for the backward (8 bytes each; rays with more composited samples march the
-# remainder, so this only trades memory for speed).  0 = never record: the backward traverses the tree itself.
-BWD_LIST_SAMPLES = int(os.environ.get("SVOXT_BWD_LIST", "96"))
-# The same for a forward nobody differentiates: scratch lists for the two-kernel forward
-# (0 = always the one-kernel forward, svoxt_volume_render_fwd).
-FWD_LIST_SAMPLES = int(os.environ.get("SVOXT_FWD_LIST", "96"))
-# SVOXT_LIST_POOL=0: dense sample lists (every ray owns `cap` slots) instead of 4 KB blocks from a pool
-LIST_POOL = _env_flag("SVOXT_LIST_POOL", "1")
-# SVOXT_AUTO_PLAN=0: plain volume_render / volume_render_backward calls hand nothing from forward to backward
-AUTO_PLAN = _env_flag("SVOXT_AUTO_PLAN", "1")
 # SVOXT_SORT_RAYS: "auto" (batches that are not images are rendered in svoxt_ray_order's order from
 # SORT_RAYS_MIN rays on), "0" never, "1" always; RaysSpec.sort per call
 SORT_RAYS = os.environ.get("SVOXT_SORT_RAYS", "auto")
 SORT_RAYS_MIN = 16384
-# SVOXT_FWD_SPLIT: "" = the library's default per payload, "0" / "1" = the forward as one kernel / as march +
-# shade kernels wherever both exist (handed to the library as svoxt_sample_lists.flags)
-FWD_SPLIT = os.environ.get("SVOXT_FWD_SPLIT", "")
-# SVOXT_BWD_GATHER: 0 = always the per-ray backward, 1 (default) = the per-tile one (grad_fused_kernel /
-# grad_wide_kernel) for batches declared as images or rendered in svoxt_ray_order's order, 2 = whenever the payload allows
-BWD_GATHER = int(os.environ.get("SVOXT_BWD_GATHER", "1") or 0)
 # --- the two TOLERANCE modes (not result-neutral; both off by default)
 # SVOXT_BWD_EXACT=0: the single-march backward -- accum = sum_c g_c * out_c from the forward's output, one
 # sweep over the lists instead of two: equal up to the rounding of that sum, which moves 36 % of the
@@ -212,19 +64,20 @@ BWD_EXACT = _env_flag("SVOXT_BWD_EXACT", "1")
 # reciprocal (forward and per-tile backward; include/svoxt.h SVOXT_LISTS_NATIVE_MATH); the stepping stays
 # bit-exact.  Outputs within 1e-5 relative, gradients within 1e-5 of the tight scale (tested at full size).
 NATIVE_MATH = _env_flag("SVOXT_NATIVE_MATH", "0")
-# SVOXT_FWD_OVERLAP=0: march and shade of the two-kernel forward as two launches instead of one grid that
-# carries both roles (include/svoxt.h, svoxt_sample_lists.tile_state); result-neutral
-FWD_OVERLAP = _env_flag("SVOXT_FWD_OVERLAP", "1")
-# RGBA-style rows of 8 / 16 / 32 floats, exact mode: the forward builds a table of the rows' exponentials in the pass that
-# builds the sigma bitmask (include/svoxt.h, svoxt_tree.exp_table: the sigmoids of such a payload do not depend on the
-# view); its shade kernel and both sweeps of the per-tile backward read that instead of forming one exponential per
-# sample and channel.  Result-neutral (the same bits); costs M * K * 4 bytes per outstanding forward.  SVOXT_EXP_TABLE=0: off
-EXP_TABLE = _env_flag("SVOXT_EXP_TABLE", "1")
-# --- not environment switches: routes the tests exercise by assignment
-BWD_TERMS = True     # False: no hand-over between the sweeps of the exact backwards (every row gathered twice)
-BWD_FUSED = True     # False: list walk and per-tile merge of an image's backward as two kernels
-BWD_XF_FUSED = True  # False: view rotations (transformation_matrices) through the two-kernel form they took until r04
-ROLES_FLAGS = 0      # OR of LISTS_TEST_* / LISTS_FWD_AGENT_FENCE: test and measurement switches of the one-launch forward
+# --- test attributes (result-neutral routes; no environment variable)
+SIGMA_MASK = True         # False: the two-kernel forward's march gathers sigma instead of reading a bit per feature row
+BWD_LIST_SAMPLES = 96     # samples kept per ray for the backward (8 bytes each; longer rays march the rest); 0: never record
+FWD_LIST_SAMPLES = 96     # the same for the scratch lists of a forward nobody differentiates; 0: always the one-kernel forward
+LIST_POOL = True          # False: dense sample lists (every ray owns `cap` slots) instead of 4 KB blocks from a pool
+AUTO_PLAN = True          # False: plain volume_render / volume_render_backward calls hand nothing from forward to backward
+FWD_SPLIT = ""            # "0" / "1": the forward as one kernel / as march + shade wherever both exist ("": the library's default)
+BWD_GATHER = 1            # 0: always the per-ray backward; 1: the per-tile one for images / sorted batches; 2: whenever the payload allows
+FWD_OVERLAP = True        # False: march and shade of the two-kernel forward as two launches instead of fwd_roles_kernel
+EXP_TABLE = True          # False: rows of 8 / 16 / 32 floats without the per-row exponentials table (svoxt_tree.exp_table)
+BWD_TERMS = True          # False: no hand-over between the sweeps of the exact backwards (every row gathered twice)
+BWD_FUSED = True          # False: list walk and per-tile merge of an image's backward as two kernels
+BWD_XF_FUSED = True       # False: view rotations (transformation_matrices) through the two-kernel form they took until r04
+ROLES_FLAGS = 0           # OR of LISTS_TEST_* / LISTS_FWD_AGENT_FENCE: test and measurement switches of the one-launch forward
 
 
 def _list_flags(native: bool = False) -> int:
@@ -239,224 +92,6 @@ def _list_flags(native: bool = False) -> int:
 
 
 # ---------------------------------------------------------------------------
-# Spec classes (svox.cpp:74-117): default-constructed, read/write attributes.
-# ---------------------------------------------------------------------------
-
-class RaysSpec:
-    def __init__(self):
-        self.origins = None
-        self.dirs = None
-        self.vdirs = None
-        # optional (not in the reference): the batch is a row-major image of this
-        # size; the kernels then walk it in 8x8 tiles.  0 = unknown.
-        self.image_width = 0
-        self.image_height = 0
-        # optional (not in the reference): render the batch in svoxt_ray_order's order (True / False;
-        # None = decide by size, SORT_RAYS below) / the batch already is in such an order
-        self.sort = None
-        self.coherent = False
-        # optional (not in the reference): int32 [Q] permutation (svoxt_ray_order's); launch thread i then works
-        # on ray order[i] -- the batch is walked in that order, nothing is gathered or scattered
-        self.order = None
-
-
-class TreeSpec:
-    def __init__(self):
-        self.features = None
-        self.data = None
-        self.child = None
-        self.parent_depth = None
-        self.extra_data = None
-        self.offset = None
-        self.scaling = None
-        self._weight_accum = None
-        self.joint_features = None
-        self.skinning_weights = None
-        self.joint_index = None
-        self.n_internal = 0
-        self.transformation_matrices = None
-        # optional (not in the reference): the caller's promise that `features` is not written behind
-        # torch's back (through `.data`, a raw pointer, a storage swap) while this tree is rendered, so that
-        # data derived from its CONTENT (the sigma bitmask) may be cached across forwards on the tensor's
-        # version counter.  False: such data is rebuilt by every forward.  N3Tree.static_features sets it.
-        self.static_features = False
-
-
-class CameraSpec:
-    def __init__(self):
-        self.c2w = None
-        self.fx = 0.0
-        self.fy = 0.0
-        self.width = 0
-        self.height = 0
-
-
-class RenderOptions:
-    def __init__(self):
-        self.step_size = 0.0
-        self.background_brightness = 0.0
-        self.format = 0
-        self.basis_dim = 0
-        self.ndc_width = 0
-        self.ndc_height = 0
-        self.ndc_focal = 0.0
-        self.min_comp = 0
-        self.max_comp = 0
-        self.sigma_thresh = 0.0
-        self.stop_thresh = 0.0
-
-
-# ---------------------------------------------------------------------------
-# Marshalling
-# ---------------------------------------------------------------------------
-
-def _check_input(x, name):
-    """CHECK_INPUT (data_spec.hpp:38-43)."""
-    if not isinstance(x, torch.Tensor):
-        raise RuntimeError(f"{name} must be a tensor")
-    if not x.is_cuda:
-        raise RuntimeError(f"{name} must be a CUDA tensor")
-    if not x.is_contiguous():
-        raise RuntimeError(f"{name} must be contiguous")
-
-
-def _numel(x):
-    return 0 if x is None else x.numel()
-
-
-def _ptr(x):
-    return None if (x is None or x.numel() == 0) else x.data_ptr()
-
-
-def _pack_tree(tree: TreeSpec) -> _CTree:
-    """TreeSpec.check() (data_spec.hpp:85-110) + pointer extraction."""
-    _check_input(tree.features, "features")
-    _check_input(tree.data, "data")
-    _check_input(tree.child, "child")
-    if tree.parent_depth is not None:
-        _check_input(tree.parent_depth, "parent_depth")
-    _check_input(tree.offset, "offset")
-    _check_input(tree.scaling, "scaling")
-    for nm in ("extra_data", "_weight_accum", "joint_features", "skinning_weights",
-               "joint_index", "transformation_matrices"):
-        t = getattr(tree, nm)
-        if _numel(t):
-            _check_input(t, nm)
-    if tree.features.dtype != torch.float32 or tree.features.dim() != 2:
-        raise RuntimeError("features must be a float32 [M, K] tensor")
-    if tree.child.dtype != torch.int32 or tree.child.dim() != 4:
-        raise RuntimeError("child must be an int32 [n, N, N, N] tensor")
-    if tree.data.dtype != torch.int32 or tree.data.numel() != tree.child.numel():
-        raise RuntimeError("data must be an int32 [n, N, N, N, 1] tensor matching child")
-    if tree.offset.dtype != torch.float32 or tree.scaling.dtype != torch.float32 \
-            or tree.offset.numel() != 3 or tree.scaling.numel() != 3:
-        raise RuntimeError("offset / scaling must be float32 tensors of 3 elements")
-    dev = tree.features.device
-    for nm in ("data", "child", "offset", "scaling"):
-        if getattr(tree, nm).device != dev:
-            raise RuntimeError(f"{nm} must be on the same device as features")
-    n_internal = int(tree.n_internal) if tree.n_internal else tree.child.shape[0]
-    if n_internal > tree.child.shape[0]:
-        raise RuntimeError("n_internal exceeds the capacity of child")
-    c = _CTree()
-    c.features = _ptr(tree.features)
-    c.M, c.K = tree.features.shape
-    c.N = tree.child.shape[1]
-    c.data = tree.data.data_ptr()
-    c.child = tree.child.data_ptr()
-    c.n_internal = n_internal
-    c.offset = tree.offset.data_ptr()
-    c.scaling = tree.scaling.data_ptr()
-    if _numel(tree.extra_data):
-        if tree.extra_data.dtype != torch.float32 or tree.extra_data.dim() != 2:
-            raise RuntimeError("extra_data must be a float32 2-D tensor")
-        c.extra_data = tree.extra_data.data_ptr()
-        c.extra_rows, c.extra_cols = tree.extra_data.shape
-    if _numel(tree._weight_accum):
-        if tree._weight_accum.dtype != torch.float32 or \
-                tree._weight_accum.numel() != tree.child.numel():
-            raise RuntimeError("_weight_accum must be float32 with one entry per leaf slot")
-        c.weight_accum = tree._weight_accum.data_ptr()
-    if _numel(tree.transformation_matrices):
-        x = tree.transformation_matrices
-        if x.dtype != torch.float32 or x.dim() != 3 or x.shape[0] != tree.features.shape[0] or \
-                tuple(x.shape[1:]) not in ((3, 3), (4, 4)):
-            raise RuntimeError("transformation_matrices must be float32 [M, 3, 3] or [M, 4, 4]")
-        _check_input(x, "transformation_matrices")
-        c.xform = x.data_ptr()
-        c.xform_dim = x.shape[1]
-    return c
-
-
-# ---------------------------------------------------------------------------
-# Acceleration grid cache.  The grid (include/svoxt.h, svoxt_accel_build) is
-# derived from the *contents* of child and data.  An entry therefore hangs off
-# the `child` tensor OBJECT (weakly: it dies with the tensor, so a recycled
-# device address can never alias a stale grid) and is valid only while the torch
-# version counters of child and data are unchanged (every in-place torch op
-# bumps them, as N3Tree.refine / construct_tree do) and `data` is the same
-# tensor object.  A writer that bypasses the version counter (`child.data[...] = v`, a kernel of its own)
-# must call invalidate_caches(); N3Tree.refine / construct_tree / parallel.broadcast_tree do.
-# ACCEL_LOG2 (SVOXT_ACCEL_LOG2) = 0 disables the grid, = g forces a resolution; default: chosen from the tree size.
-# ---------------------------------------------------------------------------
-_ACCEL_CACHE: dict = {}     # id(child tensor) -> (weakref to it, ...); entries are dropped when the tensor dies
-
-
-def _accel_log2_for(n_internal: int, N: int, feature_bytes: int = 0) -> int:
-    if ACCEL_LOG2 is not None:
-        return ACCEL_LOG2
-    if N != 2 or n_internal < 64:
-        return 0
-    slots = n_internal * 8
-    # the smallest grid with at least as many cells as the tree has leaf slots
-    # (D=8 shell tree: 128^3 cells = 16 MiB against 7.6 MiB of topology) ...
-    g = max(4, min(7, -(-slots.bit_length() // 3)))
-    # ... and one level finer (256^3 = 64 MiB of 4-byte cells at most) while cells, node pairs and the feature table
-    # still fit the 256 MiB Infinity Cache together: every leaf crossing of a depth-8 tree is then ONE
-    # dependent load instead of two (r02, 800x800 on the depth-8 tree: forward 0.246 -> 0.226 ms;
-    # with a backward behind it no change, 972 Mrays/s either way).  Past the cache the finer grid
-    # loses (depth 9, 578 MB of features: 805 -> 794 Mrays/s forward).
-    finer = 4 * (1 << (3 * (g + 1))) + 64 * n_internal
-    if g + 1 <= 8 and feature_bytes > 0 and finer + feature_bytes <= 224 * (1 << 20):
-        g += 1
-    return g
-
-
-def _accel_for(tree: TreeSpec, ct: _CTree):
-    g = _accel_log2_for(ct.n_internal, ct.N, tree.features.numel() * tree.features.element_size())
-    if g == 0 or ct.N != 2 or max(ct.M, ct.n_internal) >= (1 << 27) - 1:       # (4-byte cells: 27 index bits)
-        return None, 0
-    key = id(tree.child)
-    ent = _ACCEL_CACHE.get(key)
-    if ent is not None:
-        cref, cv, dref, dv, n_int, eg, cells = ent
-        if cref() is tree.child and cv == (tree.child._version, tree.child.data_ptr()) and dref() is tree.data \
-                and dv == (tree.data._version, tree.data.data_ptr()) and n_int == ct.n_internal and eg == g:
-            return cells, g
-    dev = tree.child.device
-    with torch.cuda.device(dev):
-        nbytes = _lib.svoxt_accel_bytes(g, ct.n_internal)       # grid cells + (child, data) pairs
-        cells = torch.empty((nbytes // 8, 2), dtype=torch.int32, device=dev)
-        _call("svoxt_accel_build", ctypes.byref(ct), g, _ptr(cells), _stream(dev))
-    # (versions AND data pointers: `tensor.data = other` swaps the storage without touching the version counter)
-    _ACCEL_CACHE[key] = (weakref.ref(tree.child, lambda _r, _k=key: _ACCEL_CACHE.pop(_k, None)),
-                         (tree.child._version, tree.child.data_ptr()), weakref.ref(tree.data),
-                         (tree.data._version, tree.data.data_ptr()), ct.n_internal, g, cells)
-    return cells, g
-
-
-def _pack_tree_accel(tree: TreeSpec) -> _CTree:
-    """_pack_tree + the (cached) acceleration grid for the marching kernels."""
-    ct = _pack_tree(tree)
-    cells, g = _accel_for(tree, ct)
-    if cells is not None:
-        ct.accel = cells.data_ptr()
-        ct.accel_log2 = g
-        ct._keepalive = cells
-    return ct
-
-
-# ---------------------------------------------------------------------------
 # Sigma bitmask (include/svoxt.h, svoxt_sigma_mask_build): one bit per feature row, for the march of
 # the two-kernel forward.  Derived from the CONTENT of `features`, which torch's version counter does not
 # vouch for: `param.data.add_(...)` and `tree.features.data[key] = v` -- the reference's own idiom --
@@ -465,7 +100,7 @@ def _pack_tree_accel(tree: TreeSpec) -> _CTree:
 # table of depth 9), inside whatever the caller times -- unless the caller has declared the table static
 # (TreeSpec.static_features, set by N3Tree.static_features = True: an inference server's frozen tree):
 # then it is cached on the tensor object, its version counter and its data pointer like the
-# acceleration grid.  SIGMA_MASK (SVOXT_SIGMA_MASK=0) False: never.  (r02: depth 9 / 578 MB of features,
+# acceleration grid.  SIGMA_MASK False: never.  (r02: depth 9 / 578 MB of features,
 # forward 1.29 -> 1.05 ms; depth 8 / 66 MB, where the gather still hits the Infinity Cache,
 # forward+backward 955 -> 972 Mrays/s with the rebuild inside the step.)
 _SIGMA_CACHE: dict = {}
@@ -535,11 +170,11 @@ def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool, ta
     return etab
 
 
-# SVOXT_GRAD_SCRATCH=0: every backward over sample lists allocates and fills its padded gradient buffer itself.
+# GRAD_SCRATCH False (test attribute): every backward over sample lists allocates and fills its padded gradient buffer itself.
 # Default: the padded [M, stride] buffer the atomics go to is kept between steps (per device, stream and shape)
 # and svoxt_compact_rows_clear leaves it zeroed while it produces the dense gradient: one fill of M * stride
 # floats per step less; result-neutral
-GRAD_SCRATCH = _env_flag("SVOXT_GRAD_SCRATCH", "1")
+GRAD_SCRATCH = True
 _GRAD_SCRATCH: dict = {}      # (device, stream, M, stride) -> [buffer, known to be all zeros]
 
 
@@ -575,81 +210,6 @@ def invalidate_caches(*tensors) -> None:
             torch.autograd.graph.increment_version(t)
 
 
-def _pack_camera(cam: "CameraSpec") -> _CRays:
-    """CameraSpec.check() (data_spec.hpp:120-125): the ray batch is the image of a
-    pinhole camera; the kernels generate the rays themselves."""
-    _check_input(cam.c2w, "c2w")
-    if not cam.c2w.is_floating_point() or cam.c2w.dim() != 2 or cam.c2w.shape[1] != 4:
-        raise RuntimeError("c2w must be a floating point [3 or 4, 4] matrix")
-    if cam.c2w.dtype != torch.float32 or cam.c2w.shape[0] < 3:
-        raise RuntimeError("c2w must be float32 with at least 3 rows")
-    w, h = int(cam.width), int(cam.height)
-    if w < 1 or h < 1:
-        raise RuntimeError("camera width / height must be positive")
-    c = _CRays()
-    c.Q = w * h
-    c.image_width, c.image_height = w, h
-    c.c2w, c.fx, c.fy = cam.c2w.data_ptr(), float(cam.fx), float(cam.fy)
-    return c
-
-
-def _pack_rays(rays) -> _CRays:
-    """RaysSpec.check() (data_spec.hpp:57-64); a CameraSpec selects camera mode."""
-    if isinstance(rays, CameraSpec):
-        return _pack_camera(rays)
-    for nm in ("origins", "dirs", "vdirs"):
-        t = getattr(rays, nm)
-        _check_input(t, nm)
-        if not t.is_floating_point():
-            raise RuntimeError(f"{nm} must be floating point")
-        if t.dtype != torch.float32:
-            raise RuntimeError(f"{nm} must be float32 (the HIP path is fp32 only)")
-        if t.dim() != 2 or t.shape[1] != 3:
-            raise RuntimeError(f"{nm} must have shape [Q, 3]")
-    Q = rays.origins.shape[0]
-    if rays.dirs.shape[0] != Q or rays.vdirs.shape[0] != Q:
-        raise RuntimeError("origins, dirs and vdirs must have the same number of rays")
-    c = _CRays()
-    c.origins, c.dirs, c.vdirs = _ptr(rays.origins), _ptr(rays.dirs), _ptr(rays.vdirs)
-    c.Q = Q
-    w, h = int(getattr(rays, "image_width", 0) or 0), int(getattr(rays, "image_height", 0) or 0)
-    order = getattr(rays, "order", None)
-    if order is not None:
-        _check_input(order, "order")
-        if order.dtype != torch.int32 or order.dim() != 1 or order.shape[0] != Q:
-            raise RuntimeError("order must be int32 [Q]")
-        c.order = _ptr(order)
-    elif w * h == Q:
-        c.image_width, c.image_height = w, h
-    return c
-
-
-def _pack_opts(opt: RenderOptions) -> _COptions:
-    return _COptions(float(opt.step_size), float(opt.background_brightness),
-                     int(opt.format), int(opt.basis_dim),
-                     int(opt.ndc_width), int(opt.ndc_height), float(opt.ndc_focal),
-                     int(opt.min_comp), int(opt.max_comp),
-                     float(opt.sigma_thresh), float(opt.stop_thresh))
-
-
-def _stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-
-
-def _call(name, *args):
-    rc = getattr(_lib, name)(*args)
-    if rc != 0:
-        raise RuntimeError(f"{name} failed ({rc}): {_lib.svoxt_last_error().decode()}")
-
-
-def get_out_data_dim(opt: RenderOptions, K: int) -> int:
-    """get_out_data_dim (rt_kernel.cu:1352-1358)."""
-    n = _lib.svoxt_out_data_dim(ctypes.byref(_pack_opts(opt)), K)
-    if n < 0:
-        raise RuntimeError("invalid RenderOptions for get_out_data_dim")
-    return n
-
-
 # ---------------------------------------------------------------------------
 # Hot-path operators
 # ---------------------------------------------------------------------------
@@ -660,7 +220,7 @@ def get_out_data_dim(opt: RenderOptions, K: int) -> int:
 # batch needs is learned from the forwards before it: now and then ("a look") the 32 block counters are
 # copied to pinned host memory without waiting -- ONE 2 KB copy, no kernel -- and read when the copy has
 # landed.  A ray that finds no block stops recording and marches the rest, so a pool that is too small
-# costs time, never correctness.  LIST_POOL (SVOXT_LIST_POOL=0) False: dense lists.
+# costs time, never correctness.  LIST_POOL False: dense lists.
 #   The size is STICKY (r05): it changes only when a look leaves the band
 #   [POOL_LOW, POOL_HIGH] of the current capacity -- above (or dry): grow at once; below: shrink after
 #   POOL_SHRINK_LOOKS such looks in a row -- and sizes are rounded up to 1/16 of a power of two, so the
@@ -850,7 +410,7 @@ def _permute_rows(src: torch.Tensor, perm32: torch.Tensor, scatter: bool) -> tor
 # table records the sample lists, a batch that is not an image is rendered in svoxt_ray_order's
 # order, and both are left on the rays spec object for the backward that arrives with it -- which
 # then replays the lists (per-tile, one kernel) instead of marching.  A backward whose forward left
-# nothing (another spec object, features changed in place since, SVOXT_AUTO_PLAN=0) marches, as
+# nothing (another spec object, features changed in place since, AUTO_PLAN False) marches, as
 # the reference does.  The explicit forms (record=True / lists= / fwd_output=) remain.
 # ---------------------------------------------------------------------------
 # Batches that are not declared images are rendered in a coherent order (svoxt_ray_order,
@@ -979,7 +539,7 @@ def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bo
     `record=True` (not in the reference) asks for the sample lists a following
     volume_render_backward can replay; the call then returns (out, lists), with
     lists = None when recording does not apply (a payload without a specialised
-    kernel, a component sub-range, SVOXT_BWD_LIST=0)."""
+    kernel, a component sub-range, BWD_LIST_SAMPLES = 0)."""
     if not record and AUTO_PLAN:
         return _planned_forward("volume", lambda t, r, o, rec: _volume_render(t, r, o, rec), tree, rays, opt)
     return _volume_render(tree, rays, opt, record)
@@ -1306,349 +866,7 @@ def _opacity_render_backward(tree, rays, opt, grad_output, lists):
     return grad
 
 
-def _check_indices(indices):
-    """check_indices (svox_kernel.cu:36-40)."""
-    _check_input(indices, "indices")
-    if indices.dim() != 2:
-        raise RuntimeError("indices must be 2-D")
-    if not indices.is_floating_point():
-        raise RuntimeError("indices must be floating point")
-    if indices.dtype != torch.float32 or indices.shape[1] != 3:
-        raise RuntimeError("indices must be float32 [Q, 3]")
-
-
-def query_vertical(tree: TreeSpec, indices: torch.Tensor):
-    """svox_kernel.cu:274-324.  Returns (values [Q,K], node_ids [Q] int64,
-    data_ids [Q] int64, leaf_node [U,4] int64).
-
-    Differences from the reference, all where its result is undefined:
-    rows of `values` for empty leaves are zeros (reference: uninitialised,
-    :282), `data_ids` is -1 there, and `leaf_node` is sorted by packed leaf id
-    (reference: order set by a float atomic counter, :260-269)."""
-    ct = _pack_tree(tree)
-    _check_indices(indices)
-    dev = indices.device
-    Q = indices.shape[0]
-    N = ct.N
-    with torch.cuda.device(dev):
-        values = torch.empty((Q, ct.K), dtype=torch.float32, device=dev)
-        node_ids = torch.empty((Q,), dtype=torch.int64, device=dev)
-        data_ids = torch.empty((Q,), dtype=torch.int64, device=dev)
-        mask = torch.zeros((ct.n_internal * N * N * N,), dtype=torch.uint8, device=dev)
-        _call("svoxt_query_fwd", ctypes.byref(ct), _ptr(indices), Q, _ptr(values), _ptr(node_ids),
-              _ptr(data_ids), _ptr(mask), _stream(dev))
-        n_slots = mask.numel()
-        cap = min(Q, n_slots)
-        leaf_buf = torch.empty((cap, 4), dtype=torch.int64, device=dev)
-        count = torch.empty((1,), dtype=torch.int64, device=dev)
-        ws = torch.empty((_lib.svoxt_query_leaves_workspace_bytes(n_slots),), dtype=torch.uint8, device=dev)
-        _call("svoxt_query_leaves", _ptr(mask), n_slots, N, _ptr(leaf_buf), _ptr(count), _ptr(ws), _stream(dev))
-        leaf_node = leaf_buf[:int(count.item())]         # host sync, like the reference's .item() (:312)
-    return values, node_ids, data_ids, leaf_node
-
-
-def query_vertical_backward(tree: TreeSpec, indices: torch.Tensor,
-                            grad_output: torch.Tensor) -> torch.Tensor:
-    """svox_kernel.cu:380-402."""
-    ct = _pack_tree(tree)
-    _check_indices(indices)
-    _check_input(grad_output, "grad_output")
-    if grad_output.dtype != torch.float32 or tuple(grad_output.shape) != (indices.shape[0], ct.K):
-        raise RuntimeError("grad_output must be float32 [Q, K]")
-    dev = indices.device
-    with torch.cuda.device(dev):
-        grad = torch.empty((ct.M, ct.K), dtype=torch.float32, device=dev)
-        _call("svoxt_query_bwd", ctypes.byref(ct), _ptr(indices), indices.shape[0],
-              _ptr(grad_output), _ptr(grad), _stream(dev))
-    return grad
-
-
-def count_forward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
-    """Roofline counters (not in the reference): int64 [5] on the device =
-    (rays hitting the cube, leaf crossings, child words read, valid leaves,
-    composited samples).  See SURVEY.md 8(d)."""
-    ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
-    dev = tree.features.device
-    with torch.cuda.device(dev):
-        counters = torch.zeros((5,), dtype=torch.int64, device=dev)
-        _call("svoxt_count_fwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
-              _ptr(counters), _stream(dev))
-    return counters
-
-
-def count_touched(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions):
-    """Roofline instrumentation (include/svoxt.h, svoxt_count_touched): what one forward march of
-    the batch touches.  Returns a dict of counts: feature rows read by the forward (valid leaves)
-    and again by the backward (composited samples), grid cells and (child, data) pairs (or child /
-    data words without the grid), and the most leaf crossings of any ray."""
-    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
-    dev = tree.features.device
-    n_slots = ct.n_internal * ct.N ** 3
-    with torch.cuda.device(dev):
-        rows = torch.zeros((2 * ct.M,), dtype=torch.uint8, device=dev)
-        n_cells = (1 << (3 * ct.accel_log2)) if ct.accel else 0
-        tmask = torch.zeros(((n_cells + n_slots) if ct.accel else 2 * n_slots,), dtype=torch.uint8, device=dev)
-        longest = torch.zeros((1,), dtype=torch.int64, device=dev)
-        _call("svoxt_count_touched", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co), _ptr(rows), _ptr(tmask),
-              _ptr(longest), _stream(dev))
-        first = n_cells if ct.accel else n_slots
-        res = {"rows_valid": int(rows[:ct.M].sum(dtype=torch.int64)), "rows_composited": int(rows[ct.M:].sum(dtype=torch.int64)),
-               "longest_ray_crossings": int(longest.item()), "accel": bool(ct.accel)}
-        a, b = int(tmask[:first].sum(dtype=torch.int64)), int(tmask[first:].sum(dtype=torch.int64))
-        res.update({"grid_cells": a, "node_pairs": b} if ct.accel else {"child_words": a, "data_words": b})
-    return res
-
-
-class bwd_counters:
-    """`with bwd_counters() as c: ...backward...; c.read()` -> (64-byte atomic requests, (tile, pass, row)
-    groups) of the one-kernel per-tile backwards run inside (svoxt_set_bwd_counters)."""
-
-    def __init__(self, device):
-        self.buf = torch.zeros((2,), dtype=torch.int64, device=device)
-
-    def __enter__(self):
-        _call("svoxt_set_bwd_counters", _ptr(self.buf))
-        return self
-
-    def __exit__(self, *exc):
-        _call("svoxt_set_bwd_counters", None)
-
-    def read(self):
-        return tuple(int(v) for v in self.buf.cpu().tolist())
-
-
-class bwd_check:
-    """`with bwd_check(dev) as c: ...backward...; c.read()` -> ({site: violations}, tiles worked on): the per-tile
-    backwards run inside take their CHECKED instances -- every LDS / pool / table index compared with its extent
-    (svoxt_set_bwd_check; the sites are listed at grad_fused_kernel / grad_wide_kernel)."""
-
-    def __init__(self, device):
-        self.buf = torch.zeros((32,), dtype=torch.int64, device=device)
-
-    def __enter__(self):
-        _call("svoxt_set_bwd_check", _ptr(self.buf))
-        return self
-
-    def __exit__(self, *exc):
-        _call("svoxt_set_bwd_check", None)
-
-    def read(self):
-        w = [int(v) for v in self.buf.cpu().tolist()]
-        return {site: n for site, n in enumerate(w[2:31]) if n}, w[31]
-
-
-def motion_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions):
-    """rt_kernel.cu:1480-1504.  Returns (joint distances [Q, J], depth [Q, 1],
-    hit_point [Q, 3], data_idx [Q, 1] int64); J = tree.extra_data.shape[0]."""
-    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
-    if not _numel(tree.extra_data):
-        raise RuntimeError("motion_render needs extra_data [n_joints, >= 3] (the joint positions)")
-    dev = tree.features.device
-    with torch.cuda.device(dev):
-        out = torch.empty((cr.Q, ct.extra_rows), dtype=torch.float32, device=dev)
-        depth = torch.empty((cr.Q, 1), dtype=torch.float32, device=dev)
-        hit = torch.empty((cr.Q, 3), dtype=torch.float32, device=dev)
-        idx = torch.empty((cr.Q, 1), dtype=torch.int64, device=dev)
-        _call("svoxt_motion_render", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
-              _ptr(out), _ptr(depth), _ptr(hit), _ptr(idx), _stream(dev))
-    return out, depth, hit, idx
-
-
-def _pack_motion(tree: TreeSpec, ct: _CTree) -> _CMotion:
-    jf, sw, ji = tree.joint_features, tree.skinning_weights, tree.joint_index
-    for nm, x in (("joint_features", jf), ("skinning_weights", sw), ("joint_index", ji)):
-        if not _numel(x):
-            raise RuntimeError(f"motion_feature_render needs {nm}")
-        _check_input(x, nm)
-    if jf.dtype != torch.float32 or jf.dim() != 2 or sw.dtype != torch.float32 or sw.dim() != 2:
-        raise RuntimeError("joint_features / skinning_weights must be float32 and 2-D")
-    if ji.dtype != torch.int32 or ji.shape != sw.shape or sw.shape[0] != ct.M:
-        raise RuntimeError("joint_index must be int32 with the shape of skinning_weights, [M, n_bind]")
-    return _CMotion(jf.data_ptr(), jf.shape[0], jf.shape[1], sw.data_ptr(), ji.data_ptr(), sw.shape[1])
-
-
-def _motion_workspace(ct: _CTree, cm: _CMotion, dev) -> torch.Tensor:
-    nbytes = _lib.svoxt_motion_workspace_bytes(ct.M, cm.feature_dim)
-    if nbytes < 0:
-        raise RuntimeError("joint feature dim must be in [1, 32] (the reference's tmp_data_dim)")
-    return torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-
-
-def motion_feature_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Tensor:
-    """rt_kernel.cu:1525-1543: [Q, joint_features.shape[1]]."""
-    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
-    cm = _pack_motion(tree, ct)
-    dev = tree.features.device
-    with torch.cuda.device(dev):
-        out = torch.empty((cr.Q, cm.feature_dim), dtype=torch.float32, device=dev)
-        ws = _motion_workspace(ct, cm, dev)
-        _call("svoxt_motion_feature_render_fwd", ctypes.byref(ct), ctypes.byref(cm), ctypes.byref(cr),
-              ctypes.byref(co), _ptr(out), _ptr(ws), ws.numel(), _stream(dev))
-    return out
-
-
-def motion_feature_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
-                                   grad_output: torch.Tensor) -> torch.Tensor:
-    """rt_kernel.cu:1546-1572: gradient wrt joint_features, [n_joints, F] (the
-    derivative of the forward; the reference's kernel is defective, include/svoxt.h)."""
-    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
-    cm = _pack_motion(tree, ct)
-    _check_input(grad_output, "grad_output")
-    if grad_output.dtype != torch.float32 or tuple(grad_output.shape) != (cr.Q, cm.feature_dim):
-        raise RuntimeError("grad_output must be float32 [Q, joint feature dim]")
-    dev = tree.features.device
-    with torch.cuda.device(dev):
-        grad = torch.empty((cm.n_joints, cm.feature_dim), dtype=torch.float32, device=dev)
-        ws = _motion_workspace(ct, cm, dev)
-        _call("svoxt_motion_feature_render_bwd", ctypes.byref(ct), ctypes.byref(cm), ctypes.byref(cr),
-              ctypes.byref(co), _ptr(grad_output), _ptr(grad), _ptr(ws), ws.numel(), _stream(dev))
-    return grad
-
-
-def _check_warp(matrices, indices, skinning_weights, joint_index):
-    _check_indices(indices)
-    for nm, x in (("matrices", matrices), ("skinning_weights", skinning_weights), ("joint_index", joint_index)):
-        _check_input(x, nm)
-    if matrices.dtype != torch.float32 or matrices.dim() != 3 or tuple(matrices.shape[1:]) != (4, 4):
-        raise RuntimeError("matrices must be float32 [n_joints, 4, 4]")
-    Q = indices.shape[0]
-    if skinning_weights.dtype != torch.float32 or skinning_weights.dim() != 2 or skinning_weights.shape[0] != Q:
-        raise RuntimeError("skinning_weights must be float32 [Q, n_bind]")
-    if joint_index.dtype != torch.int32 or joint_index.shape != skinning_weights.shape:
-        raise RuntimeError("joint_index must be int32 with the shape of skinning_weights")
-    return Q, matrices.shape[0], skinning_weights.shape[1]
-
-
-def warp_vertices(matrices: torch.Tensor, indices: torch.Tensor, skinning_weights: torch.Tensor,
-                  joint_index: torch.Tensor):
-    """svox_kernel.cu:354-378: linear blend skinning of points.  Returns
-    (vertices_out [Q, 3], matrix_out [Q, 4, 4])."""
-    Q, J, B = _check_warp(matrices, indices, skinning_weights, joint_index)
-    dev = indices.device
-    with torch.cuda.device(dev):
-        vout = torch.empty((Q, 3), dtype=torch.float32, device=dev)
-        mout = torch.empty((Q, 4, 4), dtype=torch.float32, device=dev)
-        _call("svoxt_warp_vertices", _ptr(matrices), J, _ptr(indices), Q, _ptr(skinning_weights),
-              _ptr(joint_index), B, _ptr(vout), _ptr(mout), _stream(dev))
-    return [vout, mout]
-
-
-def warp_vertices_backward(matrices: torch.Tensor, indices: torch.Tensor, skinning_weights: torch.Tensor,
-                           joint_index: torch.Tensor, indices_grad_out: torch.Tensor,
-                           matrices_grad_out: torch.Tensor):
-    """svox_kernel.cu:404-436.  Returns [grad_indices [Q, 3], grad_matrices [n_joints, 4, 4],
-    grad_skinning_weights [Q, n_bind]]."""
-    Q, J, B = _check_warp(matrices, indices, skinning_weights, joint_index)
-    _check_input(indices_grad_out, "indices_grad_out")
-    _check_input(matrices_grad_out, "matrices_grad_out")
-    if indices_grad_out.dtype != torch.float32 or tuple(indices_grad_out.shape) != (Q, 3) or \
-            matrices_grad_out.dtype != torch.float32 or tuple(matrices_grad_out.shape) != (Q, 4, 4):
-        raise RuntimeError("gradients must be float32 [Q, 3] and [Q, 4, 4]")
-    dev = indices.device
-    with torch.cuda.device(dev):
-        gi = torch.empty((Q, 3), dtype=torch.float32, device=dev)
-        gm = torch.empty((J, 4, 4), dtype=torch.float32, device=dev)
-        gs = torch.empty((Q, B), dtype=torch.float32, device=dev)
-        _call("svoxt_warp_vertices_bwd", _ptr(matrices), J, _ptr(indices), Q, _ptr(skinning_weights),
-              _ptr(joint_index), B, _ptr(indices_grad_out), _ptr(matrices_grad_out), _ptr(gi), _ptr(gm),
-              _ptr(gs), _stream(dev))
-    return [gi, gm, gs]
-
-
-def refine_leaves(child: torch.Tensor, data: torch.Tensor, parent_depth: torch.Tensor, filled: int,
-                  leaf_node: torch.Tensor, node_id: torch.Tensor = None) -> None:
-    """The table updates of N3Tree.refine for the leaves in `leaf_node` [U, 4] int64
-    (svox.py:535-546), in place, as one kernel (not an entry of the reference's
-    extension, which does this with tensor ops).  The tables must have room for
-    filled + U nodes."""
-    for nm, x in (("child", child), ("data", data), ("parent_depth", parent_depth), ("leaf_node", leaf_node)):
-        _check_input(x, nm)
-    if leaf_node.dtype != torch.int64 or leaf_node.dim() != 2 or leaf_node.shape[1] != 4:
-        raise RuntimeError("leaf_node must be int64 [U, 4]")
-    if child.dtype != torch.int32 or data.dtype != torch.int32 or parent_depth.dtype != torch.int32:
-        raise RuntimeError("child / data / parent_depth must be int32")
-    if node_id is not None:
-        _check_input(node_id, "node_id")
-        if node_id.dtype != torch.int32 or node_id.numel() != leaf_node.shape[0]:
-            raise RuntimeError("node_id must be int32 [U]")
-    dev = child.device
-    with torch.cuda.device(dev):
-        _call("svoxt_refine", _ptr(leaf_node), leaf_node.shape[0], child.shape[1], int(filled), child.shape[0],
-              _ptr(child), _ptr(data), _ptr(parent_depth), _ptr(node_id), _stream(dev))
-    for t in (child, data, parent_depth):
-        torch.autograd.graph.increment_version(t)
-    _ACCEL_CACHE.pop(id(child), None)
-
-
-def construct_tree(tree: TreeSpec, indices: torch.Tensor) -> None:
-    """svox_kernel.cu:341-352: data[leaf containing point i] = i, in place on
-    `tree.data`.  Where several points share a leaf the smallest index is kept
-    (the reference keeps whichever thread wrote last)."""
-    ct = _pack_tree(tree)
-    _check_indices(indices)
-    dev = indices.device
-    with torch.cuda.device(dev):
-        _call("svoxt_construct_tree", ctypes.byref(ct), _ptr(indices), indices.shape[0], _stream(dev))
-    # tree.data was written behind torch's back: tell the version counter (the
-    # acceleration-grid cache keys on it) and drop any grid built from the old words
-    torch.autograd.graph.increment_version(tree.data)
-    _ACCEL_CACHE.pop(id(tree.child), None)
-
-
-def build_octree(points: torch.Tensor, offset: torch.Tensor, scaling: torch.Tensor, depth: int,
-                 empty_index: int, reserve: int = 0):
-    """Octree of a point cloud in one pipeline (not an entry of the reference's
-    extension; it stands for `depth - 1` rounds of `tree[points].refine()` on a
-    fresh N = 2 tree followed by `construct_tree(points)`, include/svoxt.h).
-
-    Returns (child [n + reserve, 2, 2, 2] int32, data [n + reserve, 2, 2, 2, 1] int32,
-    parent_depth [n + reserve, 2] int32, n): the first n rows are the tree, the
-    `reserve` rows after them are initialised like unused rows of an N3Tree."""
-    _check_indices(points)
-    for name, x in (("offset", offset), ("scaling", scaling)):
-        _check_input(x, name)
-        if x.dtype != torch.float32 or x.numel() != 3:
-            raise RuntimeError(f"{name} must be float32 [3]")
-    dev = points.device
-    P = points.shape[0]
-    with torch.cuda.device(dev):
-        nbytes = _lib.svoxt_build_workspace_bytes(int(depth))
-        if nbytes < 0:
-            raise RuntimeError("build_octree: depth must be in [1, 10]")
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-        count = torch.empty((1,), dtype=torch.int64, device=dev)
-        _call("svoxt_build_count", _ptr(points), P, _ptr(offset), _ptr(scaling), int(depth),
-              _ptr(ws), nbytes, _ptr(count), _stream(dev))
-        n = int(count.item())                 # the one host read: sizes the tables
-        rows = n + int(reserve)
-        child = torch.empty((rows, 2, 2, 2), dtype=torch.int32, device=dev)
-        data = torch.empty((rows, 2, 2, 2, 1), dtype=torch.int32, device=dev)
-        parent_depth = torch.empty((rows, 2), dtype=torch.int32, device=dev)
-        if reserve > 0:
-            child[n:].zero_()
-            data[n:].fill_(int(empty_index))
-            parent_depth[n:].zero_()
-        _call("svoxt_build_emit", _ptr(points), P, _ptr(offset), _ptr(scaling), int(depth),
-              _ptr(ws), nbytes, _ptr(child), _ptr(data), _ptr(parent_depth), n, int(empty_index),
-              _stream(dev))
-    return child, data, parent_depth, n
-
-
-# ---------------------------------------------------------------------------
-# Entry points of svox_t.csrc that are outside this project's hot path
-# (SURVEY.md section 2).  They exist so a caller gets a clear error, not an
-# AttributeError.
-# ---------------------------------------------------------------------------
-
-def _out_of_scope(name):
-    def fn(*_a, **_k):
-        raise NotImplementedError(
-            f"svox_t_amd.csrc.{name}: outside the accelerated hot path "
-            "(volume_render / opacity / depth / query / construct_tree); see SURVEY.md section 2")
-    fn.__name__ = name
-    return fn
-
-
-for _n in ("assign_vertical", "p2v", "p2v_backward",
-           "calc_corners", "grid_weight_render", "quantize_median_cut"):
-    globals()[_n] = _out_of_scope(_n)
+from ._extras import (assign_vertical, build_octree, bwd_check, bwd_counters, calc_corners, construct_tree,  # noqa: E402,F401
+                      count_forward, count_touched, grid_weight_render, motion_feature_render,
+                      motion_feature_render_backward, motion_render, p2v, p2v_backward, quantize_median_cut,
+                      query_vertical, query_vertical_backward, refine_leaves, warp_vertices, warp_vertices_backward)

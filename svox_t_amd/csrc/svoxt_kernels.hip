@@ -452,17 +452,15 @@ bool launch_fwd_roles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
         const int n_march = rl.n_march;                                 // a multiple of 8: see fwd_roles_kernel
         const unsigned grid = rl.grid;                                  // + the shading workgroups (the active ones: one per tile)
         const RolesMap rmap = rl.map;
-        const bool acc = tr.accel != nullptr;
+        // (r05: only with the acceleration grid -- the default for every N = 2 tree of 64 nodes and more; without one the
+        // march and the shade stay two launches: the 18 grid-less instances of this kernel had no default caller)
+        if (tr.accel == nullptr) return false;
         const bool wt = L.terms != nullptr;
 #define SVOXT_ROLES(F, BB)                                                                                        \
         {                                                                                                         \
-            if (acc && wt) hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 1, true>), dim3(grid), dim3(512), 0, st,   \
-                                              tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
-            else if (acc) hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 1, false>), dim3(grid), dim3(512), 0, st,   \
-                                             tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
-            else if (wt) hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 0, true>), dim3(grid), dim3(512), 0, st,     \
-                                            tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
-            else hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 0, false>), dim3(grid), dim3(512), 0, st,            \
+            if (wt) hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 1, true>), dim3(grid), dim3(512), 0, st,          \
+                                       tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
+            else hipLaunchKernelGGL((fwd_roles_kernel<F, BB, 1, false>), dim3(grid), dim3(512), 0, st,            \
                                     tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap); \
             /* the fallback shade of what the launch left unshaded + the tails of overflowed rays: one small launch */ \
             if (wt) hipLaunchKernelGGL((fwd_finish_kernel<F, BB, true>), dim3(finish_grid(nb)), dim3(512), 0, st, \
@@ -479,8 +477,7 @@ bool launch_fwd_roles(const TreeDev& tr, const RaysDev& rays, const Opts& opt, f
                                    tr, rays, opt, L, aux, out, sigma_mask, tile_state, n_march, (int)nb, tflags, rmap);
 #define SVOXT_ROLES_XF(BB)                                                                                        \
             {                                                                                                     \
-                if (acc && wt) SVOXT_ROLES_XF1(BB, 1, true) else if (acc) SVOXT_ROLES_XF1(BB, 1, false)           \
-                else if (wt) SVOXT_ROLES_XF1(BB, 0, true) else SVOXT_ROLES_XF1(BB, 0, false)                      \
+                if (wt) SVOXT_ROLES_XF1(BB, 1, true) else SVOXT_ROLES_XF1(BB, 1, false)                           \
                 if (wt) hipLaunchKernelGGL((fwd_finish_kernel<FMT_SH, BB, true, false, true>), dim3(finish_grid(nb)), dim3(512), 0, st, \
                                            tr, rays, opt, L, aux, out, tile_state, (int)nb);                      \
                 else hipLaunchKernelGGL((fwd_finish_kernel<FMT_SH, BB, false, false, true>), dim3(finish_grid(nb)), dim3(512), 0, st, \

@@ -14,12 +14,12 @@
 //
 // No counterpart in the reference (which marches rays in the order given).
 // The sort is a counting sort on the cell key: count (a returning atomic per ray gives its rank in
-// the cell), exclusive scan of the 655 361 counters (rocPRIM, the vendor primitive), scatter -- 4 launches and
-// ~0.04 ms for 640 000 rays where a radix sort of (key, id) pairs takes 21 launches and 0.14 ms.
+// the cell), exclusive scan of the 655 361 counters (two small kernels of our own, below: r05 -- rocPRIM's device scan
+// was the vendor primitive until then and brought 121 kernel instances into the library for this one call), scatter --
+// 5 launches and ~0.04 ms for 640 000 rays where a radix sort of (key, id) pairs takes 21 launches and 0.14 ms.
 
 #include <cstring>
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_scan.hpp>
 
 #include "svoxt_host.h"
 
@@ -32,14 +32,8 @@ constexpr int kOrderBlock = 256;
 // the reference-API route of the headline 1 043-1 052 -> 1 080-1 093 Mrays/s (finer groups of 64 rays AND an eighth of
 // the counters to clear and scan); 3-D cells of 1/64 or 1/32 alone: 1 003 / 944; faces of 1/512 or 1/1024: 1 055-1 080 /
 // 1 009-1 020 (the scan again); faces of 1/128: 1 031-1 061.
-#ifndef SVOXT_ORDER_AXIS_BITS
-#define SVOXT_ORDER_AXIS_BITS 6
-#endif
-#ifndef SVOXT_ORDER_FACE_BITS
-#define SVOXT_ORDER_FACE_BITS 8
-#endif
-constexpr int kAxisBits = SVOXT_ORDER_AXIS_BITS;     // cells of 2^-kAxisBits of the cube per axis
-constexpr int kFaceBits = SVOXT_ORDER_FACE_BITS;     // > 0: rays that enter through a face are keyed by (face, u, v), 2^-kFaceBits cells
+constexpr int kAxisBits = 6;     // cells of 2^-kAxisBits of the cube per axis
+constexpr int kFaceBits = 8;     // rays that enter through a face are keyed by (face, u, v), 2^-kFaceBits cells
 constexpr int kOrderBits = 3 * kAxisBits;   // Morton bits of the 3-D key
 constexpr uint32_t kFaceCells = kFaceBits > 0 ? 6u << (2 * kFaceBits) : 0u;      // the face keys come first
 constexpr uint32_t kMissKey = kFaceCells + (1u << kOrderBits);
@@ -160,6 +154,62 @@ gather_rays_kernel(RaysDev rays, const int32_t* __restrict__ perm, float* __rest
 
 constexpr size_t kOrderCells = (size_t)kMissKey + 1;            // one counter per cell, the last one for rays that miss the cube
 
+// Exclusive scan of the cell counters, two launches, no cross-workgroup synchronisation: a workgroup owns kScanChunk
+// consecutive counters (256 threads x 16); the first kernel leaves each chunk's total, the second adds up the totals of
+// the chunks before its own (at most 161 of them for kOrderCells: every thread a few, one LDS reduction) and scans its
+// chunk from there -- thread t its 16 counters in registers, the threads' sums by a wavefront scan and one LDS step.
+constexpr int kScanThreads = 256, kScanItems = 16, kScanChunk = kScanThreads * kScanItems;
+constexpr size_t kScanChunks = (kOrderCells + kScanChunk - 1) / kScanChunk;
+
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* lds /* [4] */) {
+    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const uint32_t s = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return s;
+}
+
+__global__ void __launch_bounds__(kScanThreads)
+scan_chunk_sums_kernel(const uint32_t* __restrict__ counts, size_t n, uint32_t* __restrict__ chunk_sums) {
+    __shared__ uint32_t lds[4];
+    const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * kScanItems;
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) if (base + j < n) v += counts[base + j];
+    const uint32_t s = block_sum_256(v, lds);
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(kScanThreads)
+scan_chunks_kernel(const uint32_t* __restrict__ counts, size_t n, const uint32_t* __restrict__ chunk_sums,
+                   uint32_t* __restrict__ starts) {
+    __shared__ uint32_t lds[4];
+    uint32_t before = 0;
+    for (unsigned c = threadIdx.x; c < blockIdx.x; c += kScanThreads) before += chunk_sums[c];
+    const uint32_t offset = block_sum_256(before, lds);
+    const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * kScanItems;
+    uint32_t v[kScanItems], mine = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) { v[j] = base + j < n ? counts[base + j] : 0u; mine += v[j]; }
+    // exclusive scan of the threads' sums: within the wavefront, then over the four wavefronts
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    uint32_t run = offset + incl - mine;
+    for (int w = 0; w < wave; ++w) run += lds[w];
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        if (base + j < n) starts[base + j] = run;
+        run += v[j];
+    }
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace svoxt
@@ -170,12 +220,9 @@ extern "C" {
 
 int64_t svoxt_ray_order_workspace_bytes(int64_t Q) {
     if (Q < 0 || Q > 0x7fffffff) return -1;
-    size_t temp = 0;
-    uint32_t* c = nullptr;
-    if (rocprim::exclusive_scan(nullptr, temp, c, c, 0u, kOrderCells, rocprim::plus<uint32_t>(), (hipStream_t)0) != hipSuccess)
-        return -1;
-    // keys, ranks (per ray); counts, starts (per cell); the scan's scratch
-    return (int64_t)(2 * align256(sizeof(uint32_t) * (size_t)Q) + 2 * align256(sizeof(uint32_t) * kOrderCells) + align256(temp));
+    // keys, ranks (per ray); counts, starts (per cell); the scan's chunk totals
+    return (int64_t)(2 * align256(sizeof(uint32_t) * (size_t)Q) + 2 * align256(sizeof(uint32_t) * kOrderCells) +
+                     align256(sizeof(uint32_t) * kScanChunks));
 }
 
 int svoxt_ray_order(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt,
@@ -195,16 +242,16 @@ int svoxt_ray_order(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_
     uint32_t* ranks = reinterpret_cast<uint32_t*>(w + plane);
     uint32_t* counts = reinterpret_cast<uint32_t*>(w + 2 * plane);
     uint32_t* starts = reinterpret_cast<uint32_t*>(w + 2 * plane + cells);
-    void* temp = w + 2 * plane + 2 * cells;
-    size_t temp_bytes = (size_t)workspace_bytes - 2 * plane - 2 * cells;
+    uint32_t* chunk_sums = reinterpret_cast<uint32_t*>(w + 2 * plane + 2 * cells);
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(uint32_t) * kOrderCells, st);
     if (e != hipSuccess) return set_error(SVOXT_ERR_HIP, "%s: hipMemsetAsync: %s", fn, hipGetErrorString(e));
     TreeDev tr = to_dev(tree);
     const unsigned nb = (unsigned)((n + kOrderBlock - 1) / kOrderBlock);
     hipLaunchKernelGGL(ray_key_kernel, dim3(nb), dim3(kOrderBlock), 0, st, tr, to_dev(rays, tree), to_dev(opt), keys, ranks, counts);
     if ((rc = check_launch(fn))) return rc;
-    e = rocprim::exclusive_scan(temp, temp_bytes, counts, starts, 0u, kOrderCells, rocprim::plus<uint32_t>(), st);
-    if (e != hipSuccess) return set_error(SVOXT_ERR_HIP, "%s: scan: %s", fn, hipGetErrorString(e));
+    hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3((unsigned)kScanChunks), dim3(kScanThreads), 0, st, counts, kOrderCells, chunk_sums);
+    hipLaunchKernelGGL(scan_chunks_kernel, dim3((unsigned)kScanChunks), dim3(kScanThreads), 0, st, counts, kOrderCells, chunk_sums, starts);
+    if ((rc = check_launch(fn))) return rc;
     hipLaunchKernelGGL(ray_place_kernel, dim3(nb), dim3(kOrderBlock), 0, st, keys, ranks, starts, (int64_t)n, perm);
     return check_launch(fn);
 }
