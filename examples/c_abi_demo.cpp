@@ -12,8 +12,8 @@
 // out.bin: int64 cols, then out f32[Q*cols], depth f32[Q], grad f32[M*K]
 //
 // What it shows: the call sequence a C or C++ host needs -- svoxt_accel_build (optional),
-// svoxt_volume_render_fwd_record + svoxt_volume_render_bwd_replay (the fast training
-// pair), svoxt_render_depth -- with every buffer owned by the caller.
+// svoxt_step_plan + svoxt_step_forward + svoxt_step_backward (the fast training pair, routed by
+// the library: ABI v21), svoxt_render_depth -- with every buffer owned by the caller.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -82,30 +82,27 @@ int main(int argc, char** argv) {
     HIP_OK(hipMalloc(&d_out, sizeof(float) * Q * cols));
     HIP_OK(hipMalloc(&d_depth, sizeof(float) * Q));
     HIP_OK(hipMalloc(&d_grad, sizeof(float) * M * K));
-    // the backward accumulates into rows that start on 64-byte boundaries (every atomic
-    // instruction then touches one line); svoxt_compact_rows gives the dense [M, K] back
-    const int32_t gs = (K <= 8 || K % 16 == 0) ? (int32_t)K : (int32_t)((K + 15) / 16 * 16);
-    float* d_grad_rows = nullptr;
-    HIP_OK(hipMalloc(&d_grad_rows, sizeof(float) * M * gs));
 
-    // forward that records sample lists, backward that replays them: coef NULL with coef_bytes -1
-    // asks for the per-tile route as one fused kernel (image batches without view rotations,
-    // the forward's output passed along); the library falls back to the one-kernel backward
-    // where that does not apply
-    svoxt_sample_lists lists = {};
-    lists.max_samples = 96;
-    lists.coef = nullptr;
-    lists.coef_bytes = -1;
-    HIP_OK(hipMalloc(&lists.rec, (size_t)lists.max_samples * ((Q + 63) / 64 * 64) * 8));   // whole 64-ray tiles
-    HIP_OK(hipMalloc(&lists.aux, (size_t)Q * 16));
-    if (svoxt_can_record(&tree, &opt)) {
-        SVOXT_OK_(svoxt_volume_render_fwd_record(&tree, &rays, &opt, d_out, &lists, st));
-        SVOXT_OK_(svoxt_volume_render_bwd_replay(&tree, &rays, &opt, d_gout, cols, d_grad_rows, gs, &lists, d_out, st));
-    } else {
-        SVOXT_OK_(svoxt_volume_render_fwd(&tree, &rays, &opt, d_out, st));
-        SVOXT_OK_(svoxt_volume_render_bwd(&tree, &rays, &opt, d_gout, cols, d_grad_rows, gs, nullptr, 0, st));
+    // One training step: the library plans the route for this payload (sample lists from a pool, the sigma bitmask,
+    // march and shade in one launch, the forward's hand-over, the per-tile exact backward, padded gradient rows --
+    // whatever applies) and lays out ONE workspace; the host allocates it and makes two calls.  (The mechanisms
+    // underneath -- svoxt_volume_render_fwd_record / _bwd_replay and friends -- remain callable one by one.)
+    svoxt_step step;
+    SVOXT_OK_(svoxt_step_plan(&tree, &rays, &opt, /*pool_blocks: first guess*/ 0, &step));
+    void* workspace = nullptr;
+    HIP_OK(hipMalloc(&workspace, (size_t)step.workspace_bytes));          // (hipMalloc: 256-byte aligned and more)
+    SVOXT_OK_(svoxt_step_forward(&tree, &rays, &opt, d_out, &step, workspace, st));
+    SVOXT_OK_(svoxt_step_backward(&tree, &rays, &opt, d_gout, d_grad, &step, workspace, st));
+    if (step.records) {
+        // how much of the list pool the batch took: the next plan can ask for that much (+ a margin) instead of the guess
+        std::vector<int32_t> ctr(32 * 16);
+        HIP_OK(hipMemcpyAsync(ctr.data(), step.lists.pool_next, ctr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        int32_t mx = -1;
+        for (int i = 0; i < 32; ++i) mx = ctr[16 * i] > mx ? ctr[16 * i] : mx;
+        std::printf("c_abi_demo: list pool %lld blocks, used %lld; workspace %.1f MiB\n", (long long)step.lists.pool_blocks,
+                    (long long)(mx + 1) * 32, step.workspace_bytes / 1048576.0);
     }
-    SVOXT_OK_(svoxt_compact_rows(d_grad_rows, M, (int32_t)K, gs, d_grad, st));
     SVOXT_OK_(svoxt_render_depth(&tree, &rays, &opt, d_depth, st));
     HIP_OK(hipStreamSynchronize(st));
 

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 20
+#define SVOXT_ABI_VERSION 21
 
 enum {
     SVOXT_OK = 0,
@@ -485,6 +485,45 @@ int64_t svoxt_set_super_tile_rows(int64_t rows);
  * SVOXT_LISTS_WALK_SUPER for a batch declared an image of 8 x 8 tiles, 0 otherwise (-1: NULL argument).  OR it into
  * svoxt_sample_lists.flags of a recording forward and of the backward over the same lists. */
 int32_t svoxt_image_walk(const svoxt_tree* tree, const svoxt_rays* rays);
+
+/* ---- One training step, planned by the library (ABI v21; no counterpart in the reference) -------------------------
+ *
+ * Everything above is mechanism; WHICH mechanisms a forward + backward pair should use for a payload (sample lists
+ * pooled or not, the sigma bitmask and the exponentials table, the forward's hand-over to the backward, march and
+ * shade as one launch, the per-tile backward, padded gradient rows) is policy.  These three calls are that policy --
+ * the route svox_t_amd's VolumeRenderer takes with every switch at its default -- for hosts that do not want to
+ * re-implement it (INTEGRATION.md route C).  Memory stays the caller's: one workspace, sized by the plan.
+ *
+ *   svoxt_step_plan      host only: decides the route for this tree / batch / options and lays out the workspace.
+ *                        pool_blocks: 4 KB list blocks to provide (0: a first guess, 12 per 64-ray tile).  After a
+ *                        step, (max over i of step.lists.pool_next[16 i] + 1) * 32 is what the batch used (device
+ *                        words; read them whenever convenient): at or above lists.pool_blocks the pool ran dry --
+ *                        results are unaffected (such rays march their remainder) but slower; plan the next step
+ *                        with more.  A plan stays valid while tree->M / K / N / xform, the batch's shape (Q, image
+ *                        size, order given or not), the options' format / basis_dim do not change.
+ *   svoxt_step_forward   volume_render (rt_kernel.cu:1362-1379): out [Q, C+1]; leaves in the workspace what the
+ *                        backward of the SAME features / rays / options replays.  Thresholds: any (the lists hold
+ *                        every sample with sigma > 0).  tree->accel is used if given (build it once per topology);
+ *                        tree->sigma_mask / exp_table are ignored -- both are built here, per call, in the workspace.
+ *   svoxt_step_backward  volume_render_backward (rt_kernel.cu:1402-1426): grad_features dense [M, K], every element
+ *                        written (zero fill included).  Exact arithmetic (every contribution the reference's formula).
+ * The workspace must be 256-byte aligned and may be a different allocation for every step (the plan holds offsets),
+ * but the backward needs the bytes its forward left.  No call synchronises. */
+typedef struct svoxt_step {
+    svoxt_sample_lists lists;      /* pointers are (re)bound to the workspace by each call */
+    int64_t workspace_bytes;       /* device bytes the two calls need */
+    int32_t records;               /* 1: the forward records sample lists and the backward replays them; 0: both march */
+    int32_t grad_cols, grad_stride;
+    int32_t uses_mask, uses_table;
+    int64_t off_mask, off_table, off_tables, tables_bytes, off_rec, off_aux, off_terms, terms_bytes, off_grad_rows,
+            off_bwd_ws, bwd_ws_bytes, nt;
+} svoxt_step;
+int svoxt_step_plan(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt, int64_t pool_blocks,
+                    svoxt_step* step);
+int svoxt_step_forward(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt, float* out,
+                       svoxt_step* step, void* workspace, void* stream);
+int svoxt_step_backward(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt, const float* grad_out,
+                        float* grad_features, svoxt_step* step, void* workspace, void* stream);
 
 /* Acceleration grid (no counterpart in the reference).  A 2^g x 2^g x 2^g table
  * that caches, per cell, where the root->leaf descent of common.cuh:63-100

@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(CSRC, LIB_NAME)
 # step 13 -- and the one place an out-of-range private index could fault)
 RESOURCES_PATH = os.path.join(CSRC, "libsvoxt_hip.resources.txt")
 OBJ_DIR = os.path.join(CSRC, "build")          # object files (git-ignored)
-SOURCES = ["svoxt_kernels.hip", "svoxt_bwd.hip", "svoxt_build.hip", "svoxt_motion.hip", "svoxt_order.hip"]
+SOURCES = ["svoxt_kernels.hip", "svoxt_bwd.hip", "svoxt_build.hip", "svoxt_motion.hip", "svoxt_order.hip", "svoxt_step.hip"]
 HEADERS = ["svoxt_device.h", "svoxt_host.h", "svoxt_launch.h", "svoxt_lists.h", "svoxt_fwd_kernels.h", "svoxt_bwd_kernels.h",
            "svoxt_misc_kernels.h", "svoxt_tile_reduce.inc", os.path.join("..", "..", "include", "svoxt.h")]
 

@@ -16,7 +16,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -70,6 +70,14 @@ class _CLists(ctypes.Structure):         # struct svoxt_sample_lists
                 ("terms_state", ctypes.c_int32), ("flags", ctypes.c_int32), ("tile_state", ctypes.c_void_p)]
 
 
+class _CStep(ctypes.Structure):          # struct svoxt_step
+    _fields_ = [("lists", _CLists), ("workspace_bytes", ctypes.c_int64), ("records", ctypes.c_int32),
+                ("grad_cols", ctypes.c_int32), ("grad_stride", ctypes.c_int32), ("uses_mask", ctypes.c_int32),
+                ("uses_table", ctypes.c_int32)] + \
+               [(n, ctypes.c_int64) for n in ("off_mask", "off_table", "off_tables", "tables_bytes", "off_rec", "off_aux",
+                                              "off_terms", "terms_bytes", "off_grad_rows", "off_bwd_ws", "bwd_ws_bytes", "nt")]
+
+
 # svoxt_sample_lists.flags (include/svoxt.h)
 LISTS_NATIVE_MATH, LISTS_FWD_ONE_KERNEL, LISTS_FWD_TWO_KERNELS, LISTS_FWD_NO_OVERLAP, LISTS_GRAD_ZEROED, LISTS_BEGUN = 1, 2, 4, 8, 16, 32
 LISTS_TEST_DROP, LISTS_TEST_NOPOLL, LISTS_TEST_STALE, LISTS_FWD_AGENT_FENCE = 256, 512, 1024, 2048
@@ -116,6 +124,9 @@ EXPORTS = {
     "svoxt_set_bwd_check": (ctypes.c_int, [_vp]),
     "svoxt_set_super_tile_rows": (_i64, [_i64]),
     "svoxt_image_walk": (_i32, [_P(_CTree), _P(_CRays)]),
+    "svoxt_step_plan": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _i64, _P(_CStep)]),
+    "svoxt_step_forward": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _P(_CStep), _vp, _vp]),
+    "svoxt_step_backward": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _P(_CStep), _vp, _vp]),
     "svoxt_ray_order_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "svoxt_ray_order": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, ctypes.c_int64, _vp]),
     "svoxt_gather_rays": (ctypes.c_int, [_P(_CRays), _vp, _vp, _vp, _vp, _vp]),

@@ -654,9 +654,7 @@ __device__ __forceinline__ uint32_t shade_tile_body(const TreeDev& tr, const Ray
 // checksum mismatches, workgroups whose poll ran out, tiles dropped by the test flag, tiles the fallback launch shaded.
 constexpr int kRolePolls = 20000;
 constexpr int64_t kTileEmpty = 1 << 30;          // queue entry tile | kTileEmpty: no ray of the tile has a sample and its pixels are written
-constexpr int kRoleXcds = 8;
-__host__ __device__ inline int64_t roles_even(int64_t tiles) { return (tiles + 1) & ~(int64_t)1; }   // (the 64-bit queue entries behind it stay aligned)
-__host__ __device__ inline int64_t roles_state_words(int64_t tiles) { return roles_even(tiles) + 16 * 32 + (int64_t)kRoleXcds * 2 * tiles; }
+// (kRoleXcds, roles_even, roles_state_words -- the size of svoxt_sample_lists.tile_state -- live in svoxt_lists.h: svoxt_step.hip sizes workspaces with them)
 __device__ __forceinline__ int my_xcc() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (kRoleXcds - 1)); }   // HW_REG_XCC_ID, bits 3:0
 enum { kRoleCtrShaded = 256, kRoleCtrMismatch = 257, kRoleCtrGaveUp = 258, kRoleCtrDropped = 259, kRoleCtrFallback = 260 };
 // test-only behaviour of the shading workgroups (svoxt_sample_lists.flags >> 8: SVOXT_LISTS_TEST_*) and the fence form

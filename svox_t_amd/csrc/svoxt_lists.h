@@ -32,6 +32,11 @@ constexpr int kBlock = 64;
 // transmittance underflows to exactly 0 -- the remaining samples have weight
 // 0 and leave the output bits unchanged, but they belong in the list.
 constexpr uint32_t kRecOverflow = 0x80000000u;
+// svoxt_sample_lists.tile_state (fwd_roles_kernel, svoxt_fwd_kernels.h): per-tile states (rounded up to even), 16 counter
+// slots of 32 words, 8 queues (one per XCD) of one 64-bit entry per tile
+constexpr int kRoleXcds = 8;
+__host__ __device__ inline int64_t roles_even(int64_t tiles) { return (tiles + 1) & ~(int64_t)1; }   // (the 64-bit queue entries behind it stay aligned)
+__host__ __device__ inline int64_t roles_state_words(int64_t tiles) { return roles_even(tiles) + 16 * 32 + (int64_t)kRoleXcds * 2 * tiles; }
 // (r05) aux[q].w between a recording forward's shade and its tail launch: the shade ended the ray's COMPOSITING by the
 // stop rule (T <= stop_thresh, rt_kernel.cu:313-319) and has written the pixel; the forward's tail leaves the ray alone,
 // the overflow flag stays for the backward's tail (which marches every sample with sigma > 0 the list could not hold).
