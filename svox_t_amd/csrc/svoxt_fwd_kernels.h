@@ -827,6 +827,14 @@ __host__ __device__ inline int64_t roles_group_of(const RolesMap& m, int b) {   
 
 // XF (r04; SH up to 9 basis functions): per-leaf view rotations -- the shading role evaluates a record's basis from its
 // leaf's matrix (shade_tile_body<..., XF>) and its hand-over holds the exponentials of THAT basis (grad_fused_kernel<..., 3, ..., XF>).
+// (r05, measured and not kept -- exp/r05/*.diff.txt, DESIGN.md 5: (a) the shading role PERSISTENT, at most as many shading
+// workgroups as the chip holds, each taking tiles until a stop entry, tiles without samples not queued at all: forward
+// 0.2485 -> 0.2554 ms -- a pop, two dependent round trips, costs what the dispatch of a workgroup cost, and as a loop the
+// body keeps ~40 registers of invariants alive unless they are formed per tile behind asm barriers (79 -> 120 registers,
+// two workgroups per CU: 0.33 ms); (b) the gathering wavefronts' record of the next round requested a round ahead:
+// 0.2476 -> 0.2494; (c) wave 0's chain with one of its three double-precision quotients (wrong pixels, timing only):
+// 0.2559 -> 0.2543.  None of the three is what the kernel waits for: it is as long as its longest march (~155 us: 133
+// crossings of ~1.16 us) plus that tile's own shade (~45-58 us: ~19 rounds of gather -> barrier).)
 template <int FMT, int BD, int ACC, bool WTERMS, bool LOBES = false, bool XF = false>
 __global__ void __launch_bounds__(512)
 fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux, float* __restrict__ out,
