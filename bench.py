@@ -103,9 +103,10 @@ def self_launch(args, argv):
     return p.returncode if (p.returncode or lines) else 1
 
 
-def kernel_stats_ms(workload, forward_only):
+def kernel_stats_ms(workload, forward_only, per_step=False):
     """{kernel name prefix: mean ms per launch} from this round's committed `rocprofv3 --kernel-trace --stats`
-    summary of the same command (profiles/<ROUND>_<workload>[_fwd]_kernel_stats.csv), or {}."""
+    summary of the same command (profiles/<ROUND>_<workload>[_fwd]_kernel_stats.csv), or {}.
+    per_step: {name: (total ms, calls)} of EVERY kernel instead (kernel_table divides by the steps the profiled run made)."""
     import csv
     path = os.path.join(ROOT, "profiles", f"{ROUND}_{workload}{'_fwd' if forward_only else ''}_kernel_stats.csv")
     out = {}
@@ -114,7 +115,9 @@ def kernel_stats_ms(workload, forward_only):
             for r in csv.DictReader(f):
                 name = r["Name"].replace("void ", "").replace("svoxt::", "")
                 key = name.split("(")[0]
-                if int(r["Calls"]) >= 10:                  # (the one-off counting launches are not the step's)
+                if per_step:
+                    out[key] = (float(r["TotalDurationNs"]) * 1e-6, int(r["Calls"]))
+                elif int(r["Calls"]) >= 10:                # (the one-off counting launches are not the step's)
                     out[key] = round(float(r["AverageNs"]) * 1e-6, 5)
     except Exception:
         return {}
@@ -163,8 +166,9 @@ def pmc_kernel(workload, forward_only, key):
 
 def kernel_table(workload, forward_only, assign, survey, group_ms, prof_ok):
     """The step's kernels, one row each:
-        ms                 mean duration per launch from THIS ROUND's committed `rocprofv3 --kernel-trace --stats` of the same
-                           command (profiles/<ROUND>_<workload>[_fwd]_kernel_stats.csv); kernels inside one C-ABI call cannot be
+        ms                 the kernel family's time per step (total duration of all its launches / steps of the profiled run) from
+                           THIS ROUND's committed `rocprofv3 --kernel-trace --stats` of the same command
+                           (profiles/<ROUND>_<workload>[_fwd]_kernel_stats.csv); kernels inside one C-ABI call cannot be
                            separated by this run's own events -- those give the group totals (`groups`)
         compulsory_bytes   what this implementation's algorithm must move once through that kernel (counted on the device)
         overhead_bytes     passes the reference does not have (bitmask / table builds, padding and its clearing): NOT in frac
@@ -174,13 +178,18 @@ def kernel_table(workload, forward_only, assign, survey, group_ms, prof_ok):
                            instead of the descent, the per-tile merge instead of per-sample atomics), not that it beats the roof
         traffic            (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from the committed PMC passes; traffic_ratio = traffic / compulsory
     assign: {kernel key: (compulsory bytes, overhead bytes, group)}; survey: {kernel key: bytes}."""
-    kstats = kernel_stats_ms(workload, forward_only) if prof_ok else {}
+    kstats = kernel_stats_ms(workload, forward_only, per_step=True) if prof_ok else {}
+    # steps the profiled run made = launches of the step's main kernels (each runs once per step)
+    main = [c for n, (_, c) in kstats.items() if n.startswith(("fwd_roles_kernel", "grad_fused_kernel", "grad_wide_kernel", "march_rec_kernel",
+                                                              "render_fwd_kernel", "shade_chan_kernel"))]
+    steps_profiled = max(main) if main else 0
     rows = []
     for key, (comp, over, group) in assign.items():
         ms = None
-        for name, v in kstats.items():
-            if any(name.startswith(pre) for pre in KERNEL_KEYS.get(key, ())):
-                ms = (ms or 0.0) + v          # (instances of one family that each run once per step: their sum)
+        for name, (tot, calls) in kstats.items():
+            # (instances that ran once -- the counting launches in front of the timed region -- are not the step's)
+            if steps_profiled and 2 * calls >= steps_profiled and any(name.startswith(pre) for pre in KERNEL_KEYS.get(key, ())):
+                ms = (ms or 0.0) + tot / steps_profiled          # the family's time per step (every instance and launch of it)
         traffic = pmc_kernel(workload, forward_only, key) if prof_ok else None
         row = {"kernel": key, "names": list(KERNEL_KEYS.get(key, ())), "group": group, "ms": None if ms is None else round(ms, 5),
                "compulsory_bytes": int(comp), "overhead_bytes": int(over),

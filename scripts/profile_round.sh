@@ -41,6 +41,7 @@ if [ $PART = all ] || [ $PART = a ]; then
 pmc   d8_sh9_800
 stats d8_sh9_800
 bench d8_sh9_800
+stats d8_sh9_800_fwd --forward-only
 bench d8_sh9_800_fwd --forward-only
 bench d8_sh9_800_camera --route camera --no-plain
 stats d8_sh9_800_plain --route plain

@@ -595,7 +595,8 @@ def _volume_render(tree, rays, opt, record):
                               + (", native exp / rcp)" if NATIVE_MATH else ")") if wide else
                               "fwd_roles_kernel (march + shade_tile in one launch)" if roles else
                               "march_rec_kernel + shade_tile_kernel (two-kernel forward)") if split
-                             else "render_fwd_kernel") + (", recording sample lists" if record else "")
+                             else ("render_fwd_kernel" if can_rec or not record else "render_fwd_generic_kernel (no specialised instance: accumulators in "
+                                   "memory as the reference keeps them)")) + (", recording sample lists" if will_record else "")
     with torch.cuda.device(dev):
         out = torch.empty((cr.Q, get_out_data_dim(opt, ct.K)), dtype=torch.float32, device=dev)
         if will_record:
