@@ -579,7 +579,7 @@ def _volume_render(tree, rays, opt, record):
     if will_record:
         with torch.cuda.device(dev):
             lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
-    if ((split or fills == 3 or xf_roles) and FWD_SPLIT != "0") if will_record else (split and co.stop_thresh == 0.0):
+    if ((split or fills == 3 or xf_roles) and FWD_SPLIT != "0") if will_record else (split and (co.stop_thresh == 0.0 or wide)):
         # rows of 8 / 16 / 32 floats in exact mode: the same pass leaves the rows' exponentials for the shade kernel
         # (and, on the lists, for the per-tile backward of this feature content)
         # (lists for a backward hold every sample with sigma > 0 whatever the forward's threshold: the mask of threshold 0)
