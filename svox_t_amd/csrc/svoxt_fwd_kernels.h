@@ -834,7 +834,10 @@ __host__ __device__ inline int64_t roles_group_of(const RolesMap& m, int b) {   
 // two workgroups per CU: 0.33 ms); (b) the gathering wavefronts' record of the next round requested a round ahead:
 // 0.2476 -> 0.2494; (c) wave 0's chain with one of its three double-precision quotients (wrong pixels, timing only):
 // 0.2559 -> 0.2543.  None of the three is what the kernel waits for: it is as long as its longest march (~155 us: 133
-// crossings of ~1.16 us) plus that tile's own shade (~45-58 us: ~19 rounds of gather -> barrier).)
+// crossings of ~1.16 us) plus that tile's own shade (~45-58 us: ~19 rounds of gather -> barrier).  (d) The march itself: the
+// grid cell of a LATER crossing requested on speculation (where that crossing starts if the leaves keep their size), one or
+// two crossings ahead, in front of or right behind the crossing's own request: forward 0.247 -> 0.294-0.306 ms -- the ~15
+// instructions of the guess sit in every crossing's chain and the speculative line competes with the real one.)
 template <int FMT, int BD, int ACC, bool WTERMS, bool LOBES = false, bool XF = false>
 __global__ void __launch_bounds__(512)
 fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux, float* __restrict__ out,
