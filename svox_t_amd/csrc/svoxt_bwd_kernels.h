@@ -1304,6 +1304,11 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 // pool, 17 sweep 1's compacted position, 18 a compacted record's slot, 19 a feature row outside the table, 20 sweep
 // 2's table entry, 21 the list of occupied entries, 22 a record's place in the sorted order, 23 an occupied entry
 // read by the reduce, 24 a sorted record read by the reduce, 25 the row a sum is sent to.
+// (r05, measured and not kept -- exp/r05/grad_wide_split_sweeps.diff.txt: the two sweeps as two launches (sweep 1 leaves accum and the
+// final transmittance in aux, as the tail-only launch does), each compiled for its own occupancy: backward 1.31 -> 1.41-1.42 ms at
+// 8 / 8, 8 / 6 and 6 / 6 wavefronts per SIMD.  Sweep 1 alone needs 72 registers without scratch, sweep 2 alone 80 -- no gain there --
+// and as one launch the workgroups' latency-bound sweeps overlap the atomic-rate-bound reduces of their neighbours, which two
+// launches give up.)
 // ETAB (exact mode, r04): the rows are read from tr.etab -- etab[row][c] = pexpf(-features[row][c]), sigma in the last
 // column (exp_table_kernel, built once per forward) -- so neither sweep forms the exponential of a feature again, and
 // the double-precision reciprocals 1 / (1 + e) take rcp_unit_range (the compiler's division sequence minus what their
