@@ -135,3 +135,54 @@ def test_fast_full_size_config3(gpu):
     np.testing.assert_array_equal(got, O.volume_render(case.oracle_tree(), *case.rays_np(), opt))
     gwant, _, tight = O.volume_render_backward(case.oracle_tree(), *case.rays_np(), opt, g, want_abs="both")
     assert_grads_close(ggot, gwant, tight)
+
+
+@pytest.mark.parametrize("kind,B", [("SG", 9), ("ASG", 4), ("SG", 16)])
+@pytest.mark.parametrize("image", [True, False])
+def test_fast_lobes_payloads(gpu, kind, B, image):
+    """SG / ASG payloads (lists only together with the per-tile backward's hand-over, svoxt_can_record = 2) under
+    fast=True: image batches take the one-launch forward and the fused backward, ray batches march."""
+    gen = torch.Generator().manual_seed(4)
+    if kind == "SG":
+        lobes = torch.cat([torch.rand(B, 1, generator=gen) * 4 + 0.5,
+                           torch.nn.functional.normalize(torch.randn(B, 3, generator=gen), dim=-1)], -1).contiguous()
+        fmt = O.FORMAT_SG
+    else:
+        fr = torch.linalg.qr(torch.randn(B, 3, 3, generator=gen))[0]
+        lobes = torch.cat([torch.rand(B, 2, generator=gen) * 3 + 0.3, fr.reshape(B, 9)], -1).contiguous()
+        fmt = O.FORMAT_ASG
+    c = Case(depth=5, K=3 * B + 1, data_format=f"{kind}{B}", width=64, height=48)
+    tree = svox.N3Tree.from_arrays(c.st.child, c.st.data, c.st.parent_depth, c.features, data_format=f"{kind}{B}",
+                                   extra_data=lobes, device=gpu)
+    r = svox.VolumeRenderer(tree)
+    f = tree.features
+    out = r(f, c.rays_gpu(gpu), image_shape=(48, 64) if image else None, fast=True)
+    g = synth.grad_output(c.Q, 4, seed=7)
+    out.backward(g.to(gpu))
+    ot = O.Tree(c.features.numpy(), c.st.data, c.st.child, extra=lobes.numpy())
+    opt = O.make_options(format=fmt, basis_dim=B, sigma_thresh=1e-2, stop_thresh=1e-2)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O.volume_render(ot, *c.rays_np(), opt))
+    gwant, _, tight = O.volume_render_backward(ot, *c.rays_np(), opt, g.numpy(), want_abs="both")
+    assert_grads_close(f.grad.cpu().numpy(), gwant, tight)
+    if image:
+        assert "grad_fused_kernel" in _C.LAST_ROUTE["backward"], _C.LAST_ROUTE
+
+
+def test_fast_render_persp(gpu):
+    """Camera mode (rays generated in the kernels) forward + backward with fast=True, against the oracle on the rays its
+    restatement of cam2world_ray (rt_kernel.cu:1153-1166) generates: pixels bit for bit, gradient on the tight scale."""
+    case = Case(depth=6, K=28, data_format="SH9", width=96, height=64)
+    tree = case.tree(gpu)
+    r = svox.VolumeRenderer(tree)
+    pose = synth.camera_pose(azimuth_deg=30.0)
+    fx = 1111.111 * 96 / 800.0
+    g = synth.grad_output(96 * 64, 4, seed=7)
+    f = tree.features
+    img = r.render_persp(f, torch.from_numpy(pose).float().to(gpu), width=96, height=64, fx=fx, fast=True)
+    img.view(-1, 4).backward(g.to(gpu))
+    assert "marches" not in _C.LAST_ROUTE["backward"], _C.LAST_ROUTE
+    o, d, v = O.camera_rays(pose.astype(np.float32), fx, fx, 96, 64)
+    opt = O.make_options(format=case.format, basis_dim=case.basis_dim, sigma_thresh=1e-2, stop_thresh=1e-2)
+    np.testing.assert_array_equal(img.view(-1, 4).detach().cpu().numpy(), O.volume_render(case.oracle_tree(), o, d, v, opt))
+    gwant, _, tight = O.volume_render_backward(case.oracle_tree(), o, d, v, opt, g.numpy(), want_abs="both")
+    assert_grads_close(f.grad.cpu().numpy(), gwant, tight)
