@@ -16,8 +16,15 @@ depth, W, H = 8, 800, 800
 st = synth.shell_tree(depth)
 o, d, v = synth.pinhole_rays(W, H, c2w=synth.camera_pose(azimuth_deg=30.0))
 rays = svox.Rays(o.to(dev), d.to(dev), v.to(dev))
-for label, K, fmt, comps in (("SH9, 3 channels (specialised)", 28, "SH9", None), ("SH4 x 2 channels", 9, "SH4", None),
-                             ("RGBA-style row of 6 floats", 6, "RGBA", None), ("SH9, components 1..4 only", 28, "SH9", (1, 4))):
+ROWS = [("SH9, 3 channels (specialised)", 28, "SH9", None, True)]
+for pad in (True, False):      # (r05: one or two channels / other row widths are rendered as the next specialised payload: PAD_PAYLOADS)
+    ROWS += [("SH4 x 2 channels" + ("" if pad else " [generic kernels]"), 9, "SH4", None, pad),
+             ("SH9 x 1 channel" + ("" if pad else " [generic kernels]"), 10, "SH9", None, pad),
+             ("RGBA-style row of 6 floats" + ("" if pad else " [generic kernels]"), 6, "RGBA", None, pad),
+             ("RGBA-style row of 12 floats" + ("" if pad else " [generic kernels]"), 12, "RGBA", None, pad)]
+ROWS += [("SH9 x 4 channels [generic: no padding up]", 37, "SH9", None, True), ("SH9, components 1..4 only [generic]", 28, "SH9", (1, 4), True)]
+for label, K, fmt, comps, pad in ROWS:
+    _C.PAD_PAYLOADS = pad
     feats = synth.shell_features(st.n_features, K)
     tree = svox.N3Tree.from_arrays(st.child, st.data, st.parent_depth, feats, data_format=fmt, device=dev)
     r = svox.VolumeRenderer(tree) if comps is None else svox.VolumeRenderer(tree, min_comp=comps[0], max_comp=comps[1])
@@ -43,5 +50,5 @@ for label, K, fmt, comps in (("SH9, 3 channels (specialised)", 28, "SH9", None),
             fn()
         torch.cuda.synchronize()
         res.append((time.perf_counter() - t0) / 10 * 1e3)
-    print(f"{label:34s} K = {K:2d}: forward {res[0]:7.3f} ms ({W * H / res[0] / 1e3:7.1f} Mrays/s), forward+backward {res[1]:7.3f} ms "
+    print(f"{label:46s} K = {K:2d}: forward {res[0]:7.3f} ms ({W * H / res[0] / 1e3:7.1f} Mrays/s), forward+backward {res[1]:7.3f} ms "
           f"({W * H / res[1] / 1e3:7.1f} Mrays/s)   [{_C.LAST_ROUTE.get('forward')} | {_C.LAST_ROUTE.get('backward')}]", flush=True)

@@ -533,6 +533,71 @@ def _take_plan(kind, tree, rays, opt):
     return p
 
 
+# ---------------------------------------------------------------------------
+# Payloads one step away from a specialised one (r05).  The list kernels and the per-tile backward exist
+# for three channels (x 1 / 4 / 9 / 16 / 25 basis functions or lobes) and for RGBA-style rows of 4 / 8 / 16 / 32 floats;
+# the reference is generic in both (rt_kernel.cu:293-306).  A payload with FEWER channels -- one or two channels with a
+# basis, an RGBA-style row of 2 .. 31 floats of another width -- is rendered as the next specialised one with DUMMY channels:
+# feature columns of zeros in front of sigma, zeros in the upstream gradient.  Every channel's chain is its own, so the
+# real channels' pixels are the same bits; a dummy channel's sigmoid is 0.5, but its upstream gradient is 0, so it adds
+# +0.0 to total_color (the reference's sums over the channels, :410-425, 470-476: the real channels first, in order, then
+# x + 0.0 = x) and to sum_c g_c, and its own gradient columns -- exact zeros -- are dropped.  Cost: one copy of the
+# feature table in, one of the gradient out (75 MB at depth 8: ~0.03 ms each) against the generic kernels' accumulators in
+# memory and marching backward (800 x 800 / depth 8, forward+backward: SH4 x 2 2.09 ms, a row of 6 floats 1.94:
+# profiles/r05_generic_timing.txt has both ways).  PAD_PAYLOADS = False (test attribute): the generic kernels, as before.
+# More channels than three with a basis, component sub-ranges and rows wider than 32 floats stay generic.
+# ---------------------------------------------------------------------------
+PAD_PAYLOADS = True
+
+
+def _pad_layout(tree: TreeSpec, opt: RenderOptions):
+    """None, or (K', columns of real channels, dummy columns): the specialised payload this one is rendered as."""
+    f = tree.features
+    if not PAD_PAYLOADS or not isinstance(f, torch.Tensor) or f.dim() != 2 or f.dtype != torch.float32 or not f.is_cuda:
+        return None
+    K, fmt, bd = f.shape[1], int(opt.format), int(opt.basis_dim)
+    if fmt == FORMAT_RGBA:
+        if K < 2 or K > 32 or K in (4, 8, 16, 32):
+            return None
+        Kp = 4 if K < 4 else 8 if K < 8 else 16 if K < 16 else 32
+        return Kp, K - 1, Kp - K, 1
+    if bd not in (1, 4, 9, 16, 25) or (K - 1) % bd or int(opt.min_comp) != 0 or int(opt.max_comp) != bd - 1:
+        return None
+    C = (K - 1) // bd
+    if C < 1 or C >= 3:
+        return None
+    return 3 * bd + 1, C * bd, (3 - C) * bd, bd
+
+
+def _padded(tree: TreeSpec, rays, lay):
+    """The tree spec with the padded feature table (kept on the rays / camera spec for the backward of the same call:
+    the plan the forward leaves there names THIS tensor)."""
+    f = tree.features
+    key = (id(f), f._version, f.data_ptr(), lay)
+    ent = getattr(rays, "_svoxt_pad", None)
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    Kp, real, dummy, _ = lay
+    with torch.no_grad():
+        fp = torch.cat([f[:, :real], f.new_zeros((f.shape[0], dummy)), f[:, real:]], dim=1)
+    fp.requires_grad_(f.requires_grad)
+    tp = TreeSpec()
+    tp.__dict__.update(tree.__dict__)
+    tp.features = fp
+    rays._svoxt_pad = (key, tp)
+    return tp
+
+
+def _pad_cols(x, real_cols, dummy_cols):
+    """[n, real + 1] -> [n, real + dummy + 1]: zeros in front of the last column."""
+    return torch.cat([x[:, :real_cols], x.new_zeros((x.shape[0], dummy_cols)), x[:, real_cols:]], dim=1)
+
+
+def _drop_cols(x, real_cols):
+    """... and back: the real columns and the last one."""
+    return torch.cat([x[:, :real_cols], x[:, -1:]], dim=1)
+
+
 def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bool = False):
     """rt_kernel.cu:1362-1379.
 
@@ -540,6 +605,11 @@ def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bo
     volume_render_backward can replay; the call then returns (out, lists), with
     lists = None when recording does not apply (a payload without a specialised
     kernel, a component sub-range, BWD_LIST_SAMPLES = 0)."""
+    lay = _pad_layout(tree, opt) if not record else None
+    if lay is not None:
+        _, real, _, w = lay
+        out = volume_render(_padded(tree, rays, lay), rays, opt)
+        return _drop_cols(out, real // w)
     if not record and AUTO_PLAN:
         return _planned_forward("volume", lambda t, r, o, rec: _volume_render(t, r, o, rec), tree, rays, opt)
     return _volume_render(tree, rays, opt, record)
@@ -659,6 +729,15 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
     `fwd_output` (optional): the output of that forward, which saves the
     backward its first pass (include/svoxt.h, svoxt_volume_render_bwd_replay).
     Neither given: what the forward of the same spec objects left behind (see _Plan)."""
+    lay = _pad_layout(tree, opt) if (lists is None and fwd_output is None) else None
+    if lay is not None:
+        _check_input(grad_output, "grad_output")
+        _, real, dummy, w = lay
+        if grad_output.dim() != 2 or grad_output.shape[1] != real // w + 1:
+            raise RuntimeError("grad_output must be float32 [Q, C+1]")
+        gp = volume_render_backward(_padded(tree, rays, lay), rays, opt, _pad_cols(grad_output, real // w, dummy // w))
+        rays._svoxt_pad = None
+        return _drop_cols(gp, real)
     if lists is None and fwd_output is None and AUTO_PLAN:
         p = _take_plan("volume", tree, rays, opt)
         if p is not None:

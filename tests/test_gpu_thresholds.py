@@ -26,7 +26,7 @@ CASES = {
     "d5_sh4_world": dict(depth=5, K=13, data_format="SH4", width=64, height=64, radius=[1.0, 1.2, 0.8], center=[0.1, -0.2, 0.3]),
     "d4_sh16": dict(depth=4, K=49, data_format="SH16", width=48, height=48),
     "d4_sh25": dict(depth=4, K=76, data_format="SH25", width=48, height=48),
-    "d5_generic": dict(depth=5, K=9, data_format="SH4", width=48, height=48),      # (no lists: marches, as before)
+    "d5_two_channels": dict(depth=5, K=9, data_format="SH4", width=48, height=48),      # (r05: rendered as three channels, lists and all)
 }
 
 
@@ -54,8 +54,7 @@ def test_fast_forward_backward(gpu, name, image):
     np.testing.assert_array_equal(got, want)
     gwant, gabs, tight = O.volume_render_backward(case.oracle_tree(), *case.rays_np(), opt, g, want_abs="both")
     assert_grads_close(ggot, gwant, tight)
-    if name != "d5_generic":
-        assert "marches" not in _C.LAST_ROUTE["backward"], _C.LAST_ROUTE     # the lists served it
+    assert "marches" not in _C.LAST_ROUTE["backward"], _C.LAST_ROUTE         # the lists served it
     # the thresholds did something: the thresholded forward differs from the plain one on this workload
     plain = O.volume_render(case.oracle_tree(), *case.rays_np(), O.make_options(format=case.format, basis_dim=case.basis_dim))
     assert not np.array_equal(want, plain)
