@@ -517,6 +517,11 @@ typedef struct svoxt_step {
     int32_t uses_mask, uses_table;
     int64_t off_mask, off_table, off_tables, tables_bytes, off_rec, off_aux, off_terms, terms_bytes, off_grad_rows,
             off_bwd_ws, bwd_ws_bytes, nt;
+    /* a payload one step away from a specialised one is rendered AS it, with dummy channels (one or two channels with a
+       basis -> three; RGBA-style rows of 2 .. 31 floats of another width -> 4 / 8 / 16 / 32): zeros in front of sigma and in
+       the upstream gradient; the caller sees its own shapes, the same bits */
+    int32_t pad_K, pad_real, pad_dummy, pad_w;       /* pad_K == 0: not padded */
+    int64_t off_pad_features, off_pad_out, off_pad_gout, off_pad_grad;
 } svoxt_step;
 int svoxt_step_plan(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt, int64_t pool_blocks,
                     svoxt_step* step);

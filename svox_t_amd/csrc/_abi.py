@@ -75,7 +75,9 @@ class _CStep(ctypes.Structure):          # struct svoxt_step
                 ("grad_cols", ctypes.c_int32), ("grad_stride", ctypes.c_int32), ("uses_mask", ctypes.c_int32),
                 ("uses_table", ctypes.c_int32)] + \
                [(n, ctypes.c_int64) for n in ("off_mask", "off_table", "off_tables", "tables_bytes", "off_rec", "off_aux",
-                                              "off_terms", "terms_bytes", "off_grad_rows", "off_bwd_ws", "bwd_ws_bytes", "nt")]
+                                              "off_terms", "terms_bytes", "off_grad_rows", "off_bwd_ws", "bwd_ws_bytes", "nt")] + \
+               [(n, ctypes.c_int32) for n in ("pad_K", "pad_real", "pad_dummy", "pad_w")] + \
+               [(n, ctypes.c_int64) for n in ("off_pad_features", "off_pad_out", "off_pad_gout", "off_pad_grad")]
 
 
 # svoxt_sample_lists.flags (include/svoxt.h)

@@ -7,7 +7,7 @@
 // re-implementing that policy.  The three calls below ARE that policy, over the same entry points, with every byte
 // still owned by the caller: svoxt_step_plan lays out ONE workspace, svoxt_step_forward / _backward run the default
 // route for the payload (what VolumeRenderer.forward + backward take with every switch at its default).
-// Host code only: no kernel lives here.
+// Host code only, but for the two column-copy kernels of the padded payloads (below).
 #include <cstring>
 #include <hip/hip_runtime.h>
 
@@ -37,6 +37,47 @@ inline bool xf_roles(const svoxt_tree* t, const svoxt_options* o) {
 }
 inline char* at(void* ws, int64_t off) { return static_cast<char*>(ws) + off; }
 
+// Payloads one step away from a specialised one are rendered AS it, with dummy channels (what svox_t_amd/csrc/__init__.py
+// does under PAD_PAYLOADS): one or two channels with a basis -> three, RGBA-style rows of 2 .. 31 floats of
+// another width -> 4 / 8 / 16 / 32.  Columns of zeros go in front of the last column (sigma / alpha / the sigma gradient).
+struct PadLayout { int Kp, real, dummy, w; };
+inline bool pad_layout(const svoxt_tree* t, const svoxt_options* o, PadLayout* p) {
+    const int K = t->K, bd = o->basis_dim;
+    if (o->format == SVOXT_FORMAT_RGBA) {
+        if (K < 2 || K > 32 || K == 4 || K == 8 || K == 16 || K == 32) return false;
+        const int Kp = K < 4 ? 4 : K < 8 ? 8 : K < 16 ? 16 : 32;
+        *p = PadLayout{Kp, K - 1, Kp - K, 1};
+        return true;
+    }
+    if (!(bd == 1 || bd == 4 || bd == 9 || bd == 16 || bd == 25) || (K - 1) % bd != 0 || o->min_comp != 0 || o->max_comp != bd - 1) return false;
+    const int C = (K - 1) / bd;
+    if (C < 1 || C >= 3) return false;
+    *p = PadLayout{3 * bd + 1, C * bd, (3 - C) * bd, bd};
+    return true;
+}
+
+// dst [n, dc] <- src [n, sc]: the first `real` columns and the last one; PAD: zeros between them (dc > sc), else dropped (dc < sc)
+template <bool PAD>
+__global__ void __launch_bounds__(256)
+copy_cols_kernel(const float* __restrict__ src, int sc, float* __restrict__ dst, int dc, int64_t n, int real) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * dc) return;
+    const int64_t row = i / dc;
+    const int c = (int)(i - row * dc);
+    float v;
+    if (c < real) v = src[row * sc + c];
+    else if (c == dc - 1) v = src[row * sc + sc - 1];
+    else v = 0.f;                                    // (PAD only: a dropped column is never a destination)
+    dst[i] = v;
+}
+inline int copy_cols(bool pad, const float* src, int sc, float* dst, int dc, int64_t n, int real, void* stream, const char* fn) {
+    if (n == 0) return SVOXT_OK;
+    const unsigned nb = (unsigned)((n * dc + 255) / 256);
+    if (pad) hipLaunchKernelGGL((copy_cols_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, src, sc, dst, dc, n, real);
+    else hipLaunchKernelGGL((copy_cols_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, src, sc, dst, dc, n, real);
+    return check_launch(fn);
+}
+
 }  // namespace
 
 extern "C" {
@@ -48,9 +89,19 @@ int svoxt_step_plan(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_
     if (step == nullptr) return set_error(SVOXT_ERR_INVALID, "%s: step is NULL", fn);
     if ((rc = check_tree(tree, fn)) || (rc = check_rays(rays, fn)) || (rc = check_opts(opt, tree, fn, true))) return rc;
     std::memset(step, 0, sizeof(*step));
+    svoxt_tree padded_tree;
+    PadLayout pl;
+    const int64_t K_caller = tree->K;
+    const int cols_caller = svoxt_out_data_dim(opt, tree->K);
+    if (cols_caller < 2) return set_error(SVOXT_ERR_INVALID, "%s: bad output width", fn);
+    if (pad_layout(tree, opt, &pl)) {                      // planned as the specialised payload it is rendered as
+        padded_tree = *tree;
+        padded_tree.K = pl.Kp;
+        tree = &padded_tree;
+        step->pad_K = pl.Kp; step->pad_real = pl.real; step->pad_dummy = pl.dummy; step->pad_w = pl.w;
+    }
     const int64_t Q = rays->Q, M = tree->M, K = tree->K;
     const int cols = svoxt_out_data_dim(opt, tree->K);
-    if (cols < 2) return set_error(SVOXT_ERR_INVALID, "%s: bad output width", fn);
     const bool coherent = is_tiled(rays) || rays->order != nullptr || rays->c2w != nullptr;
     const bool wide = wide_rows(tree, opt);
     int rec = Q > 0 && M > 0 ? svoxt_can_record(tree, opt) : 0;
@@ -60,6 +111,14 @@ int svoxt_step_plan(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_
     step->grad_stride = (K <= 8 || K % 16 == 0) ? (int32_t)K : (int32_t)((K + 15) / 16 * 16);
     int64_t off = 0;
     auto take = [&](int64_t bytes) { const int64_t o = off; off += up(bytes > 0 ? bytes : 1); return o; };
+    step->off_pad_features = step->off_pad_out = step->off_pad_gout = step->off_pad_grad = -1;
+    if (step->pad_K) {
+        step->off_pad_features = take(4 * M * K);
+        step->off_pad_out = take(4 * Q * cols);
+        step->off_pad_gout = take(4 * Q * cols);
+        step->off_pad_grad = take(4 * M * K);
+    }
+    (void)K_caller; (void)cols_caller;
     if (step->grad_stride != K) step->off_grad_rows = take(4 * M * step->grad_stride); else step->off_grad_rows = -1;
     if (!step->records) {
         // no lists for this payload / options: both calls march; the backward gets its own scratch lists
@@ -119,8 +178,25 @@ int svoxt_step_forward(const svoxt_tree* tree, const svoxt_rays* rays, const svo
     const char* fn = "svoxt_step_forward";
     if (step == nullptr || workspace == nullptr || tree == nullptr) return set_error(SVOXT_ERR_INVALID, "%s: NULL argument", fn);
     if (((uintptr_t)workspace & 255u) != 0) return set_error(SVOXT_ERR_INVALID, "%s: workspace must be 256-byte aligned", fn);
-    if (!step->records) return svoxt_volume_render_fwd(tree, rays, opt, out, stream);
     int rc;
+    svoxt_tree padded_tree;
+    float* out_caller = out;
+    const int cols_caller = opt != nullptr ? svoxt_out_data_dim(opt, tree->K) : 0;
+    if (step->pad_K) {
+        if (rays == nullptr || opt == nullptr) return set_error(SVOXT_ERR_INVALID, "%s: NULL argument", fn);
+        float* fp = reinterpret_cast<float*>(at(workspace, step->off_pad_features));
+        if ((rc = copy_cols(true, tree->features, tree->K, fp, step->pad_K, tree->M, step->pad_real, stream, fn))) return rc;
+        padded_tree = *tree;
+        padded_tree.features = fp;
+        padded_tree.K = step->pad_K;
+        tree = &padded_tree;
+        out = reinterpret_cast<float*>(at(workspace, step->off_pad_out));
+    }
+    auto finish = [&](int r) -> int {
+        if (r != SVOXT_OK || !step->pad_K) return r;
+        return copy_cols(false, out, step->grad_cols, out_caller, cols_caller, rays->Q, step->pad_real / step->pad_w, stream, fn);
+    };
+    if (!step->records) return finish(svoxt_volume_render_fwd(tree, rays, opt, out, stream));
     bind_lists(step, workspace);
     svoxt_sample_lists& l = step->lists;
     l.flags &= ~SVOXT_LISTS_BEGUN;
@@ -143,7 +219,7 @@ int svoxt_step_forward(const svoxt_tree* tree, const svoxt_rays* rays, const svo
     if (l.terms_state == 0) { l.terms = nullptr; l.terms_bytes = 0; }       // (wide rows: the backward's scratch, not the forward's)
     rc = svoxt_volume_render_fwd_record(&t, rays, opt, out, &l, stream);
     if (step->off_terms >= 0) l.terms = at(workspace, step->off_terms);
-    return rc;
+    return finish(rc);
 }
 
 int svoxt_step_backward(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_options* opt, const float* grad_out,
@@ -153,6 +229,21 @@ int svoxt_step_backward(const svoxt_tree* tree, const svoxt_rays* rays, const sv
         return set_error(SVOXT_ERR_INVALID, "%s: NULL argument", fn);
     if (grad_features == nullptr && tree->M > 0) return set_error(SVOXT_ERR_INVALID, "%s: grad_features is NULL", fn);
     int rc;
+    svoxt_tree padded_tree;
+    float* grad_caller = grad_features;
+    const int32_t K_caller = tree->K;
+    if (step->pad_K) {
+        // (the padded feature table is the one the forward left in the workspace: the lists' hand-over was formed from it)
+        float* gp = reinterpret_cast<float*>(at(workspace, step->off_pad_gout));
+        const int cols_caller = svoxt_out_data_dim(opt, tree->K);
+        if ((rc = copy_cols(true, grad_out, cols_caller, gp, step->grad_cols, rays->Q, step->pad_real / step->pad_w, stream, fn))) return rc;
+        grad_out = gp;
+        padded_tree = *tree;
+        padded_tree.features = reinterpret_cast<const float*>(at(workspace, step->off_pad_features));
+        padded_tree.K = step->pad_K;
+        tree = &padded_tree;
+        grad_features = reinterpret_cast<float*>(at(workspace, step->off_pad_grad));
+    }
     const int64_t M = tree->M;
     const int32_t K = tree->K, gs = step->grad_stride;
     float* rows = step->off_grad_rows >= 0 ? reinterpret_cast<float*>(at(workspace, step->off_grad_rows)) : grad_features;
@@ -185,7 +276,8 @@ int svoxt_step_backward(const svoxt_tree* tree, const svoxt_rays* rays, const sv
         rc = svoxt_volume_render_bwd_replay(&t, rays, opt, grad_out, step->grad_cols, rows, gs, &l, nullptr, stream);
     }
     if (rc != SVOXT_OK) return rc;
-    if (rows != grad_features) return svoxt_compact_rows(rows, M, K, gs, grad_features, stream);
+    if (rows != grad_features && (rc = svoxt_compact_rows(rows, M, K, gs, grad_features, stream))) return rc;
+    if (step->pad_K) return copy_cols(false, grad_features, K, grad_caller, K_caller, M, step->pad_real, stream, fn);
     return SVOXT_OK;
 }
 

@@ -25,7 +25,10 @@ CASES = {
     "d5_sh4_world_rays": (dict(depth=5, K=13, data_format="SH4", width=61, height=47, radius=[1.0, 1.2, 0.8], center=[0.1, -0.2, 0.3]), False, "render_bwd"),
     "d4_sh25_image": (dict(depth=4, K=76, data_format="SH25", width=48, height=48), True, "grad_fused"),
     "d5_rgba8_rays": (dict(depth=5, K=8, data_format="RGBA", width=64, height=64), False, "render_bwd"),
-    "d5_generic": (dict(depth=5, K=9, data_format="SH4", width=48, height=48), True, None),       # no lists: both calls march
+    "d5_sh4_two_channels": (dict(depth=5, K=9, data_format="SH4", width=48, height=48), True, "grad_fused"),    # rendered as three channels (pad_K = 13)
+    "d5_rgba6_image": (dict(depth=5, K=6, data_format="RGBA", width=48, height=48), True, "grad_wide"),          # ... as a row of 8 floats
+    "d5_rgba3_rays": (dict(depth=5, K=3, data_format="RGBA", width=47, height=31), False, "render_bwd"),         # ... of 4
+    "d4_generic": (dict(depth=4, K=37, data_format="SH9", width=40, height=40), True, None),      # four channels: no lists, both calls march
 }
 
 
@@ -65,7 +68,8 @@ def test_step_api_matches_the_oracle(gpu, name):
         np.testing.assert_array_equal(out, O.volume_render(case.oracle_tree(), *case.rays_np(), oo))
         gw, _, tight = O.volume_render_backward(case.oracle_tree(), *case.rays_np(), oo, g, want_abs="both")
         assert_grads_close(grad, gw, tight)                 # (every element written: the NaN fill is gone)
-        assert bool(step.records) == (name != "d5_generic")
+        assert bool(step.records) == (name != "d4_generic")
+        assert (step.pad_K > 0) == (name in ("d5_sh4_two_channels", "d5_rgba6_image", "d5_rgba3_rays")), step.pad_K
 
 
 def test_step_api_with_a_pool_that_runs_dry(gpu):
