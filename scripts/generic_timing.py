@@ -21,8 +21,9 @@ for pad in (True, False):      # (r05: one or two channels / other row widths ar
     ROWS += [("SH4 x 2 channels" + ("" if pad else " [generic kernels]"), 9, "SH4", None, pad),
              ("SH9 x 1 channel" + ("" if pad else " [generic kernels]"), 10, "SH9", None, pad),
              ("RGBA-style row of 6 floats" + ("" if pad else " [generic kernels]"), 6, "RGBA", None, pad),
-             ("RGBA-style row of 12 floats" + ("" if pad else " [generic kernels]"), 12, "RGBA", None, pad)]
-ROWS += [("SH9 x 4 channels [generic: no padding up]", 37, "SH9", None, True), ("SH9, components 1..4 only [generic]", 28, "SH9", (1, 4), True)]
+             ("RGBA-style row of 12 floats" + ("" if pad else " [generic kernels]"), 12, "RGBA", None, pad),
+             ("SH9, components 1..4 only" + ("" if pad else " [generic kernels]"), 28, "SH9", (1, 4), pad)]
+ROWS += [("SH9 x 4 channels [generic: no padding up]", 37, "SH9", None, True)]
 for label, K, fmt, comps, pad in ROWS:
     _C.PAD_PAYLOADS = pad
     feats = synth.shell_features(st.n_features, K)

@@ -545,7 +545,11 @@ def _take_plan(kind, tree, rays, opt):
 # feature table in, one of the gradient out (75 MB at depth 8: ~0.03 ms each) against the generic kernels' accumulators in
 # memory and marching backward (800 x 800 / depth 8, forward+backward: SH4 x 2 2.09 ms, a row of 6 floats 1.94:
 # profiles/r05_generic_timing.txt has both ways).  PAD_PAYLOADS = False (test attribute): the generic kernels, as before.
-# More channels than three with a basis, component sub-ranges and rows wider than 32 floats stay generic.
+# A component SUB-RANGE of a basis (min_comp / max_comp: the reference's `for i = min_comp .. max_comp`, rt_kernel.cu:295-298)
+# goes the same way: the coefficients outside the range are zeros in the copy and the kernels run the full range -- the
+# products outside it are (+-)0, the sums the same floats up to the sign of a zero that exp() does not see -- and the
+# gradient columns outside the range, which the reference never touches, come back as zeros.
+# More channels than three with a basis and rows wider than 32 floats stay generic.
 # ---------------------------------------------------------------------------
 PAD_PAYLOADS = True
 
@@ -560,13 +564,15 @@ def _pad_layout(tree: TreeSpec, opt: RenderOptions):
         if K < 2 or K > 32 or K in (4, 8, 16, 32):
             return None
         Kp = 4 if K < 4 else 8 if K < 8 else 16 if K < 16 else 32
-        return Kp, K - 1, Kp - K, 1
-    if bd not in (1, 4, 9, 16, 25) or (K - 1) % bd or int(opt.min_comp) != 0 or int(opt.max_comp) != bd - 1:
+        return Kp, K - 1, Kp - K, 1, None
+    if bd not in (1, 4, 9, 16, 25) or (K - 1) % bd:
         return None
     C = (K - 1) // bd
-    if C < 1 or C >= 3:
+    lo, hi = int(opt.min_comp), int(opt.max_comp)
+    sub = (lo, hi) != (0, bd - 1)
+    if C < 1 or C > 3 or (C == 3 and not sub) or (sub and not (0 <= lo <= hi < bd)):
         return None
-    return 3 * bd + 1, C * bd, (3 - C) * bd, bd
+    return 3 * bd + 1, C * bd, (3 - C) * bd, bd, ((lo, hi) if sub else None)
 
 
 def _padded(tree: TreeSpec, rays, lay):
@@ -577,15 +583,30 @@ def _padded(tree: TreeSpec, rays, lay):
     ent = getattr(rays, "_svoxt_pad", None)
     if ent is not None and ent[0] == key:
         return ent[1]
-    Kp, real, dummy, _ = lay
+    Kp, real, dummy, w, sub = lay
     with torch.no_grad():
         fp = torch.cat([f[:, :real], f.new_zeros((f.shape[0], dummy)), f[:, real:]], dim=1)
+        if sub is not None:
+            fp[:, :real] *= _sub_mask(f, real, w, sub)
     fp.requires_grad_(f.requires_grad)
     tp = TreeSpec()
     tp.__dict__.update(tree.__dict__)
     tp.features = fp
     rays._svoxt_pad = (key, tp)
     return tp
+
+
+def _sub_mask(like, real, w, sub):
+    """float [real]: 1 for the coefficients min_comp .. max_comp of every channel, 0 outside."""
+    i = torch.arange(real, device=like.device) % w
+    return ((i >= sub[0]) & (i <= sub[1])).to(like.dtype)
+
+
+def _full_range(opt: RenderOptions) -> RenderOptions:
+    o = RenderOptions()
+    o.__dict__.update(opt.__dict__)
+    o.min_comp, o.max_comp = 0, int(opt.basis_dim) - 1
+    return o
 
 
 def _pad_cols(x, real_cols, dummy_cols):
@@ -607,9 +628,9 @@ def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bo
     kernel, a component sub-range, BWD_LIST_SAMPLES = 0)."""
     lay = _pad_layout(tree, opt) if not record else None
     if lay is not None:
-        _, real, _, w = lay
-        out = volume_render(_padded(tree, rays, lay), rays, opt)
-        return _drop_cols(out, real // w)
+        _, real, dummy, w, sub = lay
+        out = volume_render(_padded(tree, rays, lay), rays, opt if sub is None else _full_range(opt))
+        return _drop_cols(out, real // w) if dummy else out
     if not record and AUTO_PLAN:
         return _planned_forward("volume", lambda t, r, o, rec: _volume_render(t, r, o, rec), tree, rays, opt)
     return _volume_render(tree, rays, opt, record)
@@ -732,12 +753,16 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
     lay = _pad_layout(tree, opt) if (lists is None and fwd_output is None) else None
     if lay is not None:
         _check_input(grad_output, "grad_output")
-        _, real, dummy, w = lay
+        _, real, dummy, w, sub = lay
         if grad_output.dim() != 2 or grad_output.shape[1] != real // w + 1:
             raise RuntimeError("grad_output must be float32 [Q, C+1]")
-        gp = volume_render_backward(_padded(tree, rays, lay), rays, opt, _pad_cols(grad_output, real // w, dummy // w))
+        gp = volume_render_backward(_padded(tree, rays, lay), rays, opt if sub is None else _full_range(opt),
+                                    _pad_cols(grad_output, real // w, dummy // w) if dummy else grad_output)
         rays._svoxt_pad = None
-        return _drop_cols(gp, real)
+        gp = _drop_cols(gp, real) if dummy else gp
+        if sub is not None:
+            gp[:, :real] *= _sub_mask(gp, real, w, sub)
+        return gp
     if lists is None and fwd_output is None and AUTO_PLAN:
         p = _take_plan("volume", tree, rays, opt)
         if p is not None:

@@ -90,3 +90,27 @@ def test_padded_payload_through_camera_mode_and_plain_calls(gpu):
     rs = _rays_spec_from_rays(svox.Rays(*(torch.from_numpy(a).to(gpu) for a in (o, d, v))), (48, 64))
     grad = _C.volume_render_backward(tree._spec(tree.features), rs, r._get_options(), g.to(gpu))
     assert_grads_close(grad.cpu().numpy(), gwant, tight)
+
+
+@pytest.mark.parametrize("fmt,K,lo,hi", [("SH9", 28, 1, 4), ("SH9", 28, 0, 0), ("SH4", 9, 1, 3), ("SH16", 49, 4, 8), ("SH9", 10, 2, 8)])
+def test_component_subrange_through_the_fast_kernels(gpu, fmt, K, lo, hi, monkeypatch):
+    """min_comp / max_comp (rt_kernel.cu:295-298): coefficients outside the range are zeros in the copy the kernels see;
+    gradient columns outside it come back as exact zeros, as the reference leaves them."""
+    c = Case(depth=5, K=K, data_format=fmt, width=64, height=48)
+    opt = c.oracle_opts(min_comp=lo, max_comp=hi)
+    want = O.volume_render(c.oracle_tree(), *c.rays_np(), opt)
+    g = synth.grad_output(c.Q, want.shape[1], seed=5)
+    gwant, gabs, tight = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), opt, g.numpy(), want_abs="both")
+    for pad in (True, False):
+        monkeypatch.setattr(_C, "PAD_PAYLOADS", pad)
+        tree = c.tree(gpu)
+        r = svox.VolumeRenderer(tree, min_comp=lo, max_comp=hi)
+        f = tree.features
+        out = r(f, c.rays_gpu(gpu), image_shape=(48, 64))
+        out.backward(g.to(gpu))
+        np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
+        assert_grads_close(f.grad.cpu().numpy(), gwant, tight)
+        assert ("generic" in _C.LAST_ROUTE["forward"]) == (not pad), _C.LAST_ROUTE
+    bd = c.basis_dim
+    outside = [ch * bd + i for ch in range((K - 1) // bd) for i in range(bd) if not lo <= i <= hi]
+    assert np.all(f.grad.cpu().numpy()[:, outside] == 0) and np.all(gabs[:, outside] == 0)
