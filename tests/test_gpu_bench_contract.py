@@ -53,6 +53,10 @@ def test_bench_json_contract(gpu):
     pw = r["prewarm"]
     assert pw["seconds"] >= 0.5 and pw["steps"] >= 20 and pw["converged"] is True, pw
     assert pw["last_batch_ms"]["backward"] <= 1.1 * ps["summary"]["backward"]["median"]    # the timed steps are the settled ones
+    # the default run carries BASELINE.json's other single-GPU configs along, briefly (the driver then holds numbers for them too)
+    oc = r["other_configs"]
+    assert len(oc) == 6 and all("error" not in o and o["value"] > 0 for o in oc), oc
+    assert any("configs[3]" in o["config"] and "forward+backward" in o["config"] and o["value"] > 300 for o in oc)
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert r["counters"]["steps"] == 18919396                                           # the workload is the one named
