@@ -232,8 +232,12 @@ def main(argv=None):
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--fast", action="store_true",
                     help="sigma_thresh = stop_thresh = 1e-2 (svox_t/renderer.py:428-430): SURVEY.md 8(d)'s extra row; the headline is thresholds 0")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "all_reduce", "direct"],
-                    help="N > 1: the gradient all-reduce (auto: both are timed on a gradient-sized buffer first, the faster is used)")
+    ap.add_argument("--exchange", default="all_reduce", choices=["auto", "all_reduce", "direct"],
+                    help="N > 1: the gradient all-reduce.  all_reduce (default): RCCL's own, in 32 MB row chunks; direct: "
+                         "parallel.direct_all_reduce (reduce-scatter + all-gather as two rounds of simultaneous point-to-point "
+                         "transfers, one per xGMI link); auto: both are timed on a gradient-sized buffer first and the faster is "
+                         "used.  The point-to-point form has never run on RCCL hardware (one-GPU boxes only: tests cover it on "
+                         "gloo), so it is opt-in: the first multi-GPU measurement must not depend on it")
     ap.add_argument("--prewarm-s", type=float, default=PREWARM_MIN_S,
                     help="least seconds of untimed full steps before the --warmup steps (0: one batch of %d steps: for runs under "
                          "a profiler, where every dispatch is slow)" % PREWARM_BATCH)
@@ -335,7 +339,7 @@ def main(argv=None):
     if dist is not None and not args.forward_only:
         probe = torch.ones((M, K), dtype=torch.float32, device=dev)
         timings = {}
-        for mode in ("all_reduce", "direct"):
+        for mode in (("all_reduce", "direct") if args.exchange == "auto" else (args.exchange,)):
             # A mode may fail on ONE rank only (point-to-point unavailable on its device): every rank then still joins
             # the collective that agrees on the outcome -- the MAX of (time, or inf on failure) -- outside the try, so that
             # nobody waits in it for a rank that took the except branch.
@@ -362,9 +366,11 @@ def main(argv=None):
             best = "all_reduce"
         exchange = {"used": best, "probe_ms": {k: (None if v == float("inf") else round(v * 1e3, 4)) for k, v in timings.items()},
                     "bytes": 4 * M * K,
-                    "what": "all-reduce(sum) of a gradient-sized buffer, 5 repetitions after 2, max over ranks: the backend's own "
-                            "all_reduce in 32 MB row chunks against parallel.direct_all_reduce (two rounds of simultaneous "
-                            "point-to-point transfers, one per link of the mesh); the faster is used by the timed steps"}
+                    "requested": args.exchange,
+                    "what": "all-reduce(sum) of a gradient-sized buffer, 5 repetitions after 2, max over ranks, per exchange form probed "
+                            "(--exchange auto probes both: the backend's own all_reduce in 32 MB row chunks and "
+                            "parallel.direct_all_reduce, two rounds of simultaneous point-to-point transfers, one per link of the "
+                            "mesh, and uses the faster; default: the backend's own)"}
         del probe
     reducer = parallel.OverlappedGradReducer(dist, backend=args.backend, mode=exchange["used"] if exchange else "all_reduce") \
         if dist is not None else None
