@@ -41,12 +41,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-# exp/atomic_bench.hip: the memory side takes 64-byte float-atomic requests at
+# exp/atomic_bench.hip (NOTEBOOK.md 5): the memory side takes 64-byte float-atomic requests at
 # ~22 G/s whatever their size or scope (3.0 M wave-atomics of two segments each: 0.614 ms)
 ATOMIC_REQUESTS_PER_S = 22e9
 # us per leaf crossing of a wavefront alone on its SIMD: r02 timeline of march_rec_kernel
 # (exp/trace_march.py, profiles/r02_march_timeline.txt) for the stepping alone; r01 timeline of
-# render_fwd_kernel ("Timelines") for stepping + shading in one chain
+# render_fwd_kernel (NOTEBOOK.md 5, "Timelines") for stepping + shading in one chain
 US_PER_CROSSING_UNLOADED = {"march": 0.72, "march+shade": 1.14}
 
 WORKLOADS = {
@@ -333,7 +333,7 @@ def main(argv=None):
         atomic_requests, merged_rows = ctr.read()
         features.grad = None
     # N > 1: which gradient exchange?  RCCL's own all-reduce (ring / tree over its channels) or the direct form priced in
-    # DESIGN.md 7 (reduce-scatter + all-gather as two rounds of simultaneous point-to-point transfers, one per xGMI link)?
+    # NOTEBOOK.md 7 (reduce-scatter + all-gather as two rounds of simultaneous point-to-point transfers, one per xGMI link)?
     # Measured here on a gradient-sized buffer, both checked against each other; the faster one is what the step uses.
     exchange = None
     if dist is not None and not args.forward_only:
@@ -748,7 +748,7 @@ def main(argv=None):
                 "bound": "floor: the rate at which the memory side takes 64-byte float-atomic requests (exp/atomic_bench.hip: 22 G/s)"
                          + (".  Not what binds the per-tile backward today: 15 % fewer requests (rows carried across the reduce's "
                             "16-record groups) made it 6 % SLOWER, shorter instruction paths in the same reduce 3 % faster -- its phases "
-                            "are serial per workgroup and latency-bound (DESIGN.md steps 39-41)"
+                            "are serial per workgroup and latency-bound (NOTEBOOK.md steps 39-41)"
                             if "grad_fused" in (route_bwd or "") else ""),
                 "atomic_requests": atomic_requests, "merged_rows": merged_rows,
                 "floor_ms": round(atomic_requests / ATOMIC_REQUESTS_PER_S * 1e3, 4), "measured_ms": round(bwd_ms, 4)}

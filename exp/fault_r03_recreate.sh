@@ -5,7 +5,7 @@
 # into the __forceinline__ device function with a dozen pointer parameters it had been, compiles the unit to
 # assembly with the resource remarks, and classifies every scratch_* instruction of the instance that was running
 # (grad_fused_kernel<SH, 9, single march>).  That the recreation IS the faulting build is shown by its numbers: 88
-# bytes of scratch for that instance, 68-112 for the SH9 instances, 0 for the others -- DESIGN.md 4.1's record of
+# bytes of scratch for that instance, 68-112 for the SH9 instances, 0 for the others -- NOTEBOOK.md 4.1's record of
 # the incident -- whereas a plain (not inlined) function gives 340-380.  No GPU needed.
 set -e
 root=$(cd $(dirname $0)/.. && pwd)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Builds exp/libsvoxt_roles8.so: the library with fwd_roles_kernel held to 64 registers
 (__launch_bounds__(512, 8): four workgroups per CU instead of three, at the price of a few spilled
-registers).  Run the benchmark with SVOXT_LIB=exp/libsvoxt_roles8.so to compare."""
+registers).  Run the benchmark with SVOXT_LIB=exp/libsvoxt_roles8.so to compare (NOTEBOOK.md step 33)."""
 import os
 import re
 import subprocess

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where fwd_roles_kernel's time goes: `build` writes exp/libsvoxt_rtrace.so, the library
+"""Where fwd_roles_kernel's time goes (NOTEBOOK.md step 33): `build` writes exp/libsvoxt_rtrace.so, the library
 with three time stamps added to the kernel (wall_clock64, 100 MHz): the first workgroup's start, the end of the
 LAST march, the end of the last shade -- plus the end of the last shade among the tiles whose march ended in the
 first half of the marching phase; `run` (GPU box) runs the headline's recording forward and prints them."""

@@ -170,7 +170,7 @@ int svoxt_volume_render_fwd(const svoxt_tree* tree, const svoxt_rays* rays,
  * tail launch), one that shades the lists: per 64-ray tile with eight wavefronts sharing the
  * work (3-channel payloads; only on request: svoxt_volume_render_fwd_scratch with SVOXT_LISTS_FWD_TWO_KERNELS), or with the channels of a row on
  * the lanes of a wavefront (RGBA-style rows of 8 / 16 / 32 floats: the default for them) --
- * instead of one kernel as long as its longest ray.  Other payloads,
+ * instead of one kernel as long as its longest ray (NOTEBOOK.md 5).  Other payloads,
  * tree->weight_accum, a NULL or too small workspace: exactly svoxt_volume_render_fwd.  Contents of the workspace on return are unspecified.
  * (Reference: volume_render, rt_kernel.cu:1362-1379; trace_ray :222-328.) */
 /* flags: 0, or an OR of the SVOXT_LISTS_* values below (how the scratch lists are filled); among them
@@ -342,7 +342,7 @@ typedef struct svoxt_sample_lists {
                               forward of 3-channel payloads (N = 2, no view rotations, sigma bitmask at hand) runs its march
                               and its shade as ONE launch: tiles are shaded in the order their marches finish, beside the
                               marches still running (per-tile states, then per-XCD ready queues of 64-bit entries -- tile id and a
-                              checksum of the tile's lists -- and their counters: fwd_roles_kernel).  Cleared by the
+                              checksum of the tile's lists -- and their counters: fwd_roles_kernel; NOTEBOOK.md step 33).  Cleared by the
                               forward together with the block table (one fill when it lies right behind pool_next's
                               counters).  Same lists, terms and pixels bit for bit.  NULL: two launches. */
 } svoxt_sample_lists;
@@ -355,7 +355,7 @@ int svoxt_fwd_fills_terms(const svoxt_tree* tree, const svoxt_options* opt, int3
 /* The sigma bitmask of svoxt_tree.sigma_mask (no counterpart in the reference): bytes for M rows, and the
  * build -- bit (row & 31) of 32-bit word (row >> 5) = features[row * K + K - 1] > sigma_thresh.  One read of a
  * 64-byte line per row (0.05 ms for 4.7 M rows of 32 floats); worth it where the feature table no longer fits
- * the Infinity Cache. */
+ * the Infinity Cache (see NOTEBOOK.md, step 26). */
 int64_t svoxt_sigma_mask_bytes(int64_t M);
 int svoxt_sigma_mask_build(const svoxt_tree* tree, float sigma_thresh, void* mask, void* stream);
 /* ... and, in the same launch (ABI v18), fill_bytes bytes at `fill` (device, 16-byte aligned, a multiple of 16) set to

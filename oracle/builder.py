@@ -1,6 +1,6 @@
 """CPU restatement of the reference's octree construction from a point cloud.
 
-TEST INFRASTRUCTURE ONLY (see oracle/README in DESIGN.md 3): imported by tests/,
+TEST INFRASTRUCTURE ONLY: imported by tests/,
 never by the product.  numpy, float32 arithmetic where the reference's is.
 
 The reference builds a frame's tree with (Artemis' usage of this package; the

@@ -14,7 +14,7 @@
 // (tests/golden/make_golden.py: tree topology from the reference's refine, SH
 // polynomials and row layout from its sh.py, format table, world->tree
 // transform) and (d) an independent vectorised PyTorch renderer with autograd
-// (oracle/torch_renderer.py).  See DESIGN.md section 4.
+// (oracle/torch_renderer.py).  See DESIGN.md section 5.
 //
 // Every function cites the reference lines it follows (paths relative to
 // /root/reference).  Arithmetic is written so that each C++ expression has

@@ -55,7 +55,7 @@ def _env_flag(name: str, default: str) -> bool:
 # SORT_RAYS_MIN rays on), "0" never, "1" always; RaysSpec.sort per call
 SORT_RAYS = os.environ.get("SVOXT_SORT_RAYS", "auto")
 SORT_RAYS_MIN = 16384
-# --- the two TOLERANCE modes (not result-neutral; both off by default)
+# --- the two TOLERANCE modes (not result-neutral; both off by default; NOTEBOOK.md 4)
 # SVOXT_BWD_EXACT=0: the single-march backward -- accum = sum_c g_c * out_c from the forward's output, one
 # sweep over the lists instead of two: equal up to the rounding of that sum, which moves 36 % of the
 # sigma-column entries by more than 1e-5 of their own value (tests/test_gpu_query_and_misc.py)

@@ -1,7 +1,7 @@
 // svoxt_bwd.hip -- volume_render_backward (trace_ray_backward, rt_kernel.cu:331-496, 675-694, 1402-1426) and
 // opacity_render_backward (:1593-1616) behind the C ABI: which kernel of svoxt_bwd_kernels.h serves a payload / list
 // combination.  A translation unit of its own so that the two halves of the library's kernels compile side by side
-// (svoxt_kernels.hip keeps the forward, the queries and the utilities).  DESIGN.md 5.
+// (svoxt_kernels.hip keeps the forward, the queries and the utilities).  DESIGN.md 4 (the measurements behind it: NOTEBOOK.md 5).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
 

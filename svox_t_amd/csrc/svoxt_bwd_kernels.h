@@ -2,7 +2,7 @@
 // per-ray kernel (marching or replaying sample lists, shaped atomics through LDS staging; its
 // two-kernel, tail-only and one-sigmoid-pass forms), the per-tile kernels (grad_merge_kernel,
 // grad_fused_kernel for 3-channel payloads, grad_wide_kernel for RGBA rows of 8 / 16 / 32 floats)
-// and the generic fallbacks.  See the file header of svoxt_kernels.hip and DESIGN.md 5.
+// and the generic fallbacks.  See the file header of svoxt_kernels.hip and DESIGN.md 4 (the measurements: NOTEBOOK.md 5).
 #pragma once
 
 #include <hip/hip_runtime.h>

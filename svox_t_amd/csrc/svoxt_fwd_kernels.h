@@ -1,7 +1,7 @@
 // svoxt_fwd_kernels.h -- volume_render forward (trace_ray, rt_kernel.cu:222-328): the one-kernel
 // forward (optionally recording sample lists), the generic fallback, and the forward as two kernels
 // (march, then shade per tile / with channels on lanes, plus their tail launches).  See the file
-// header of svoxt_kernels.hip and DESIGN.md 5.
+// header of svoxt_kernels.hip and DESIGN.md 4 (the measurements: NOTEBOOK.md 5).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -827,7 +827,7 @@ __host__ __device__ inline int64_t roles_group_of(const RolesMap& m, int b) {   
 
 // XF (r04; SH up to 9 basis functions): per-leaf view rotations -- the shading role evaluates a record's basis from its
 // leaf's matrix (shade_tile_body<..., XF>) and its hand-over holds the exponentials of THAT basis (grad_fused_kernel<..., 3, ..., XF>).
-// (r05, measured and not kept -- exp/r05/*.diff.txt, DESIGN.md 5: (a) the shading role PERSISTENT, at most as many shading
+// (r05, measured and not kept -- exp/r05/*.diff.txt, NOTEBOOK.md 4.1: (a) the shading role PERSISTENT, at most as many shading
 // workgroups as the chip holds, each taking tiles until a stop entry, tiles without samples not queued at all: forward
 // 0.2485 -> 0.2554 ms -- a pop, two dependent round trips, costs what the dispatch of a workgroup cost, and as a loop the
 // body keeps ~40 registers of invariants alive unless they are formed per tile behind asm barriers (79 -> 120 registers,

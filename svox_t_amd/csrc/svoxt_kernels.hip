@@ -25,7 +25,7 @@
 // unit so that the two halves compile side by side), svoxt_build.hip (octree from a point
 // cloud, construct_tree), svoxt_motion.hip (motion variants, point skinning), svoxt_order.hip
 // (coherent order for ray batches that are not images).
-// The design rationale and the measurements behind each choice are in DESIGN.md 5.
+// The design rationale and the measurements behind each choice are in DESIGN.md 4 and, step by step, NOTEBOOK.md 5.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
 

@@ -244,7 +244,7 @@ def direct_all_reduce(dist_module, grad: torch.Tensor, group=None) -> torch.Tens
         all-gather       every rank sends its summed range to each peer, again one transfer of S / W per link.
 
     Per link and direction 2 S / W bytes move in two rounds: 2 S / (W B) seconds at B bytes/s per link, against
-    2 (W - 1) S / (W B) for a ring that uses one link per step (DESIGN.md 7 has the table).  No padding, no staging copy of
+    2 (W - 1) S / (W B) for a ring that uses one link per step (NOTEBOOK.md 7 has the table).  No padding, no staging copy of
     the gradient: ranges are views, ragged splits are fine.  Adds happen in rank order on the owner (own, then peers
     ascending): the result is the same on every rank, bit for bit."""
     W, me = dist_module.get_world_size(group), dist_module.get_rank(group)
@@ -398,7 +398,7 @@ class OverlappedGradReducer:
                  mode: str = "all_reduce"):
         """mode: "all_reduce" -- the backend's own all-reduce per row chunk (RCCL chooses ring / tree and its channels);
         "direct" -- direct_all_reduce: reduce-scatter and all-gather as two rounds of simultaneous point-to-point
-        transfers, one per link of the mesh (the form priced for xGMI); "touched" -- sparse_all_reduce
+        transfers, one per link of the mesh (NOTEBOOK.md 7: the form priced for xGMI); "touched" -- sparse_all_reduce
         (only row blocks somebody touched; one host synchronisation per exchange, so start() then blocks the host)."""
         assert mode in ("all_reduce", "direct", "touched")
         self.dist, self.group, self.backend, self.mode = dist_module, group, backend, mode

@@ -56,11 +56,11 @@ def test_no_kernel_keeps_private_arrays_in_scratch_memory():
     -Rpass-analysis=kernel-resource-usage remarks next to the library).  No kernel may have a dynamic
     stack, and none more than a few spilled registers' worth of scratch: a per-lane array (feature
     row, basis, accumulators) that lands in scratch memory costs a memory round trip per access
-    (forward 0.33 -> 0.28 ms when 12 bytes left it) -- and scratch is the only place
+    (NOTEBOOK.md step 13: forward 0.33 -> 0.28 ms when 12 bytes left it) -- and scratch is the only place
     where an out-of-range private index could fault instead of reading another register.  The one
     unexplained abort in this project's records (r02, gpurun_out/r2q/t5.log) was an EXPERIMENT build
     that capped shade_tile_kernel at 64 registers: its SH16 instance, the first kernel of that test
-    run with a large spill (152 bytes per lane), is what was running."""
+    run with a large spill (152 bytes per lane), is what was running (NOTEBOOK.md 4.1)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("_svoxt_build", os.path.join(ROOT, "svox_t_amd", "build.py"))
     b = importlib.util.module_from_spec(spec)
@@ -84,7 +84,7 @@ def test_no_kernel_keeps_private_arrays_in_scratch_memory():
     # the ISA of that build, recreated in r04 (exp/fault_r03_recreate.sh, profiles/r04_fault_isa.txt), holds only
     # compile-time-offset register spills, stored under a full EXEC mask: no private array in memory, no index that
     # could leave it; the checked instances (tests/test_gpu_checked_backward.py) find no LDS / pool / table index
-    # out of range at any full-size geometry either.
+    # out of range at any full-size geometry either (NOTEBOOK.md 4.1).
     # (r04: the table instances of grad_wide_kernel are compiled for 64 registers -- four workgroups per CU: backward
     # 1.70 -> 1.59 ms at depth 9 -- and keep 36-52 bytes of loop invariants in scratch for it)
     assert all(v <= 64 for v in worst.values()), worst

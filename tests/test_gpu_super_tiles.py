@@ -1,4 +1,4 @@
-"""The super-tile walk of image batches (svoxt_set_super_tile_rows): which launch tile renders
+"""The super-tile walk of image batches (NOTEBOOK.md step 70; svoxt_set_super_tile_rows): which launch tile renders
 which 8 x 8 pixels changes, nothing a caller sees may.  The library switches it on for trees of more than 2^21 feature rows
 only -- config 4's full-size tests run under it -- so here the threshold is set to 0 and small images whose tile grid
 is ragged against the 8 x 8 tiles of a super-tile (25 x 9, 8 x 8, 3 x 17 tiles) go through every image route."""

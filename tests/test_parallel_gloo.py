@@ -216,7 +216,7 @@ def _exchange_worker(rank, world, port, result_dir):
 @pytest.mark.parametrize("world", [2, 3])
 def test_direct_and_touched_block_exchanges_equal_the_plain_sum(tmp_path, world):
     """parallel.direct_all_reduce (reduce-scatter + all-gather as two rounds of simultaneous point-to-point
-    transfers: the form DESIGN.md 7 prices for the xGMI mesh) and parallel.sparse_all_reduce (only the row blocks
+    transfers: the form NOTEBOOK.md 7 prices for the xGMI mesh) and parallel.sparse_all_reduce (only the row blocks
     somebody touched) against dist.all_reduce on 2 and 3 gloo ranks: ragged row splits, fewer rows than ranks,
     block masks that differ per rank, blocks nobody touched, a short last block."""
     port = 30500 + (os.getpid() + 7 * world) % 900

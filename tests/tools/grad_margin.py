@@ -1,5 +1,5 @@
 """Report how far the HIP gradient sits from the oracle's, as a fraction of the
-1e-5 * S tolerance.  Test tooling: uses oracle/.
+1e-5 * S tolerance (NOTEBOOK.md 4).  Test tooling: uses oracle/.
 
     python tests/tools/grad_margin.py        # on the GPU box, from the repo root
 """
