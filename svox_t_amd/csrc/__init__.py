@@ -468,12 +468,58 @@ def _wants_sort(rays) -> bool:
     return bool(s)
 
 
+# A batch that IS a row-major pinhole image but was not declared one -- what the reference's API gives a caller: its
+# RaysSpec has no image fields (data_spec.hpp:52-65) -- is recognised (r05): one origin for all rays and directions that
+# move by a small step along a row and jump where a row wraps.  The first wrap gives the width; it must divide the batch,
+# width and height must be multiples of 8 and the second row must wrap where the first did.  Found once per set of ray
+# tensors (one host read, cached on their storage and version), the batch is then walked in 8 x 8 pixel tiles like a
+# declared image instead of being sorted: the reference-API route of the headline 1 102 -> the hinted route's figure.
+# Results are per ray and do not depend on the walk: a wrong guess could only cost time.  DETECT_IMAGES False: off.
+DETECT_IMAGES = True
+_IMAGE_SHAPES: dict = {}        # (origins ptr, dirs ptr, versions, Q) -> (H, W) or None
+
+
+def _detect_image(rays):
+    if not DETECT_IMAGES:
+        return None
+    o, d = rays.origins, rays.dirs
+    Q = o.shape[0]
+    if Q < 4096 or Q % 64 or d.dtype != torch.float32 or not d.is_cuda or getattr(rays, "sort", None) is not None:
+        return None
+    key = (o.data_ptr(), d.data_ptr(), o._version, d._version, Q)
+    if key in _IMAGE_SHAPES:
+        return _IMAGE_SHAPES[key]
+    shape = None
+    n = min(Q, 1 << 16)
+    with torch.no_grad():
+        step = (d[1:n] - d[:n - 1]).abs().sum(dim=1)                       # |dir[i + 1] - dir[i]|: small along a row, a jump at a wrap
+        same_origin = (o[:n] == o[:1]).all()
+        thr = step[:1024].median() * 4
+        wraps = (step > thr).nonzero()[:2, 0]                              # the first two wraps
+        info = torch.cat([same_origin.view(1).long(), wraps.new_tensor([wraps.numel()]), wraps, wraps.new_zeros(2)])[:4].tolist()   # ONE host read
+    if info[0] == 1 and info[1] >= 1:
+        W = info[2] + 1
+        if W >= 8 and W % 8 == 0 and Q % W == 0 and (Q // W) % 8 == 0 and (info[1] < 2 or info[3] + 1 == 2 * W):
+            shape = (Q // W, W)
+    if len(_IMAGE_SHAPES) >= 16:
+        _IMAGE_SHAPES.clear()
+    _IMAGE_SHAPES[key] = shape
+    return shape
+
+
 def _in_coherent_order(tree, rays, opt):
     """(rays spec to render, perm): the batch with svoxt_ray_order's permutation attached when that pays
     (RaysSpec.order: the kernels walk the batch in that order, every ray's data stays where it is, so
     perm -- what a caller would have to undo -- is None), else as it is."""
     if not _wants_sort(rays):
         return rays, None
+    shape = _detect_image(rays)
+    if shape is not None:        # an undeclared image: walked in tiles, nothing to sort
+        s = RaysSpec()
+        s.origins, s.dirs, s.vdirs = rays.origins, rays.dirs, rays.vdirs
+        s.image_height, s.image_width = shape
+        s.sort = False
+        return s, None
     s = RaysSpec()
     s.origins, s.dirs, s.vdirs = rays.origins, rays.dirs, rays.vdirs
     s.order = _ray_order32(tree, rays, opt)      # the kernels read it: no gather of the rays, no scatter of the pixels

@@ -533,6 +533,7 @@ def test_plain_calls_hand_the_forwards_lists_to_the_backward(name, gpu, monkeypa
     want_out = O.volume_render(c.oracle_tree(), *c.rays_np(), c.oracle_opts())
     want, absum = O.volume_render_backward(c.oracle_tree(), *c.rays_np(), c.oracle_opts(), g.cpu().numpy(), want_abs=True)
     monkeypatch.setattr(_C, "SORT_RAYS_MIN", 1024)          # these small batches take the sorted route too
+    monkeypatch.setattr(_C, "DETECT_IMAGES", False)         # (the batch IS a 64 x 64 pinhole image: r05 would recognise it and walk it in tiles)
     for sort in (None, False):
         f = tree.features.detach().clone().requires_grad_(True)
         rs = _C.RaysSpec()                                   # as the reference fills it: three tensors
