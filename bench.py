@@ -510,8 +510,8 @@ def main(argv=None):
 
     # the other routes, for the record (same process, after the timed region)
     WHAT = {"plain": "the two calls the reference's own autograd function makes (svox_t/renderer.py:60-77) on "
-                     "svox_t_amd.csrc: no image hint; the operator layer orders the rays, records and replays "
-                     "the sample lists by itself",
+                     "svox_t_amd.csrc: no image hint; the operator layer recognises the batch as a row-major pinhole image "
+                     "(else it would sort the rays by entry point), records and replays the sample lists by itself",
             "hinted": "VolumeRenderer.forward(..., image_shape=(H, W))",
             "camera": "VolumeRenderer.render_persp (svox_t/renderer.py:310-366 -> volume_render_image, rt_kernel.cu:1153-1238): "
                       "the kernels generate the pinhole rays themselves, no ray tensors are read"}
