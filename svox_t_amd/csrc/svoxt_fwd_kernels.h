@@ -951,6 +951,8 @@ fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restri
 // ray's group at once (lane c takes record c mod 8: sigma of that record from the sigma lane, delta_t from the lane's
 // own copy of the record line) instead of eight times by every lane; the quotients w / (1 + e) by div_unit_range.
 // Per record and lane ~30 vector instructions where the exact instance without the table executes 74 (r03 PMC).
+// (r05, measured and not kept: the next block's record line requested behind this block's row gathers -- 74 registers, 6
+// wavefronts per SIMD instead of 7: config 4 forward 1.047 -> 1.067 ms.  The kernel does not wait for its records.)
 template <int K, bool STOP, bool FAST, bool ETAB = false>
 __global__ void __launch_bounds__(256)
 shade_chan_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L,
