@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""render_depth (rt_kernel.cu:782-834) on the two benchmark geometries: 800 x 800 rays on the depth-8 SH9 tree and
+"""render_depth (rt_kernel.cu:782-834) and the weight-accumulating forward on the two benchmark geometries: 800 x 800 rays on the depth-8 SH9 tree and
 BASELINE configs[3]'s second output, 1024 x 1024 rays on the depth-9 tree with 32-float rows.
 
     python scripts/depth_timing.py [--reps 30]
@@ -47,6 +47,18 @@ def main():
             except TypeError:
                 continue
             print(f"depth {depth}, K {K}, {size} x {size}: {name:46s} {ms:7.3f} ms  {Q / ms / 1e3:8.1f} Mrays/s", flush=True)
+        # the forward that also adds every sample's compositing weight to its leaf slot (tree._weight_accum,
+        # rt_kernel.cu:266-267, 309-311; svox.py:948-969): SURVEY 8 f3, one float atomic per sample
+        with torch.no_grad(), tree.accumulate_weights() as acc:
+            ms = timed(lambda: r(feats, rays), a.reps)
+            total = float(acc.value.double().sum())
+        with torch.no_grad():
+            ms0 = timed(lambda: r(feats, rays), a.reps)
+        print(f"depth {depth}, K {K}, {size} x {size}: {'volume_render + per-leaf weight accumulation':46s} {ms:7.3f} ms  {Q / ms / 1e3:8.1f} Mrays/s"
+              f"   (the same call without: {ms0:.3f} ms; sum of weights over {a.reps + 3} calls {total:.1f})", flush=True)
+        if os.environ.get("SVOXT_TIMING_ROUTES"):
+            import svox_t_amd.csrc as _C
+            print("   route:", _C.LAST_ROUTE["forward"], flush=True)
 
 
 if __name__ == "__main__":

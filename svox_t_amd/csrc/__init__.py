@@ -691,7 +691,10 @@ def _volume_render(tree, rays, opt, record):
     dev = tree.features.device
     lists = None
     wide = co.format == FORMAT_RGBA and ct.K in (8, 16, 32)
-    split = (FWD_SPLIT != "0") if FWD_SPLIT != "" else wide
+    # (per-leaf weight accumulation: the library's one-kernel forward alone adds the weights -- fwd_split_payload -- so no
+    # scratch, mask or table is made for a forward that would not touch them; r05: its untouched scratch was read as the
+    # pool's use, the r04 mistake of the 3-channel payloads over again)
+    split = ((FWD_SPLIT != "0") if FWD_SPLIT != "" else wide) and ct.weight_accum is None
     can_rec = _lib.svoxt_can_record(ctypes.byref(ct), ctypes.byref(co)) if (record and BWD_LIST_SAMPLES > 0 and cr.Q > 0) else 0
     will_record = bool(can_rec)
     if can_rec == 2:

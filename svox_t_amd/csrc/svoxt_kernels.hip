@@ -683,6 +683,9 @@ static int fwd_common(const svoxt_tree* tree, const svoxt_rays* rays, const svox
         }
         if (done) return check_launch(fn);
     }
+    // (r05) Scratch lists this forward will not use (no two-kernel forward for the payload, or the tree accumulates weights):
+    // their block counters are still left "nothing taken", so that a caller who sizes its pool by them reads a defined state.
+    if (scratch != nullptr && (rc = lists_begin(scratch, rays->Q, st, fn))) return rc;
     if (uses_xform(tree, opt)) {
         // per-leaf view rotations re-evaluate the basis per sample: specialised for SH
         // payloads on N = 2 trees, the generic kernel otherwise

@@ -263,7 +263,7 @@ def test_weight_accumulation(gpu):
     assert (w[empty] == 0).all()
 
 
-@pytest.mark.parametrize("name", ["d5_rgba4", "d6_sh9", "random2", "random3"])
+@pytest.mark.parametrize("name", ["d5_rgba4", "d5_rgba8", "d6_sh9", "random2", "random3"])
 @pytest.mark.parametrize("accel", ["grid", "plain"])
 def test_weight_accumulation_matches_oracle(gpu, name, accel, monkeypatch):
     """tree._weight_accum (rt_kernel.cu:266-267, 309-311; svox.py:948-969) per leaf slot against the
@@ -290,6 +290,7 @@ def test_weight_accumulation_matches_oracle(gpu, name, accel, monkeypatch):
         rays_np = (o.numpy(), d.numpy(), v.numpy())
     else:
         cfg = dict(d5_rgba4=dict(depth=5, K=4, data_format="RGBA", width=64, height=64),
+                   d5_rgba8=dict(depth=5, K=8, data_format="RGBA", width=64, height=64),    # rows with a two-kernel forward: not taken here
                    d6_sh9=dict(depth=6, K=28, data_format="SH9", width=96, height=96))[name]
         c = Case(**cfg)
         tree, ot = c.tree(gpu), c.oracle_tree()
@@ -297,11 +298,15 @@ def test_weight_accumulation_matches_oracle(gpu, name, accel, monkeypatch):
         fmt, bd = c.format, c.basis_dim
         rays, rays_np = c.rays_gpu(gpu), c.rays_np()
     r = svox.VolumeRenderer(tree)
+    _C._POOL_HINT.clear()
     for fast in (False, True):
         th = 1e-2 if fast else 0.0
         with torch.no_grad(), tree.accumulate_weights() as acc:
             out = r(features, rays, fast=fast)
             got = acc.value.double().cpu().numpy()
+        # (r05) the weight-accumulating forward is the one-kernel forward: no scratch lists were made for it, so none
+        # was read back as a pool's use
+        assert not _C._POOL_HINT, _C._POOL_HINT
         want_out, want = O.volume_render_weights(ot, *rays_np, O.make_options(format=fmt, basis_dim=bd,
                                                                                sigma_thresh=th, stop_thresh=th))
         np.testing.assert_array_equal(out.cpu().numpy(), want_out)
