@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SVOXT_ABI_VERSION 21
+#define SVOXT_ABI_VERSION 22
 
 enum {
     SVOXT_OK = 0,
@@ -565,6 +565,19 @@ int     svoxt_gather_rays(const svoxt_rays* rays, const int32_t* perm, float* or
                           void* stream);
 int     svoxt_permute_rows(const float* src, const int32_t* perm, float* dst, int64_t n, int32_t cols,
                            int32_t scatter, void* stream);
+
+/* Is an undeclared batch a row-major pinhole image (no counterpart in the reference; ABI v22)?  A caller of the
+ * reference's API hands over 800 x 800 rays as [640 000, 3] arrays and says nothing; walked in 8 x 8 pixel tiles such a
+ * batch needs no sort and its tiles are coherent in direction too.  Two small launches over the first 65 536 rays write
+ * result[0 .. 4] (device, int32, room for SVOXT_IMAGE_PROBE_WORDS words: the rest is scratch): [0] 1 if every origin
+ * equals the first; [1] how many jumps of the L1 distance between consecutive directions were found (at most 2: a jump
+ * is more than four times the median of the first 1 024 distances); [2], [3] their positions; [4] `ticket`, so that a
+ * host that reads the words later, from a buffer it reuses, can tell whose answer it holds.  An image of width W has
+ * its first jump at W - 1 and its second at 2 W - 1; the caller then sets image_width / image_height (which must be
+ * multiples of 8 with W * H = Q).  A hint like every other: results do not depend on what the caller concludes.
+ * Q >= 4096; not for camera mode. */
+#define SVOXT_IMAGE_PROBE_WORDS 256
+int     svoxt_image_probe(const svoxt_rays* rays, int32_t* result, int32_t ticket, void* stream);
 
 /* ---- Octree construction from a point cloud -------------
  *

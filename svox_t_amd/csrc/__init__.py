@@ -470,13 +470,58 @@ def _wants_sort(rays) -> bool:
 
 # A batch that IS a row-major pinhole image but was not declared one -- what the reference's API gives a caller: its
 # RaysSpec has no image fields (data_spec.hpp:52-65) -- is recognised (r05): one origin for all rays and directions that
-# move by a small step along a row and jump where a row wraps.  The first wrap gives the width; it must divide the batch,
-# width and height must be multiples of 8 and the second row must wrap where the first did.  Found once per set of ray
-# tensors (one host read, cached on their storage and version), the batch is then walked in 8 x 8 pixel tiles like a
-# declared image instead of being sorted: the reference-API route of the headline 1 102 -> the hinted route's figure.
-# Results are per ray and do not depend on the walk: a wrong guess could only cost time.  DETECT_IMAGES False: off.
+# move by a small step along a row and jump where a row wraps (svoxt_image_probe: one small launch, four words back).
+# The first wrap gives the width; it must divide the batch, width and height must be multiples of 8 and the second row
+# must wrap where the first did.  The batch is then walked in 8 x 8 pixel tiles like a declared image instead of being
+# sorted: the reference-API route of the headline 1 102 -> the hinted route's figure.
+# Results are per ray and do not depend on the walk: a wrong guess can only cost time.  That is what lets a training loop,
+# which hands over NEW tensors every step, go without the host read: the answer is remembered per set of tensor objects
+# (their versions and storage), and once IMAGE_TRUST_AFTER batches of a size in a row gave the same answer the next one
+# is TAKEN to give it too -- its probe is still enqueued and read a step later, without waiting; one that disagrees ends
+# the trust (waiting for the read drains the queue the host had filled ahead: 0.51 -> 0.77 ms per step at 800 x 800).
+# DETECT_IMAGES False: off.
 DETECT_IMAGES = True
-_IMAGE_SHAPES: dict = {}        # (origins ptr, dirs ptr, versions, Q) -> (H, W) or None
+IMAGE_TRUST_AFTER = 3
+_IMAGE_SHAPES: dict = {}        # id(dirs tensor) -> [weakrefs to dirs and origins, (addresses, versions, Q), (H, W) or None, unread probe or None]
+_IMAGE_TRUST: dict = {}         # Q -> [last answer, answers like it in a row, the entry of _IMAGE_SHAPES whose probe is unread or None]
+_PROBE_RING: list = [None, 0]   # pinned int32 [64, 8], the next ticket
+
+
+def _probe_row():
+    """(row of the pinned ring, ticket): a probe's five words land there; the ticket tells a late reader whose they are."""
+    if _PROBE_RING[0] is None:
+        _PROBE_RING[0] = torch.zeros((64, 8), dtype=torch.int32, pin_memory=True)
+    _PROBE_RING[1] = _PROBE_RING[1] % 0x7ffffff0 + 1
+    return _PROBE_RING[0][_PROBE_RING[1] % 64], _PROBE_RING[1]
+
+
+def _image_shape_from(info, Q):
+    if info[0] == 1 and info[1] >= 1:
+        W = info[2] + 1
+        if W >= 8 and W % 8 == 0 and Q % W == 0 and (Q // W) % 8 == 0 and (info[1] < 2 or info[3] + 1 == 2 * W):
+            return (Q // W, W)
+    return None
+
+
+def _settle_probe(ent, Q):
+    """The probe of a batch whose answer was taken on trust has arrived: the entry gets the answer it gave, the trust its due."""
+    _, row, ticket = ent[4]
+    ent[4] = None
+    tr = _IMAGE_TRUST.get(Q)
+    if tr is not None and tr[2] is ent:
+        tr[2] = None
+    info = row.tolist()
+    if info[4] != ticket:                  # the ring came round before anybody looked: nothing learnt, nothing trusted
+        if tr is not None:
+            tr[1] = 0
+        return
+    got, assumed = _image_shape_from(info, Q), ent[3]
+    ent[3] = got
+    if tr is not None:
+        if got == assumed and got == tr[0]:
+            tr[1] += 1
+        else:
+            tr[0], tr[1] = got, 1
 
 
 def _detect_image(rays):
@@ -486,25 +531,44 @@ def _detect_image(rays):
     Q = o.shape[0]
     if Q < 4096 or Q % 64 or d.dtype != torch.float32 or not d.is_cuda or getattr(rays, "sort", None) is not None:
         return None
-    key = (o.data_ptr(), d.data_ptr(), o._version, d._version, Q)
-    if key in _IMAGE_SHAPES:
-        return _IMAGE_SHAPES[key]
-    shape = None
-    n = min(Q, 1 << 16)
-    with torch.no_grad():
-        step = (d[1:n] - d[:n - 1]).abs().sum(dim=1)                       # |dir[i + 1] - dir[i]|: small along a row, a jump at a wrap
-        same_origin = (o[:n] == o[:1]).all()
-        thr = step[:1024].median() * 4
-        wraps = (step > thr).nonzero()[:2, 0]                              # the first two wraps
-        info = torch.cat([same_origin.view(1).long(), wraps.new_tensor([wraps.numel()]), wraps, wraps.new_zeros(2)])[:4].tolist()   # ONE host read
-    if info[0] == 1 and info[1] >= 1:
-        W = info[2] + 1
-        if W >= 8 and W % 8 == 0 and Q % W == 0 and (Q // W) % 8 == 0 and (info[1] < 2 or info[3] + 1 == 2 * W):
-            shape = (Q // W, W)
-    if len(_IMAGE_SHAPES) >= 16:
+    # (the tensor OBJECTS, their versions and storage: an address alone comes back with other rays in it once a batch is
+    # freed -- r05: a shuffled batch at the address of last step's image was walked as that image, 0.73 -> 2.2 ms)
+    key = id(d)
+    ent = _IMAGE_SHAPES.get(key)
+    stamp = (o.data_ptr(), d.data_ptr(), o._version, d._version, Q)
+    if ent is not None and ent[0]() is d and ent[1]() is o and ent[2] == stamp:
+        if ent[4] is not None and ent[4][0].query():
+            _settle_probe(ent, Q)
+        return ent[3]
+    tr = _IMAGE_TRUST.setdefault(Q, [None, 0, None])
+    if tr[2] is not None and tr[2][4] is not None and tr[2][4][0].query():      # an earlier batch's probe has arrived
+        _settle_probe(tr[2], Q)
+    cr = _pack_rays(rays)
+    dev = d.device
+    with torch.cuda.device(dev):
+        words = torch.empty((256,), dtype=torch.int32, device=dev)              # (SVOXT_IMAGE_PROBE_WORDS)
+        row, ticket = _probe_row()
+        _call("svoxt_image_probe", ctypes.byref(cr), _ptr(words), ticket, _stream(dev))
+        row.copy_(words[:8], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+    ent = [weakref.ref(d, lambda _r, _k=key: _IMAGE_SHAPES.pop(_k, None)), weakref.ref(o), stamp, None, None]
+    if tr[1] >= IMAGE_TRUST_AFTER:
+        ent[3], ent[4] = tr[0], (ev, row, ticket)            # taken on trust; read when it has arrived (the next call that looks)
+        if tr[2] is None or tr[2][4] is None:
+            tr[2] = ent
+    else:
+        ev.synchronize()
+        info = row.tolist()
+        ent[3] = _image_shape_from(info, Q) if info[4] == ticket else None
+        if ent[3] == tr[0]:
+            tr[1] += 1
+        else:
+            tr[0], tr[1] = ent[3], 1
+    if len(_IMAGE_SHAPES) >= 64:
         _IMAGE_SHAPES.clear()
-    _IMAGE_SHAPES[key] = shape
-    return shape
+    _IMAGE_SHAPES[key] = ent
+    return ent[3]
 
 
 def _in_coherent_order(tree, rays, opt):

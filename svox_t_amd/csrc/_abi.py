@@ -16,7 +16,7 @@ if not os.path.exists(LIB_PATH):
 
 _lib = ctypes.CDLL(LIB_PATH)
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 FORMAT_RGBA, FORMAT_SH, FORMAT_SG, FORMAT_ASG = 0, 1, 2, 3
 
 
@@ -131,6 +131,7 @@ EXPORTS = {
     "svoxt_step_backward": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, _P(_CStep), _vp, _vp]),
     "svoxt_ray_order_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "svoxt_ray_order": (ctypes.c_int, [_P(_CTree), _P(_CRays), _P(_COptions), _vp, _vp, ctypes.c_int64, _vp]),
+    "svoxt_image_probe": (ctypes.c_int, [_P(_CRays), _vp, _i32, _vp]),
     "svoxt_gather_rays": (ctypes.c_int, [_P(_CRays), _vp, _vp, _vp, _vp, _vp]),
     "svoxt_permute_rows": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _vp]),
     "svoxt_accel_bytes": (ctypes.c_int64, [_i32, ctypes.c_int64]),

@@ -210,6 +210,65 @@ scan_chunks_kernel(const uint32_t* __restrict__ counts, size_t n, const uint32_t
     }
 }
 
+// Is this batch a row-major pinhole image nobody declared?  The first 65 536 rays are looked at: the L1 distance between
+// consecutive directions is small along an image row and jumps where the next row starts.  res[0]: every origin equals
+// the first; res[1]: jumps found (at most 2); res[2], res[3]: their positions; res[4]: the caller's ticket.  The
+// threshold is four times the (lower) median of the first 1 024 distances, which every workgroup works out for itself.
+// Two launches: 64 workgroups, a ray per thread, leave their two first jumps in res[8 + 3 b ..]; one wavefront merges.
+constexpr int kProbeThreads = 1024, kProbeBlocks = 64, kProbeNone = 0x7fffffff;
+__device__ __forceinline__ float probe_step(const float* __restrict__ d, int i) {
+    return (fabsf(d[3 * (i + 1)] - d[3 * i]) + fabsf(d[3 * (i + 1) + 1] - d[3 * i + 1])) + fabsf(d[3 * (i + 1) + 2] - d[3 * i + 2]);
+}
+__global__ void __launch_bounds__(kProbeThreads)
+image_probe_kernel(const float* __restrict__ o, const float* __restrict__ d, int64_t Q, int32_t* __restrict__ res) {
+    __shared__ float s[kProbeThreads];
+    __shared__ float s_med;
+    __shared__ int s_same, s_first, s_second;
+    const int t = (int)threadIdx.x;
+    const int n = (int)(Q < (int64_t)kProbeThreads * kProbeBlocks ? Q : (int64_t)kProbeThreads * kProbeBlocks);
+    if (t == 0) { s_med = __builtin_inff(); s_same = 1; s_first = kProbeNone; s_second = kProbeNone; }
+    s[t] = probe_step(d, t);                                 // (the host refuses Q < 4 096)
+    __syncthreads();
+    const float mine = s[t];
+    int lt = 0, le = 0;
+    for (int j = 0; j < kProbeThreads; ++j) { const float x = s[j]; lt += x < mine ? 1 : 0; le += x <= mine ? 1 : 0; }
+    if (lt <= kProbeThreads / 2 - 1 && kProbeThreads / 2 - 1 < le) s_med = mine;       // (every such thread holds the same value)
+    __syncthreads();
+    const float thr = s_med * 4.f;
+    const int i = (int)blockIdx.x * kProbeThreads + t;
+    bool jump = false;
+    if (i < n) {
+        if (!(o[3 * i] == o[0] && o[3 * i + 1] == o[1] && o[3 * i + 2] == o[2])) s_same = 0;
+        jump = i < n - 1 && probe_step(d, i) > thr;
+        if (jump) atomicMin(&s_first, i);
+    }
+    __syncthreads();
+    if (jump && i > s_first) atomicMin(&s_second, i);
+    __syncthreads();
+    if (t == 0) {
+        res[8 + 3 * blockIdx.x] = s_same;
+        res[9 + 3 * blockIdx.x] = s_first;
+        res[10 + 3 * blockIdx.x] = s_second;
+    }
+}
+__global__ void __launch_bounds__(64)
+image_probe_merge_kernel(int32_t* __restrict__ res, int32_t ticket) {
+    const int b = (int)threadIdx.x;                          // kProbeBlocks == 64: a workgroup's partial per lane
+    const int same = res[8 + 3 * b], f = res[9 + 3 * b], s2 = res[10 + 3 * b];
+    int first = f;
+    for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off, 64));
+    int second = f > first ? f : s2;                         // this workgroup's smallest jump past the batch's first
+    for (int off = 32; off > 0; off >>= 1) second = min(second, __shfl_xor(second, off, 64));
+    const unsigned long long all_same = __ballot(same != 0);
+    if (b == 0) {
+        res[0] = all_same == ~0ull ? 1 : 0;
+        res[1] = (first != kProbeNone ? 1 : 0) + (second != kProbeNone ? 1 : 0);
+        res[2] = first != kProbeNone ? first : 0;
+        res[3] = second != kProbeNone ? second : 0;
+        res[4] = ticket;
+    }
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace svoxt
@@ -253,6 +312,21 @@ int svoxt_ray_order(const svoxt_tree* tree, const svoxt_rays* rays, const svoxt_
     hipLaunchKernelGGL(scan_chunks_kernel, dim3((unsigned)kScanChunks), dim3(kScanThreads), 0, st, counts, kOrderCells, chunk_sums, starts);
     if ((rc = check_launch(fn))) return rc;
     hipLaunchKernelGGL(ray_place_kernel, dim3(nb), dim3(kOrderBlock), 0, st, keys, ranks, starts, (int64_t)n, perm);
+    return check_launch(fn);
+}
+
+int svoxt_image_probe(const svoxt_rays* rays, int32_t* result, int32_t ticket, void* stream) {
+    const char* fn = "svoxt_image_probe";
+    static_assert(8 + 3 * kProbeBlocks <= SVOXT_IMAGE_PROBE_WORDS, "the partials fit the result buffer");
+    int rc;
+    if ((rc = check_rays(rays, fn))) return rc;
+    if (result == nullptr) return set_error(SVOXT_ERR_INVALID, "%s: result is NULL", fn);
+    if (rays->c2w != nullptr || rays->origins == nullptr || rays->dirs == nullptr)
+        return set_error(SVOXT_ERR_INVALID, "%s: a batch of ray arrays is needed", fn);
+    if (rays->Q < 4096) return set_error(SVOXT_ERR_INVALID, "%s: fewer than 4096 rays", fn);
+    hipLaunchKernelGGL(image_probe_kernel, dim3(kProbeBlocks), dim3(kProbeThreads), 0, (hipStream_t)stream, rays->origins, rays->dirs,
+                       rays->Q, result);
+    hipLaunchKernelGGL(image_probe_merge_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, result, ticket);
     return check_launch(fn);
 }
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_C.EXPORTS)          # the ctypes table and the header agree
-    assert lib.svoxt_abi_version() == _C.ABI_VERSION == 21
+    assert lib.svoxt_abi_version() == _C.ABI_VERSION == 22
 
 
 def test_struct_layouts_match_header(tmp_path):

@@ -36,7 +36,9 @@ def test_bench_json_contract(gpu):
     ref = rf["reference_equivalent"]
     assert abs(ref["gbps"] - ref["bytes_per_step"] / (r["ms_per_step"] * 1e-3) / 1e9) < 0.01 * ref["gbps"]
     assert 4.9e9 < ref["bytes_per_step"] < 5.2e9                                        # 1.225 GB forward + 3.811 GB backward
-    assert 0 < r["value_plain"] <= r["value"] * 1.05
+    # (against the better of the wall-clock and the event figure: over this test's 3 timed steps the wall clock carries the
+    # first forward's launch gap; the plain route, recognised as an image since r05, is within a few per cent of the hinted one)
+    assert 0 < r["value_plain"] <= max(r["value"], r["value_median"]) * 1.05
     # the line says what happened step by step: the K intervals, their spread, the median's value,
     # and what the untimed warm-up saw -- by time and convergence, not by count
     ps = r["per_step_ms"]
