@@ -1308,7 +1308,8 @@ grad_fused_kernel(TreeDev tr, RaysDev rays, Opts opt, const float* __restrict__ 
 // final transmittance in aux, as the tail-only launch does), each compiled for its own occupancy: backward 1.31 -> 1.41-1.42 ms at
 // 8 / 8, 8 / 6 and 6 / 6 wavefronts per SIMD.  Sweep 1 alone needs 72 registers without scratch, sweep 2 alone 80 -- no gain there --
 // and as one launch the workgroups' latency-bound sweeps overlap the atomic-rate-bound reduces of their neighbours, which two
-// launches give up.)
+// launches give up.  Profiled apart at config 4 (exp/prof_lib.sh): sweep 1 0.487 ms -- no atomics: its row gathers, lane = record, and
+// ~17 instructions per column -- sweep 2 0.878 ms against the 0.54 ms its 11.8 M atomic requests take at the memory side.)
 // ETAB (exact mode, r04): the rows are read from tr.etab -- etab[row][c] = pexpf(-features[row][c]), sigma in the last
 // column (exp_table_kernel, built once per forward) -- so neither sweep forms the exponential of a feature again, and
 // the double-precision reciprocals 1 / (1 + e) take rcp_unit_range (the compiler's division sequence minus what their
