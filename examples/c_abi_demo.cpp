@@ -71,8 +71,9 @@ int main(int argc, char** argv) {
     rays.image_width = (int32_t)h[6]; rays.image_height = (int32_t)h[7];
     float* d_gout = to_device(grad_out);
 
-    // optional: the acceleration grid (a cache of the descent; results do not depend on it)
-    const int g = 5;
+    // optional: the acceleration grid (a cache of the descent; results do not depend on it) -- in 4 x 4 x 4 bricks, the
+    // layout for a grid that training steps render through (SVOXT_ACCEL_BRICKS)
+    const int g = 5 | SVOXT_ACCEL_BRICKS;
     void* cells = nullptr;
     HIP_OK(hipMalloc(&cells, svoxt_accel_bytes(g, tree.n_internal)));
     SVOXT_OK_(svoxt_accel_build(&tree, g, cells, st));

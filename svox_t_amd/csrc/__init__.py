@@ -35,7 +35,7 @@ import torch
 from ._abi import (ABI_VERSION, EXPORTS, FORMAT_ASG, FORMAT_RGBA, FORMAT_SG, FORMAT_SH, LIB_PATH, LISTS_BEGUN, LISTS_FWD_AGENT_FENCE,
                    LISTS_FWD_NO_OVERLAP, LISTS_FWD_ONE_KERNEL, LISTS_FWD_TWO_KERNELS, LISTS_GRAD_ZEROED, LISTS_NATIVE_MATH,
                    LISTS_TEST_DROP, LISTS_TEST_NOPOLL, LISTS_TEST_STALE, _CLists, _CMotion, _COptions, _CRays, _CTree, _lib)
-from ._marshal import (ACCEL_LOG2, CameraSpec, RaysSpec, RenderOptions, TreeSpec, _ACCEL_CACHE, _accel_for, _accel_log2_for,
+from ._marshal import (ACCEL_BRICKS, ACCEL_LOG2, CameraSpec, RaysSpec, RenderOptions, TreeSpec, _ACCEL_CACHE, _accel_for, _accel_log2_for,
                        _call, _check_input, _numel, _pack_camera, _pack_opts, _pack_rays, _pack_tree, _pack_tree_accel, _ptr,
                        _stream, get_out_data_dim)
 
@@ -201,7 +201,7 @@ def invalidate_caches(*tensors) -> None:
         _GRAD_SCRATCH.clear()
         return
     ids = {id(t) for t in tensors if isinstance(t, torch.Tensor)}
-    for k in [k for k, ent in _ACCEL_CACHE.items() if k in ids or id(ent[2]()) in ids]:
+    for k in [k for k, ent in _ACCEL_CACHE.items() if k[0] in ids or id(ent[2]()) in ids]:
         _ACCEL_CACHE.pop(k, None)
     for k in ids:
         _SIGMA_CACHE.pop(k, None)
@@ -751,7 +751,11 @@ LAST_ROUTE = {"forward": None, "backward": None, "forward_terms": False}
 
 
 def _volume_render(tree, rays, opt, record):
-    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
+    # (r05) A recording forward's march is wavefronts of its own that wait for the grid cell and nothing else: for them the
+    # grid in 4 x 4 x 4 bricks (fwd_roles_kernel at 800 x 800 / depth 8: 0.248 -> 0.234 ms); rows of 8 / 16 / 32 floats on
+    # the depth-9 tree gain nothing, and the one-kernel forward loses (include/svoxt.h, SVOXT_ACCEL_BRICKS).
+    bricks = bool(record) and _numel(tree._weight_accum) == 0 and not (int(opt.format) == FORMAT_RGBA and tree.features.shape[1] in (8, 16, 32))
+    ct, cr, co = _pack_tree_accel(tree, bricks), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
     lists = None
     wide = co.format == FORMAT_RGBA and ct.K in (8, 16, 32)
@@ -807,6 +811,7 @@ def _volume_render(tree, rays, opt, record):
             # (the walk of an image's tiles goes on the lists: the backward replays them the way they were recorded,
             # whatever svoxt_set_super_tile_rows says by then)
             lists.flags = lflags | max(0, _lib.svoxt_image_walk(ctypes.byref(ct), ctypes.byref(cr)))
+            lists.bricks = bool(ct.accel and (ct.accel_log2 & 0x100))
             lists.exp_table = etab
             if fills:
                 # the exact per-tile backward will want (att, e0, e1, e2) of every sample: this forward has them
@@ -889,7 +894,8 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
 
 
 def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
-    ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
+    # (the grid the forward that recorded the lists went through: a backward with lists marches overflowed rays at most)
+    ct, cr, co = _pack_tree_accel(tree, bool(getattr(lists, "bricks", False))), _pack_rays(rays), _pack_opts(opt)
     _check_input(grad_output, "grad_output")
     if grad_output.dtype != torch.float32 or grad_output.dim() != 2 or grad_output.shape[0] != cr.Q:
         raise RuntimeError("grad_output must be float32 [Q, C+1]")

@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from ._abi import _CMotion, _CTree, _lib
-from ._marshal import (RaysSpec, RenderOptions, TreeSpec, _ACCEL_CACHE, _call, _check_input, _numel, _pack_opts, _pack_rays,
+from ._marshal import (RaysSpec, RenderOptions, TreeSpec, _ACCEL_CACHE, _drop_accel, _call, _check_input, _numel, _pack_opts, _pack_rays,
                        _pack_tree, _pack_tree_accel, _ptr, _stream)
 
 def _check_indices(indices):
@@ -91,7 +91,7 @@ def count_touched(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions):
     n_slots = ct.n_internal * ct.N ** 3
     with torch.cuda.device(dev):
         rows = torch.zeros((2 * ct.M,), dtype=torch.uint8, device=dev)
-        n_cells = (1 << (3 * ct.accel_log2)) if ct.accel else 0
+        n_cells = (1 << (3 * (ct.accel_log2 & 0xff))) if ct.accel else 0
         tmask = torch.zeros(((n_cells + n_slots) if ct.accel else 2 * n_slots,), dtype=torch.uint8, device=dev)
         longest = torch.zeros((1,), dtype=torch.int64, device=dev)
         _call("svoxt_count_touched", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co), _ptr(rows), _ptr(tmask),
@@ -282,7 +282,7 @@ def refine_leaves(child: torch.Tensor, data: torch.Tensor, parent_depth: torch.T
               _ptr(child), _ptr(data), _ptr(parent_depth), _ptr(node_id), _stream(dev))
     for t in (child, data, parent_depth):
         torch.autograd.graph.increment_version(t)
-    _ACCEL_CACHE.pop(id(child), None)
+    _drop_accel(child)
 
 
 def construct_tree(tree: TreeSpec, indices: torch.Tensor) -> None:
@@ -297,7 +297,7 @@ def construct_tree(tree: TreeSpec, indices: torch.Tensor) -> None:
     # tree.data was written behind torch's back: tell the version counter (the
     # acceleration-grid cache keys on it) and drop any grid built from the old words
     torch.autograd.graph.increment_version(tree.data)
-    _ACCEL_CACHE.pop(id(tree.child), None)
+    _drop_accel(tree.child)
 
 
 def build_octree(points: torch.Tensor, offset: torch.Tensor, scaling: torch.Tensor, depth: int,

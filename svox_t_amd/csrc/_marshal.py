@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 import weakref
 
 import torch
@@ -250,12 +251,19 @@ ACCEL_LOG2 = (lambda v: None if v is None else max(0, min(8, int(v))))(os.enviro
 # must call invalidate_caches(); N3Tree.refine / construct_tree / parallel.broadcast_tree do.
 # ACCEL_LOG2 (SVOXT_ACCEL_LOG2) = 0 disables the grid, = g forces a resolution; default: chosen from the tree size.
 # ---------------------------------------------------------------------------
-_ACCEL_CACHE: dict = {}     # id(child tensor) -> (weakref to it, ...); entries are dropped when the tensor dies
+_ACCEL_CACHE: dict = {}     # (id(child tensor), bricks) -> (weakref to it, ...); entries are dropped when the tensor dies
+
+
+def _switch(name: str):
+    """A test switch as the PACKAGE holds it now (tests set svox_t_amd.csrc.<name>; this module's own global is the default)."""
+    pkg = sys.modules.get(__package__)
+    return getattr(pkg, name, globals()[name])
 
 
 def _accel_log2_for(n_internal: int, N: int, feature_bytes: int = 0) -> int:
-    if ACCEL_LOG2 is not None:
-        return ACCEL_LOG2
+    forced = _switch("ACCEL_LOG2")
+    if forced is not None:
+        return forced
     if N != 2 or n_internal < 64:
         return 0
     slots = n_internal * 8
@@ -273,33 +281,46 @@ def _accel_log2_for(n_internal: int, N: int, feature_bytes: int = 0) -> int:
     return g
 
 
-def _accel_for(tree: TreeSpec, ct: _CTree):
+ACCEL_BRICKS = None     # test switch: True / False force the grid's layout; None: the caller's choice (_pack_tree_accel)
+SVOXT_ACCEL_BRICKS = 0x100
+
+
+def _accel_for(tree: TreeSpec, ct: _CTree, bricks: bool = False):
     g = _accel_log2_for(ct.n_internal, ct.N, tree.features.numel() * tree.features.element_size())
     if g == 0 or ct.N != 2 or max(ct.M, ct.n_internal) >= (1 << 27) - 1:       # (4-byte cells: 27 index bits)
         return None, 0
-    key = id(tree.child)
+    forced = _switch("ACCEL_BRICKS")
+    bricks = bool(bricks if forced is None else forced) and g >= 2
+    key = (id(tree.child), bricks)      # (a tree rendered both ways -- training steps and forward-only views -- keeps both grids)
     ent = _ACCEL_CACHE.get(key)
     if ent is not None:
         cref, cv, dref, dv, n_int, eg, cells = ent
         if cref() is tree.child and cv == (tree.child._version, tree.child.data_ptr()) and dref() is tree.data \
                 and dv == (tree.data._version, tree.data.data_ptr()) and n_int == ct.n_internal and eg == g:
-            return cells, g
+            return cells, g | (SVOXT_ACCEL_BRICKS if bricks else 0)
     dev = tree.child.device
     with torch.cuda.device(dev):
         nbytes = _lib.svoxt_accel_bytes(g, ct.n_internal)       # grid cells + (child, data) pairs
         cells = torch.empty((nbytes // 8, 2), dtype=torch.int32, device=dev)
-        _call("svoxt_accel_build", ctypes.byref(ct), g, _ptr(cells), _stream(dev))
+        _call("svoxt_accel_build", ctypes.byref(ct), g | (SVOXT_ACCEL_BRICKS if bricks else 0), _ptr(cells), _stream(dev))
     # (versions AND data pointers: `tensor.data = other` swaps the storage without touching the version counter)
     _ACCEL_CACHE[key] = (weakref.ref(tree.child, lambda _r, _k=key: _ACCEL_CACHE.pop(_k, None)),
                          (tree.child._version, tree.child.data_ptr()), weakref.ref(tree.data),
                          (tree.data._version, tree.data.data_ptr()), ct.n_internal, g, cells)
-    return cells, g
+    return cells, g | (SVOXT_ACCEL_BRICKS if bricks else 0)
 
 
-def _pack_tree_accel(tree: TreeSpec) -> _CTree:
-    """_pack_tree + the (cached) acceleration grid for the marching kernels."""
+def _drop_accel(child) -> None:
+    """Forget the grids (either layout) built from this child tensor."""
+    for b in (False, True):
+        _ACCEL_CACHE.pop((id(child), b), None)
+
+
+def _pack_tree_accel(tree: TreeSpec, bricks: bool = False) -> _CTree:
+    """_pack_tree + the (cached) acceleration grid for the marching kernels; `bricks`: in the layout that pays where a
+    kernel waits for the cell load alone (include/svoxt.h, SVOXT_ACCEL_BRICKS)."""
     ct = _pack_tree(tree)
-    cells, g = _accel_for(tree, ct)
+    cells, g = _accel_for(tree, ct, bricks)
     if cells is not None:
         ct.accel = cells.data_ptr()
         ct.accel_log2 = g

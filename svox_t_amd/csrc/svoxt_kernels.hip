@@ -79,8 +79,11 @@ int check_tree(const svoxt_tree* t, const char* fn) {
     if (t->n_internal < 1) return fail(SVOXT_ERR_INVALID, "%s: n_internal must be >= 1", fn);
     if ((double)t->n_internal * t->N * t->N * t->N >= 2147483648.0)
         return fail(SVOXT_ERR_INVALID, "%s: tree too large for 32-bit slot indices", fn);
-    if (t->accel != nullptr && (t->accel_log2 < 1 || t->accel_log2 > 8))
-        return fail(SVOXT_ERR_INVALID, "%s: accel_log2 must be in [1, 8]", fn);
+    if (t->accel != nullptr) {
+        const int32_t g = t->accel_log2 & ~SVOXT_ACCEL_BRICKS;
+        if (g < 1 || g > 8 || ((t->accel_log2 & SVOXT_ACCEL_BRICKS) && g < 2))
+            return fail(SVOXT_ERR_INVALID, "%s: accel_log2 must be in [1, 8] (with SVOXT_ACCEL_BRICKS: [2, 8])", fn);
+    }
     if (t->xform != nullptr && t->xform_dim != 0 && t->xform_dim != 3 && t->xform_dim != 4)
         return fail(SVOXT_ERR_INVALID, "%s: xform_dim must be 3 or 4", fn);
     return SVOXT_OK;
@@ -134,7 +137,8 @@ TreeDev to_dev(const svoxt_tree* t) {
     d.xform_dim = t->xform_dim == 4 ? 4 : 3;
     const bool use_accel = t->accel != nullptr && t->N == 2;
     d.accel = use_accel ? reinterpret_cast<const uint32_t*>(t->accel) : nullptr;
-    d.accel_g = use_accel ? t->accel_log2 : 0;
+    d.accel_g = use_accel ? (t->accel_log2 & ~SVOXT_ACCEL_BRICKS) : 0;
+    d.accel_bricks = use_accel && (t->accel_log2 & SVOXT_ACCEL_BRICKS) != 0;
     // the exponentials table serves RGBA-style rows of 8 / 16 / 32 floats only
     d.etab = (t->exp_table != nullptr && (t->K == 8 || t->K == 16 || t->K == 32)) ? t->exp_table : nullptr;
     return d;
@@ -1086,6 +1090,7 @@ static int compact_rows(const float* src, float* src_clear, int64_t M, int32_t K
 }
 
 int64_t svoxt_accel_bytes(int32_t log2_res, int64_t n_internal) {
+    log2_res &= ~SVOXT_ACCEL_BRICKS;                         // (the same size in either layout)
     if (log2_res < 1 || log2_res > 8 || n_internal < 0) return -1;
     return ((int64_t)sizeof(uint32_t) << (3 * log2_res)) + (int64_t)sizeof(uint2) * 8 * n_internal;
 }
@@ -1095,7 +1100,10 @@ int svoxt_accel_build(const svoxt_tree* tree, int32_t log2_res, void* cells, voi
     int rc;
     if ((rc = check_tree(tree, fn))) return rc;
     if (tree->N != 2) return fail(SVOXT_ERR_UNSUPPORTED, "%s: the acceleration grid exists for N == 2 only", fn);
-    if (log2_res < 1 || log2_res > 8) return fail(SVOXT_ERR_INVALID, "%s: log2_res must be in [1, 8]", fn);
+    const bool bricks = (log2_res & SVOXT_ACCEL_BRICKS) != 0;
+    log2_res &= ~SVOXT_ACCEL_BRICKS;
+    if (log2_res < (bricks ? 2 : 1) || log2_res > 8)
+        return fail(SVOXT_ERR_INVALID, "%s: log2_res must be in [1, 8] (with SVOXT_ACCEL_BRICKS: [2, 8])", fn);
     if (cells == nullptr || ((uintptr_t)cells & 7u) != 0) return fail(SVOXT_ERR_INVALID, "%s: cells is NULL or not 8-byte aligned", fn);
     if (tree->M >= (int64_t)kAccelIdx || tree->n_internal >= (int64_t)kAccelIdx)
         return fail(SVOXT_ERR_UNSUPPORTED, "%s: the 4-byte cells hold row and node indices below 2^27 - 1", fn);
@@ -1103,7 +1111,7 @@ int svoxt_accel_build(const svoxt_tree* tree, int32_t log2_res, void* cells, voi
     tr.accel = nullptr;
     const unsigned n = 1u << (3 * log2_res);
     hipLaunchKernelGGL(accel_build_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0,
-                       (hipStream_t)stream, tr, (int)log2_res, reinterpret_cast<uint32_t*>(cells));
+                       (hipStream_t)stream, tr, (int)log2_res, bricks, reinterpret_cast<uint32_t*>(cells));
     const int64_t slots = tree->n_internal * 8;
     if (slots > 0)
         hipLaunchKernelGGL(accel_nodes_kernel, dim3((unsigned)((slots + kBlock - 1) / kBlock)), dim3(kBlock), 0,

@@ -552,11 +552,11 @@ compact_rows_clear_pow2_kernel(float4* __restrict__ src, uint32_t n /* rows * SV
 // ---------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(kBlock)
-accel_build_kernel(TreeDev tr, int G, uint32_t* __restrict__ cells) {
+accel_build_kernel(TreeDev tr, int G, bool bricks, uint32_t* __restrict__ cells) {
     const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
     if (c >= (1u << (3 * G))) return;
-    const uint32_t mask = (1u << G) - 1u;
-    const uint32_t cz = c & mask, cy = (c >> G) & mask, cx = c >> (2 * G);
+    uint32_t cx, cy, cz;
+    accel_cell_coords(c, G, bricks, cx, cy, cz);
     int32_t node = 0;
     for (int k = 1; k <= G; ++k) {
         const int sh = G - k;
