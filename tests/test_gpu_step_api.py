@@ -40,7 +40,7 @@ def _run(case, gpu, image, thresholds=(0.0, 0.0), pool_blocks=0):
     rays = case.rays_gpu(gpu)
     spec = tree._spec(tree.features)
     rs = _rays_spec_from_rays(rays, case.image if image else None)
-    ct, cr, co = _C._pack_tree_accel(spec), _C._pack_rays(rs), _C._pack_opts(opt)
+    ct, cr, co = _C._pack_tree_accel(spec, True), _C._pack_rays(rs), _C._pack_opts(opt)
     step = _abi._CStep()
     _C._call("svoxt_step_plan", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co), pool_blocks, ctypes.byref(step))
     ws = torch.empty((step.workspace_bytes + 256,), dtype=torch.uint8, device=gpu)
@@ -96,7 +96,7 @@ def test_step_api_headline_size_and_speed(gpu):
     rays = case.rays_gpu(gpu)
     rs = _rays_spec_from_rays(rays, (800, 800))
     spec = tree._spec(tree.features)
-    ct, cr, co = _C._pack_tree_accel(spec), _C._pack_rays(rs), _C._pack_opts(opt)
+    ct, cr, co = _C._pack_tree_accel(spec, True), _C._pack_rays(rs), _C._pack_opts(opt)
     step = _abi._CStep()
     _C._call("svoxt_step_plan", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co), 0, ctypes.byref(step))
     ws = torch.empty((step.workspace_bytes + 256,), dtype=torch.uint8, device=gpu)
