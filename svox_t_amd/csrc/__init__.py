@@ -751,10 +751,13 @@ LAST_ROUTE = {"forward": None, "backward": None, "forward_terms": False}
 
 
 def _volume_render(tree, rays, opt, record):
-    # (r05) A recording forward's march is wavefronts of its own that wait for the grid cell and nothing else: for them the
-    # grid in 4 x 4 x 4 bricks (fwd_roles_kernel at 800 x 800 / depth 8: 0.248 -> 0.234 ms); rows of 8 / 16 / 32 floats on
-    # the depth-9 tree gain nothing, and the one-kernel forward loses (include/svoxt.h, SVOXT_ACCEL_BRICKS).
-    bricks = bool(record) and _numel(tree._weight_accum) == 0 and not (int(opt.format) == FORMAT_RGBA and tree.features.shape[1] in (8, 16, 32))
+    # (r05) A forward whose march is wavefronts of its own -- every recording forward, and the two-kernel forward of rows of
+    # 8 / 16 / 32 floats -- waits for the grid cell and nothing else: for them the grid in 4 x 4 x 4 bricks and a level finer
+    # (fwd_roles_kernel at 800 x 800 / depth 8: 0.248 -> 0.234 ms; march_rec_kernel + shade_chan_kernel at 1024 x 1024 /
+    # depth 9: 0.837 -> 0.801); the one-kernel forward, short of issue slots, keeps the row-major grid (include/svoxt.h,
+    # SVOXT_ACCEL_BRICKS).
+    bricks = _numel(tree._weight_accum) == 0 and (bool(record) or (int(opt.format) == FORMAT_RGBA and tree.features.shape[1] in (8, 16, 32)
+                                                                    and FWD_SPLIT != "0"))
     ct, cr, co = _pack_tree_accel(tree, bricks), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
     lists = None

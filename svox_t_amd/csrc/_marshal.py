@@ -260,7 +260,7 @@ def _switch(name: str):
     return getattr(pkg, name, globals()[name])
 
 
-def _accel_log2_for(n_internal: int, N: int, feature_bytes: int = 0) -> int:
+def _accel_log2_for(n_internal: int, N: int, feature_bytes: int = 0, marching: bool = False) -> int:
     forced = _switch("ACCEL_LOG2")
     if forced is not None:
         return forced
@@ -278,6 +278,12 @@ def _accel_log2_for(n_internal: int, N: int, feature_bytes: int = 0) -> int:
     finer = 4 * (1 << (3 * (g + 1))) + 64 * n_internal
     if g + 1 <= 8 and feature_bytes > 0 and finer + feature_bytes <= 224 * (1 << 20):
         g += 1
+    # (r05) ... and one level finer whatever the cache holds when the march is wavefronts of its own that wait for these
+    # loads and nothing else (`marching`: the two-kernel / one-launch forwards; the grid then lies in bricks too): depth 9 /
+    # 578 MB of features at 1024 x 1024, g 7 -> 8 in bricks: forward 0.837 -> 0.801 ms, forward + backward 439 -> 446
+    # Mrays/s (g 8 row-major 0.828; g 7 in bricks 0.837) -- a dependent 8-byte load per crossing less.
+    elif marching and g + 1 <= 8:
+        g += 1
     return g
 
 
@@ -286,11 +292,12 @@ SVOXT_ACCEL_BRICKS = 0x100
 
 
 def _accel_for(tree: TreeSpec, ct: _CTree, bricks: bool = False):
-    g = _accel_log2_for(ct.n_internal, ct.N, tree.features.numel() * tree.features.element_size())
+    forced = _switch("ACCEL_BRICKS")
+    bricks = bool(bricks if forced is None else forced)
+    g = _accel_log2_for(ct.n_internal, ct.N, tree.features.numel() * tree.features.element_size(), marching=bricks)
     if g == 0 or ct.N != 2 or max(ct.M, ct.n_internal) >= (1 << 27) - 1:       # (4-byte cells: 27 index bits)
         return None, 0
-    forced = _switch("ACCEL_BRICKS")
-    bricks = bool(bricks if forced is None else forced) and g >= 2
+    bricks = bricks and g >= 2
     key = (id(tree.child), bricks)      # (a tree rendered both ways -- training steps and forward-only views -- keeps both grids)
     ent = _ACCEL_CACHE.get(key)
     if ent is not None:

@@ -80,13 +80,30 @@ def test_the_layout_follows_the_kind_of_forward(gpu):
     gb = g - 2
     ci = (((((x >> 2) << gb) + (y >> 2)) << gb) + (z >> 2) << 6) | ((x & 3) << 4) | ((y & 3) << 2) | (z & 3)
     assert torch.equal(bri[:n][ci.reshape(-1)], lin[:n]) and torch.equal(bri[n:], lin[n:])
-    # rows of 8 / 16 / 32 floats and weight accumulation stay row-major (nothing to gain there)
+    # rows of 8 / 16 / 32 floats: their forward is march + shade as two kernels with or without a backward behind it -- bricks
+    # either way; the weight-accumulating forward is the one-kernel forward -- row-major
     c8 = Case(depth=5, K=8, data_format="RGBA", width=64, height=64)
     t8 = c8.tree(gpu)
+    r8 = svox.VolumeRenderer(t8)
+    with torch.no_grad():
+        r8(t8.features, c8.rays_gpu(gpu))
+    assert (id(t8.child), True) in _C._ACCEL_CACHE and (id(t8.child), False) not in _C._ACCEL_CACHE
     f8 = t8.features.detach().clone().requires_grad_(True)
-    o8 = svox.VolumeRenderer(t8)(f8, c8.rays_gpu(gpu), image_shape=(64, 64))
+    o8 = r8(f8, c8.rays_gpu(gpu), image_shape=(64, 64))
     o8.backward(torch.ones_like(o8))
-    assert (id(t8.child), False) in _C._ACCEL_CACHE and (id(t8.child), True) not in _C._ACCEL_CACHE
+    assert (id(t8.child), False) not in _C._ACCEL_CACHE
+    with torch.no_grad(), t8.accumulate_weights():
+        r8(t8.features, c8.rays_gpu(gpu))
+    assert (id(t8.child), False) in _C._ACCEL_CACHE
+
+
+def test_a_level_finer_for_marching_wavefronts_past_the_cache_rule():
+    """Resolution: the cache-fit rule of the one-kernel forward, plus one level (at most 8) where the march is wavefronts of
+    its own (depth 9 / 578 MB of features: 7 -> 8)."""
+    from svox_t_amd.csrc import _marshal as M
+    assert M._accel_log2_for(792753, 2, 578 << 20) == 7 and M._accel_log2_for(792753, 2, 578 << 20, marching=True) == 8
+    assert M._accel_log2_for(95000, 2, 71 << 20) == 8 == M._accel_log2_for(95000, 2, 71 << 20, marching=True)      # already finer: fits
+    assert M._accel_log2_for(40, 2, 1 << 20, marching=True) == 0 and M._accel_log2_for(10 ** 6, 3, 1 << 20, marching=True) == 0
 
 
 def test_library_refuses_bricks_too_coarse_for_them(gpu):
