@@ -368,8 +368,9 @@ constexpr uint32_t kAccelIdx = 0x07ffffffu;      // row / node bits; as a row: e
 // step along x or y is a new line (1 KB / 256 KB away at G = 8).  Measured at 800 x 800 / depth 8 (G = 8): the marching
 // wavefronts of fwd_roles_kernel, which wait for exactly this load, 0.2477 -> 0.2342 ms (requests to L2 -26 %, fetches
 // -15 %); the one-kernel forward, which is short of issue slots rather than of memory, pays for the six extra integer
-// operations per crossing, 0.2033 -> 0.2157 ms; rows of 32 floats on the depth-9 tree: no change.  Nested bricks (4^3
-// in 16^3 ...) and 8^3 bricks: between the two.  So the layout is the caller's to choose per grid (svoxt_tree.accel_log2,
+// operations per crossing, 0.2033 -> 0.2157 ms; rows of 32 floats on the depth-9 tree: no change at g 7, 0.837 -> 0.801 ms a
+// level finer.  Nested bricks (4^3 in 16^3 ...) and 8^3 bricks: between the two; 2 x 4 x 4, 4 x 4 x 2, 4 x 2 x 4, 4 x 4 x 8 and
+// 2 x 2 x 2: within noise of 4 x 4 x 4 or behind it.  So the layout is the caller's to choose per grid (svoxt_tree.accel_log2,
 // SVOXT_ACCEL_BRICKS), uniform per launch.
 __device__ __forceinline__ uint32_t accel_cell_index(uint32_t x, uint32_t y, uint32_t z, int G, bool bricks) {
     if (!bricks) return (((x << G) + y) << G) + z;
