@@ -390,10 +390,10 @@ __device__ __forceinline__ void accel_cell_coords(uint32_t c, int G, bool bricks
     }
 }
 
-// MARK: mark[cell] = 1 for the grid cell read, mark[n_cells + slot] = 1 for every (child, data) pair read
-template <bool MARK = false>
-__device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float py, float pz,
-                                             Leaf& lf, int32_t& idx, uint8_t* mark = nullptr) {
+// The grid cell of a point: the clamp (in place: what follows uses the clamped point), the fixed-point coordinates the
+// descent below the grid takes its child bits from, and the cell's index.
+__device__ __forceinline__ uint32_t accel_point(const TreeDev& tr, float& px, float& py, float& pz,
+                                                uint32_t& ux, uint32_t& uy, uint32_t& uz) {
     // (r03) the clamp as ONE median-of-three per axis: for every non-NaN p the value of fmaxf(0, fminf(hi, p))
     // (a zero may come out with the other sign: p * 2^22 truncates to the same 0 and f - floor(f) is +0 either
     // way); a NaN position cannot reach this point (no finite t makes one, and t = NaN ends the march).
@@ -401,14 +401,19 @@ __device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float 
     py = __builtin_amdgcn_fmed3f(py, 0.f, kClampHi);
     pz = __builtin_amdgcn_fmed3f(pz, 0.f, kClampHi);
     const float S = (float)(1 << kFixBits);
-    const uint32_t ux = (uint32_t)(px * S);
-    const uint32_t uy = (uint32_t)(py * S);
-    const uint32_t uz = (uint32_t)(pz * S);
+    ux = (uint32_t)(px * S);
+    uy = (uint32_t)(py * S);
+    uz = (uint32_t)(pz * S);
     const int G = tr.accel_g;
     const int gs = kFixBits - G;
-    const uint32_t ci = accel_cell_index(ux >> gs, uy >> gs, uz >> gs, G, tr.accel_bricks);
-    const uint32_t cell = tr.accel[ci];
-    if constexpr (MARK) mark[ci] = 1;
+    return accel_cell_index(ux >> gs, uy >> gs, uz >> gs, G, tr.accel_bricks);
+}
+
+// The leaf of a (clamped) point given its grid cell's word: the levels below the grid, the data word, the local coordinates.
+template <bool MARK = false>
+__device__ __forceinline__ void accel_resolve(const TreeDev& tr, uint32_t cell, float px, float py, float pz,
+                                              uint32_t ux, uint32_t uy, uint32_t uz, Leaf& lf, int32_t& idx, uint8_t* mark = nullptr) {
+    const int G = tr.accel_g;
     int k;
     uint32_t slot = 0xffffffffu;
     if (cell & kAccelLeaf) {
@@ -459,12 +464,47 @@ __device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float 
     lf.levels = k;
 }
 
+// MARK: mark[cell] = 1 for the grid cell read, mark[n_cells + slot] = 1 for every (child, data) pair read
+template <bool MARK = false>
+__device__ __forceinline__ void locate_accel(const TreeDev& tr, float px, float py, float pz,
+                                             Leaf& lf, int32_t& idx, uint8_t* mark = nullptr) {
+    uint32_t ux, uy, uz;
+    const uint32_t ci = accel_point(tr, px, py, pz, ux, uy, uz);
+    const uint32_t cell = tr.accel[ci];
+    if constexpr (MARK) mark[ci] = 1;
+    accel_resolve<MARK>(tr, cell, px, py, pz, ux, uy, uz, lf, idx, mark);
+}
+
 struct Sample {
     Leaf leaf;
     int32_t idx;       // data word of the leaf: the feature row when `valid`
     float delta_t;     // chord of the leaf along the ray + step_size
     bool valid;        // 0 <= idx < M (anything else marks an empty leaf)
 };
+
+// The step across a leaf from a point inside it (leaf-local coordinates l in [0, 1), cube_sz = 2^level for N = 2):
+// _dda_unit on the leaf-local point (rt_kernel.cu:273).  The point lies inside its leaf, so on every axis one of
+// t1 = -c*inv and t2 = t1 + inv is <= 0: the entry distance max(0, min...) is 0 and `subcube_tmax - subcube_tmin`
+// (:275) is subcube_tmax itself -- only the exit distance is evaluated.
+template <bool N2>
+__device__ __forceinline__ float leaf_delta_t(float lx, float ly, float lz, float cube_sz, const Ray& r, float step_size) {
+    float sub_tmax = 1e9f;
+    {
+        float t1, t2;
+        t1 = -lx * r.ix; t2 = t1 + r.ix; sub_tmax = fminf(sub_tmax, fmaxf(t1, t2));
+        t1 = -ly * r.iy; t2 = t1 + r.iy; sub_tmax = fminf(sub_tmax, fmaxf(t1, t2));
+        t1 = -lz * r.iz; t2 = t1 + r.iz; sub_tmax = fminf(sub_tmax, fmaxf(t1, t2));
+    }
+    float t_subcube;
+    if constexpr (N2) {
+        // cube_sz is a power of two: multiplying by its reciprocal is the
+        // same correctly rounded result as the reference's division (:275).
+        t_subcube = sub_tmax * __int_as_float((254 << 23) - __float_as_int(cube_sz));
+    } else {
+        t_subcube = sub_tmax / cube_sz;
+    }
+    return t_subcube + step_size;
+}
 
 // One leaf crossing: rt_kernel.cu:261-277.
 // ACC: -1 = look at tr.accel at run time; 1 / 0 = the caller knows the acceleration grid is
@@ -497,27 +537,7 @@ __device__ __forceinline__ void march_step(const TreeDev& tr, const Ray& r, floa
     // (one unsigned compare: a negative index is a large unsigned one, and a table of 2^31 rows or more holds
     // every non-negative int32)
     s.valid = (uint32_t)s.idx < (tr.M > 0x7fffffffLL ? 0x80000000u : (uint32_t)tr.M);
-    // _dda_unit on the leaf-local point (:273).  The point lies inside its leaf
-    // (local coordinates in [0, 1)), so on every axis one of t1 = -c*inv and
-    // t2 = t1 + inv is <= 0: the entry distance max(0, min...) is 0 and
-    // `subcube_tmax - subcube_tmin` (:275) is subcube_tmax itself -- only the exit
-    // distance is evaluated.
-    float sub_tmax = 1e9f;
-    {
-        float t1, t2;
-        t1 = -s.leaf.lx * r.ix; t2 = t1 + r.ix; sub_tmax = fminf(sub_tmax, fmaxf(t1, t2));
-        t1 = -s.leaf.ly * r.iy; t2 = t1 + r.iy; sub_tmax = fminf(sub_tmax, fmaxf(t1, t2));
-        t1 = -s.leaf.lz * r.iz; t2 = t1 + r.iz; sub_tmax = fminf(sub_tmax, fmaxf(t1, t2));
-    }
-    float t_subcube;
-    if constexpr (N2) {
-        // cube_sz is a power of two: multiplying by its reciprocal is the
-        // same correctly rounded result as the reference's division (:275).
-        t_subcube = sub_tmax * __int_as_float((254 << 23) - __float_as_int(s.leaf.cube_sz));
-    } else {
-        t_subcube = sub_tmax / s.leaf.cube_sz;
-    }
-    s.delta_t = t_subcube + step_size;
+    s.delta_t = leaf_delta_t<N2>(s.leaf.lx, s.leaf.ly, s.leaf.lz, s.leaf.cube_sz, r, step_size);
 }
 
 // expf with a fixed operation sequence (Cephes-style: n = rint(x*log2e), two-

@@ -837,7 +837,12 @@ __host__ __device__ inline int64_t roles_group_of(const RolesMap& m, int b) {   
 // crossings of ~1.16 us) plus that tile's own shade (~45-58 us: ~19 rounds of gather -> barrier).  (d) The march itself: the
 // grid cell of a LATER crossing requested on speculation (where that crossing starts if the leaves keep their size), one or
 // two crossings ahead, in front of or right behind the crossing's own request: forward 0.247 -> 0.294-0.306 ms -- the ~15
-// instructions of the guess sit in every crossing's chain and the speculative line competes with the real one.)
+// instructions of the guess sit in every crossing's chain and the speculative line competes with the real one.  (e) The
+// march TWO crossings at a time: the step across the crossing's leaf formed from the level of the leaf before it while the
+// cell is on its way, the next point's cell requested right behind it and USED when the level was the one assumed (bit for
+// bit the reference's march either way; exp/r05/march_two_crossings_at_a_time.diff.txt): forward 0.237 -> 0.270 ms here (89
+// registers), and 0.80 -> 0.83 at 1024 x 1024 / depth 9 where the march is a kernel of its own at 64 -- runs of equal
+// levels are short on these trees, and every iteration pays two points and two requests.)
 template <int FMT, int BD, int ACC, bool WTERMS, bool LOBES = false, bool XF = false>
 __global__ void __launch_bounds__(512)
 fwd_roles_kernel(TreeDev tr, RaysDev rays, Opts opt, RecLists L, uint4* __restrict__ aux, float* __restrict__ out,
