@@ -126,16 +126,15 @@ ray_place_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__
 }
 
 // dst[i, :] = src[perm[i], :] (GATHER) or dst[perm[i], :] = src[i, :]: rows of `cols` floats, one thread per float
-template <bool GATHER>
 __global__ void __launch_bounds__(kOrderBlock)
 permute_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ perm, float* __restrict__ dst,
-                    int64_t n, int cols) {
+                    int64_t n, int cols, bool gather) {
     const int64_t i = (int64_t)blockIdx.x * kOrderBlock + threadIdx.x;
     if (i >= n * cols) return;
     const int64_t row = i / cols;
     const int c = (int)(i - row * cols);
     const int64_t other = perm[row];
-    if constexpr (GATHER) dst[i] = src[other * cols + c];
+    if (gather) dst[i] = src[other * cols + c];          // (uniform)
     else dst[other * cols + c] = src[i];
 }
 
@@ -351,8 +350,7 @@ int svoxt_permute_rows(const float* src, const int32_t* perm, float* dst, int64_
     if (src == nullptr || perm == nullptr || dst == nullptr) return set_error(SVOXT_ERR_INVALID, "%s: NULL argument", fn);
     const int64_t tot = n * cols;
     const unsigned nb = (unsigned)((tot + kOrderBlock - 1) / kOrderBlock);
-    if (scatter) hipLaunchKernelGGL((permute_rows_kernel<false>), dim3(nb), dim3(kOrderBlock), 0, (hipStream_t)stream, src, perm, dst, n, (int)cols);
-    else hipLaunchKernelGGL((permute_rows_kernel<true>), dim3(nb), dim3(kOrderBlock), 0, (hipStream_t)stream, src, perm, dst, n, (int)cols);
+    hipLaunchKernelGGL(permute_rows_kernel, dim3(nb), dim3(kOrderBlock), 0, (hipStream_t)stream, src, perm, dst, n, (int)cols, scatter == 0);
     return check_launch(fn);
 }
 

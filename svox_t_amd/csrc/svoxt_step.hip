@@ -56,8 +56,8 @@ inline bool pad_layout(const svoxt_tree* t, const svoxt_options* o, PadLayout* p
     return true;
 }
 
-// dst [n, dc] <- src [n, sc]: the first `real` columns and the last one; PAD: zeros between them (dc > sc), else dropped (dc < sc)
-template <bool PAD>
+// dst [n, dc] <- src [n, sc]: the first `real` columns and the last one; zeros between them where dc > sc, the columns between
+// dropped where dc < sc
 __global__ void __launch_bounds__(256)
 copy_cols_kernel(const float* __restrict__ src, int sc, float* __restrict__ dst, int dc, int64_t n, int real) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -67,14 +67,13 @@ copy_cols_kernel(const float* __restrict__ src, int sc, float* __restrict__ dst,
     float v;
     if (c < real) v = src[row * sc + c];
     else if (c == dc - 1) v = src[row * sc + sc - 1];
-    else v = 0.f;                                    // (PAD only: a dropped column is never a destination)
+    else v = 0.f;                                    // (padding only: a dropped column is never a destination)
     dst[i] = v;
 }
-inline int copy_cols(bool pad, const float* src, int sc, float* dst, int dc, int64_t n, int real, void* stream, const char* fn) {
+inline int copy_cols(bool /* pad */, const float* src, int sc, float* dst, int dc, int64_t n, int real, void* stream, const char* fn) {
     if (n == 0) return SVOXT_OK;
     const unsigned nb = (unsigned)((n * dc + 255) / 256);
-    if (pad) hipLaunchKernelGGL((copy_cols_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, src, sc, dst, dc, n, real);
-    else hipLaunchKernelGGL((copy_cols_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, src, sc, dst, dc, n, real);
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, sc, dst, dc, n, real);
     return check_launch(fn);
 }
 
