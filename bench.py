@@ -29,6 +29,7 @@ workload, host cores.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -64,6 +65,7 @@ ROUND = "r05"        # which round's committed profiles the line quotes (profile
 # the first process on a fresh box with backwards at 0.41-0.45 ms against 0.26 ms in steady state -- BENCH_r04.json,
 # gpurun_out/r4b/bench_d8_1.json vs _2.json: the memory side of a cold device; BASELINE.md "fresh box".)
 PREWARM_MIN_S, PREWARM_MAX_S, PREWARM_WINDOW, PREWARM_TOL, PREWARM_BATCH = 0.5, 3.0, 10, 0.05, 20
+STALL_FACTOR = 4.0
 
 
 def _median(xs):
@@ -419,6 +421,8 @@ def main(argv=None):
         bwd = [events[i][1].elapsed_time(events[i][2]) for i in range(n)]
         return fwd, bwd
 
+    _TEST_STALL_MS = [float(os.environ.get("BENCH_TEST_STALL_MS", "0") or 0)]      # (tests/test_gpu_bench_contract.py)
+
     def timed(n, **kw):
         """Mean seconds per step of n steps, bracketed by barrier + synchronize, max over ranks."""
         if reducer is not None:
@@ -429,6 +433,10 @@ def main(argv=None):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n):
+            if i == 1 and _TEST_STALL_MS[0] > 0:                     # (tests: the host falls asleep once, as a stalled step looks)
+                torch.cuda.synchronize()
+                time.sleep(_TEST_STALL_MS[0] * 1e-3)
+                _TEST_STALL_MS[0] = 0.0
             step(i if kw.get("events") else None, **{k: v for k, v in kw.items() if k != "events"})
         if reducer is not None:
             reducer.wait()                    # the last gradient is reduced inside the timed region
@@ -483,9 +491,31 @@ def main(argv=None):
                        f"{PREWARM_BATCH} steps shown: a cold device shows up as first >> last)"}
     if hasattr(_C, "freeze_pools"):
         _C.freeze_pools(True)      # the lists' pool sizes stay what the warm-up settled on: no re-sizing inside the timed steps
+    # (the host's own pauses stay out of the K timed steps as far as they can be kept out: the cyclic collector runs before,
+    # not inside; a step that still stalls shows in per_step_ms -- and see `retimed` below)
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         step()
     elapsed = timed(args.steps, events=True)
+    # A stalled step (r05: one 20 ms step among twenty of 0.8 ms, once in some hundred runs, on a box that was normal before
+    # and after -- the queue the host keeps filled ran dry for a moment) is the host's, not the path's: when an interval is
+    # more than STALL_FACTOR times its median the K steps are timed ONCE more, and the line carries both runs (`retimed`).
+    retimed = None
+    f1, b1 = intervals(ev, args.steps)
+    stall = max(max(f1) / max(_median(f1), 1e-9), (max(b1) / max(_median(b1), 1e-9)) if not args.forward_only else 0.0)
+    again = stall > STALL_FACTOR
+    if dist is not None:
+        t = torch.tensor([1.0 if again else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        again = bool(t.item() > 0.0)
+    if again:
+        retimed = {"why": f"a timed step took more than {STALL_FACTOR}x the median of its kind: the K steps were timed once more and "
+                          "`value`, `ms_per_step`, `per_step_ms` are the second run's; the first run is kept here",
+                   "first_run": {"ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+                                 "forward": [round(x, 4) for x in f1], "backward": [round(x, 4) for x in b1]}}
+        elapsed = timed(args.steps, events=True)
+    gc.enable()
     if hasattr(_C, "freeze_pools"):
         _C.freeze_pools(False)
 
@@ -789,6 +819,7 @@ def main(argv=None):
             "steps": args.steps,
             "warmup": args.warmup,
             "prewarm": prewarm,
+            "retimed": retimed,
             "ms_per_step": round(ms_per_step, 4),
             # the same K steps, per step, from the HIP events on the launch stream (forward: previous step's end -> this
             # step's forward end; backward: -> this step's backward end): one hiccup and K slow steps read differently here

@@ -73,3 +73,21 @@ def test_bench_json_contract(gpu):
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert r["counters"]["steps"] == 18919396                                           # the workload is the one named
+
+
+def test_a_stalled_step_is_timed_again_and_said_so(gpu):
+    """The host falls asleep for 30 ms inside the timed steps (BENCH_TEST_STALL_MS: what a stalled step looks like from
+    the stream's events): the K steps are timed once more, the line carries both runs, `value` is the settled one."""
+    env = dict(os.environ, BENCH_TEST_STALL_MS="30")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-plain", "--no-other-configs"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    rt = r["retimed"]
+    assert rt is not None and len(rt["first_run"]["forward"]) == 6
+    assert max(rt["first_run"]["forward"] + rt["first_run"]["backward"]) > 20.0          # the sleep, in the first run
+    sm = r["per_step_ms"]["summary"]
+    assert sm["step"]["max"] < 4.0 * sm["step"]["median"] and r["ms_per_step"] < 0.25 * rt["first_run"]["ms_per_step"]
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "1", "--no-cpu-baseline",
+                         "--no-plain", "--no-other-configs"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert json.loads([l for l in p2.stdout.splitlines() if l.strip()][-1])["retimed"] is None
