@@ -37,7 +37,7 @@ from ._abi import (ABI_VERSION, EXPORTS, FORMAT_ASG, FORMAT_RGBA, FORMAT_SG, FOR
                    LISTS_TEST_DROP, LISTS_TEST_NOPOLL, LISTS_TEST_STALE, _CLists, _CMotion, _COptions, _CRays, _CTree, _lib)
 from ._marshal import (ACCEL_BRICKS, ACCEL_LOG2, CameraSpec, RaysSpec, RenderOptions, TreeSpec, _ACCEL_CACHE, _accel_for, _accel_log2_for,
                        _call, _check_input, _numel, _pack_camera, _pack_opts, _pack_rays, _pack_tree, _pack_tree_accel, _ptr,
-                       _stream, get_out_data_dim)
+                       _on, _stream, get_out_data_dim)
 
 
 # ---------------------------------------------------------------------------
@@ -147,7 +147,7 @@ def _attach_sigma_mask(tree: TreeSpec, ct: _CTree, thresh: float, keep: bool, ta
             mask, etab = ent[3], (ent[4] if table else None)
     if mask is None:
         dev = f.device
-        with torch.cuda.device(dev):
+        with _on(dev):
             mask = torch.empty((_lib.svoxt_sigma_mask_bytes(ct.M) // 8,), dtype=torch.int64, device=dev)
             if table:
                 etab = torch.empty_like(f, requires_grad=False)
@@ -377,7 +377,7 @@ def _ray_order32(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Te
     """... as the library writes it (int32), for svoxt_gather_rays / svoxt_permute_rows."""
     ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         perm = torch.empty((cr.Q,), dtype=torch.int32, device=dev)
         nbytes = _lib.svoxt_ray_order_workspace_bytes(cr.Q)
         if nbytes < 0:
@@ -394,7 +394,7 @@ def _permute_rows(src: torch.Tensor, perm32: torch.Tensor, scatter: bool) -> tor
     if src.dtype != torch.float32 or src.dim() != 2 or not src.is_contiguous():
         src = src.contiguous().float()
     dev = src.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         dst = torch.empty_like(src)
         _call("svoxt_permute_rows", _ptr(src), _ptr(perm32), _ptr(dst), src.shape[0], src.shape[1], 1 if scatter else 0,
               _stream(dev))
@@ -545,7 +545,7 @@ def _detect_image(rays):
         _settle_probe(tr[2], Q)
     cr = _pack_rays(rays)
     dev = d.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         words = torch.empty((256,), dtype=torch.int32, device=dev)              # (SVOXT_IMAGE_PROBE_WORDS)
         row, ticket = _probe_row()
         _call("svoxt_image_probe", ctypes.byref(cr), _ptr(words), ticket, _stream(dev))
@@ -788,7 +788,7 @@ def _volume_render(tree, rays, opt, record):
     etab = None
     lists = None
     if will_record:
-        with torch.cuda.device(dev):
+        with _on(dev):
             lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
     if ((split or fills == 3 or xf_roles) and FWD_SPLIT != "0") if will_record else (split and (co.stop_thresh == 0.0 or wide)):
         # rows of 8 / 16 / 32 floats in exact mode: the same pass leaves the rows' exponentials for the shade kernel
@@ -808,7 +808,7 @@ def _volume_render(tree, rays, opt, record):
                               "march_rec_kernel + shade_tile_kernel (two-kernel forward)") if split
                              else ("render_fwd_kernel" if can_rec or not record else "render_fwd_generic_kernel (no specialised instance: accumulators in "
                                    "memory as the reference keeps them)")) + (", recording sample lists" if will_record else "")
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((cr.Q, get_out_data_dim(opt, ct.K)), dtype=torch.float32, device=dev)
         if will_record:
             # (the walk of an image's tiles goes on the lists: the backward replays them the way they were recorded,
@@ -925,7 +925,7 @@ def _volume_render_backward(tree, rays, opt, grad_output, lists, fwd_output):
             gather and BWD_FUSED and BWD_EXACT and ct.xform is None and lists.terms is not None and lists.terms_state == 3):
         lists = None              # SG / ASG lists serve the exact per-tile backward only: march instead
         gather = False
-    with torch.cuda.device(dev):
+    with _on(dev):
         kept = _grad_scratch(dev, M, stride) if (GRAD_SCRATCH and lists is not None and stride != K and M > 0) else None
         buf = kept[0] if kept is not None else torch.empty((M, stride), dtype=torch.float32, device=dev)
         if lists is not None:
@@ -1023,7 +1023,7 @@ def render_depth(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.Te
     """rt_kernel.cu:1506-1523."""
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         depth = torch.empty((cr.Q, 1), dtype=torch.float32, device=dev)
         _call("svoxt_render_depth", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
               _ptr(depth), _stream(dev))
@@ -1042,7 +1042,7 @@ def _opacity_render(tree, rays, opt, record):
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
     lists = None
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((cr.Q, 1), dtype=torch.float32, device=dev)
         if record and BWD_LIST_SAMPLES > 0 and cr.Q > 0:
             lists = SampleLists(cr.Q, _list_cap(ct, BWD_LIST_SAMPLES), dev)
@@ -1078,7 +1078,7 @@ def _opacity_render_backward(tree, rays, opt, grad_output, lists):
     dev = tree.features.device
     if lists is not None and lists.consumed:
         lists = None
-    with torch.cuda.device(dev):
+    with _on(dev):
         grad = torch.empty_like(tree.features)
         if lists is not None:
             if lists.aux.shape[0] != cr.Q or lists.aux.device != dev:

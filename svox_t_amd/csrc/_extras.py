@@ -9,7 +9,7 @@ import torch
 
 from ._abi import _CMotion, _CTree, _lib
 from ._marshal import (RaysSpec, RenderOptions, TreeSpec, _ACCEL_CACHE, _drop_accel, _call, _check_input, _numel, _pack_opts, _pack_rays,
-                       _pack_tree, _pack_tree_accel, _ptr, _stream)
+                       _on, _pack_tree, _pack_tree_accel, _ptr, _stream)
 
 def _check_indices(indices):
     """check_indices (svox_kernel.cu:36-40)."""
@@ -35,7 +35,7 @@ def query_vertical(tree: TreeSpec, indices: torch.Tensor):
     dev = indices.device
     Q = indices.shape[0]
     N = ct.N
-    with torch.cuda.device(dev):
+    with _on(dev):
         values = torch.empty((Q, ct.K), dtype=torch.float32, device=dev)
         node_ids = torch.empty((Q,), dtype=torch.int64, device=dev)
         data_ids = torch.empty((Q,), dtype=torch.int64, device=dev)
@@ -61,7 +61,7 @@ def query_vertical_backward(tree: TreeSpec, indices: torch.Tensor,
     if grad_output.dtype != torch.float32 or tuple(grad_output.shape) != (indices.shape[0], ct.K):
         raise RuntimeError("grad_output must be float32 [Q, K]")
     dev = indices.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         grad = torch.empty((ct.M, ct.K), dtype=torch.float32, device=dev)
         _call("svoxt_query_bwd", ctypes.byref(ct), _ptr(indices), indices.shape[0],
               _ptr(grad_output), _ptr(grad), _stream(dev))
@@ -74,7 +74,7 @@ def count_forward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) -> torch.T
     composited samples).  See SURVEY.md 8(d)."""
     ct, cr, co = _pack_tree(tree), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         counters = torch.zeros((5,), dtype=torch.int64, device=dev)
         _call("svoxt_count_fwd", ctypes.byref(ct), ctypes.byref(cr), ctypes.byref(co),
               _ptr(counters), _stream(dev))
@@ -89,7 +89,7 @@ def count_touched(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions):
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     dev = tree.features.device
     n_slots = ct.n_internal * ct.N ** 3
-    with torch.cuda.device(dev):
+    with _on(dev):
         rows = torch.zeros((2 * ct.M,), dtype=torch.uint8, device=dev)
         n_cells = (1 << (3 * (ct.accel_log2 & 0xff))) if ct.accel else 0
         tmask = torch.zeros(((n_cells + n_slots) if ct.accel else 2 * n_slots,), dtype=torch.uint8, device=dev)
@@ -149,7 +149,7 @@ def motion_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions):
     if not _numel(tree.extra_data):
         raise RuntimeError("motion_render needs extra_data [n_joints, >= 3] (the joint positions)")
     dev = tree.features.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((cr.Q, ct.extra_rows), dtype=torch.float32, device=dev)
         depth = torch.empty((cr.Q, 1), dtype=torch.float32, device=dev)
         hit = torch.empty((cr.Q, 3), dtype=torch.float32, device=dev)
@@ -184,7 +184,7 @@ def motion_feature_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions) ->
     ct, cr, co = _pack_tree_accel(tree), _pack_rays(rays), _pack_opts(opt)
     cm = _pack_motion(tree, ct)
     dev = tree.features.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((cr.Q, cm.feature_dim), dtype=torch.float32, device=dev)
         ws = _motion_workspace(ct, cm, dev)
         _call("svoxt_motion_feature_render_fwd", ctypes.byref(ct), ctypes.byref(cm), ctypes.byref(cr),
@@ -202,7 +202,7 @@ def motion_feature_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOp
     if grad_output.dtype != torch.float32 or tuple(grad_output.shape) != (cr.Q, cm.feature_dim):
         raise RuntimeError("grad_output must be float32 [Q, joint feature dim]")
     dev = tree.features.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         grad = torch.empty((cm.n_joints, cm.feature_dim), dtype=torch.float32, device=dev)
         ws = _motion_workspace(ct, cm, dev)
         _call("svoxt_motion_feature_render_bwd", ctypes.byref(ct), ctypes.byref(cm), ctypes.byref(cr),
@@ -230,7 +230,7 @@ def warp_vertices(matrices: torch.Tensor, indices: torch.Tensor, skinning_weight
     (vertices_out [Q, 3], matrix_out [Q, 4, 4])."""
     Q, J, B = _check_warp(matrices, indices, skinning_weights, joint_index)
     dev = indices.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         vout = torch.empty((Q, 3), dtype=torch.float32, device=dev)
         mout = torch.empty((Q, 4, 4), dtype=torch.float32, device=dev)
         _call("svoxt_warp_vertices", _ptr(matrices), J, _ptr(indices), Q, _ptr(skinning_weights),
@@ -250,7 +250,7 @@ def warp_vertices_backward(matrices: torch.Tensor, indices: torch.Tensor, skinni
             matrices_grad_out.dtype != torch.float32 or tuple(matrices_grad_out.shape) != (Q, 4, 4):
         raise RuntimeError("gradients must be float32 [Q, 3] and [Q, 4, 4]")
     dev = indices.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         gi = torch.empty((Q, 3), dtype=torch.float32, device=dev)
         gm = torch.empty((J, 4, 4), dtype=torch.float32, device=dev)
         gs = torch.empty((Q, B), dtype=torch.float32, device=dev)
@@ -277,7 +277,7 @@ def refine_leaves(child: torch.Tensor, data: torch.Tensor, parent_depth: torch.T
         if node_id.dtype != torch.int32 or node_id.numel() != leaf_node.shape[0]:
             raise RuntimeError("node_id must be int32 [U]")
     dev = child.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         _call("svoxt_refine", _ptr(leaf_node), leaf_node.shape[0], child.shape[1], int(filled), child.shape[0],
               _ptr(child), _ptr(data), _ptr(parent_depth), _ptr(node_id), _stream(dev))
     for t in (child, data, parent_depth):
@@ -292,7 +292,7 @@ def construct_tree(tree: TreeSpec, indices: torch.Tensor) -> None:
     ct = _pack_tree(tree)
     _check_indices(indices)
     dev = indices.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         _call("svoxt_construct_tree", ctypes.byref(ct), _ptr(indices), indices.shape[0], _stream(dev))
     # tree.data was written behind torch's back: tell the version counter (the
     # acceleration-grid cache keys on it) and drop any grid built from the old words
@@ -316,7 +316,7 @@ def build_octree(points: torch.Tensor, offset: torch.Tensor, scaling: torch.Tens
             raise RuntimeError(f"{name} must be float32 [3]")
     dev = points.device
     P = points.shape[0]
-    with torch.cuda.device(dev):
+    with _on(dev):
         nbytes = _lib.svoxt_build_workspace_bytes(int(depth))
         if nbytes < 0:
             raise RuntimeError("build_octree: depth must be in [1, 10]")

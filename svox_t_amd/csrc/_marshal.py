@@ -220,7 +220,30 @@ def _pack_opts(opt: RenderOptions) -> _COptions:
 
 
 def _stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """torch's CURRENT stream on `device` as the library takes it (the raw handle: torch.cuda.current_stream() builds a
+    Stream object around it first -- 4.6 us a call, five calls a step)."""
+    idx = device.index
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx))
+
+
+class _NoContext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CONTEXT = _NoContext()
+
+
+def _on(device):
+    """`with _on(dev):` -- torch.cuda.device(dev) where dev is not the current device already (the library launches on the
+    current device; the context manager costs ~2 us each way, ten a step, and a single-GPU process never needs it)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_CONTEXT
+    return torch.cuda.device(device)
 
 
 def _call(name, *args):
@@ -306,7 +329,7 @@ def _accel_for(tree: TreeSpec, ct: _CTree, bricks: bool = False):
                 and dv == (tree.data._version, tree.data.data_ptr()) and n_int == ct.n_internal and eg == g:
             return cells, g | (SVOXT_ACCEL_BRICKS if bricks else 0)
     dev = tree.child.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         nbytes = _lib.svoxt_accel_bytes(g, ct.n_internal)       # grid cells + (child, data) pairs
         cells = torch.empty((nbytes // 8, 2), dtype=torch.int32, device=dev)
         _call("svoxt_accel_build", ctypes.byref(ct), g | (SVOXT_ACCEL_BRICKS if bricks else 0), _ptr(cells), _stream(dev))
