@@ -64,7 +64,12 @@ ROUND = "r05"        # which round's committed profiles the line quotes (profile
 # PREWARM_TOL of their median, at most PREWARM_MAX_S.  (r04: a fixed count of 30 + 5 steps, ~25 ms of GPU work, left
 # the first process on a fresh box with backwards at 0.41-0.45 ms against 0.26 ms in steady state -- BENCH_r04.json,
 # gpurun_out/r4b/bench_d8_1.json vs _2.json: the memory side of a cold device; BASELINE.md "fresh box".)
-PREWARM_MIN_S, PREWARM_MAX_S, PREWARM_WINDOW, PREWARM_TOL, PREWARM_BATCH = 0.5, 3.0, 10, 0.05, 20
+PREWARM_MIN_S, PREWARM_MAX_S, PREWARM_WINDOW, PREWARM_TOL, PREWARM_BATCH = 1.0, 4.0, 10, 0.05, 20
+# ... and no downward trend left: the median of the steps of the last PREWARM_TREND_S seconds within PREWARM_TREND_TOL of the median of
+# the PREWARM_TREND_S before them (r05: a fresh box's backward went 0.2702 -> 0.2638 ms over its first 0.5 s and on to 0.258 -- inside
+# the 5 % window all the way, so `converged` said yes while the device was still warming: the headline 1 252 beside 1 298 for the
+# routes measured after it)
+PREWARM_TREND_S, PREWARM_TREND_TOL = 0.4, 0.01
 STALL_FACTOR = 4.0
 
 
@@ -456,6 +461,12 @@ def main(argv=None):
     # least PREWARM_MIN_S have passed AND the last PREWARM_WINDOW forward and backward intervals each lie within
     # PREWARM_TOL of their median -- or PREWARM_MAX_S are over, which the line then shows (`prewarm.converged` false).
     # Every rank runs the same number of batches (the decision is all-reduced): the collectives stay matched.
+    # (the host's own pauses stay out of the K timed steps as far as they can be kept out: the cyclic collector runs HERE, before
+    # the warm-up, and not again until the timed steps are over -- between warm-up and timed steps it would leave the device idle
+    # for tens of milliseconds, and an idle device's memory side takes ~15 steps to come back (r05: backward 0.259 -> 0.268 ms
+    # over the 20 timed steps, 1 290 -> 1 252 Mrays/s); a step that still stalls shows in per_step_ms -- and see `retimed` below)
+    gc.collect()
+    gc.disable()
     pre_ev = new_events(PREWARM_BATCH)
     pre_fwd, pre_bwd, pre_steps, converged = [], [], 0, False
     t_pre = time.perf_counter()
@@ -473,7 +484,15 @@ def main(argv=None):
             w = xs[-PREWARM_WINDOW:]
             m = _median(w)
             return m > 0 and all(abs(x - m) <= PREWARM_TOL * m for x in w)
+        def flat(xs):
+            n = max(PREWARM_BATCH, int(PREWARM_TREND_S * pre_steps / max(el_pre, 1e-9)))      # steps in PREWARM_TREND_S of this workload
+            if len(xs) < 2 * n:
+                return False
+            a, b = _median(xs[-2 * n:-n]), _median(xs[-n:])
+            return b >= (1.0 - PREWARM_TREND_TOL) * a
         converged = settled(pre_fwd) and (args.forward_only or settled(pre_bwd))
+        if args.prewarm_s >= PREWARM_MIN_S:       # (the trend rule with the default warm-up only: profiler runs shorten it)
+            converged = converged and flat(pre_fwd) and (args.forward_only or flat(pre_bwd))
         done = (el_pre >= args.prewarm_s and (converged or args.prewarm_s <= 0)) or el_pre >= PREWARM_MAX_S
         if dist is not None:
             t = torch.tensor([1.0 if done else 0.0, 1.0 if converged else 0.0], dtype=torch.float64, device=dev)
@@ -487,14 +506,10 @@ def main(argv=None):
                "last_batch_ms": {"forward": round(_median(pre_fwd[-PREWARM_BATCH:]), 4),
                                  "backward": round(_median(pre_bwd[-PREWARM_BATCH:]), 4)},
                "rule": f">= {PREWARM_MIN_S} s of full steps and the last {PREWARM_WINDOW} forward and backward intervals within "
-                       f"{PREWARM_TOL:.0%} of their median, at most {PREWARM_MAX_S} s (untimed; medians of the first / last "
+                       f"{PREWARM_TOL:.0%} of their median, no downward trend left (median of the last {PREWARM_TREND_S} s of steps within {PREWARM_TREND_TOL:.0%} of the {PREWARM_TREND_S} s before), at most {PREWARM_MAX_S} s (untimed; medians of the first / last "
                        f"{PREWARM_BATCH} steps shown: a cold device shows up as first >> last)"}
     if hasattr(_C, "freeze_pools"):
         _C.freeze_pools(True)      # the lists' pool sizes stay what the warm-up settled on: no re-sizing inside the timed steps
-    # (the host's own pauses stay out of the K timed steps as far as they can be kept out: the cyclic collector runs before,
-    # not inside; a step that still stalls shows in per_step_ms -- and see `retimed` below)
-    gc.collect()
-    gc.disable()
     for _ in range(args.warmup):
         step()
     elapsed = timed(args.steps, events=True)
