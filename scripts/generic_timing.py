@@ -23,9 +23,11 @@ for pad in (True, False):      # (r05: one or two channels / other row widths ar
              ("RGBA-style row of 6 floats" + ("" if pad else " [generic kernels]"), 6, "RGBA", None, pad),
              ("RGBA-style row of 12 floats" + ("" if pad else " [generic kernels]"), 12, "RGBA", None, pad),
              ("SH9, components 1..4 only" + ("" if pad else " [generic kernels]"), 28, "SH9", (1, 4), pad)]
-ROWS += [("SH9 x 4 channels [generic: no padding up]", 37, "SH9", None, True)]
+# (r05: more than three channels with a basis in groups of three: GROUP_PAYLOADS)
+ROWS += [("SH9 x 4 channels (two groups of three)", 37, "SH9", None, True), ("SH9 x 4 channels [generic kernels]", 37, "SH9", None, False),
+         ("SH4 x 6 channels (two groups of three)", 25, "SH4", None, True), ("SH4 x 6 channels [generic kernels]", 25, "SH4", None, False)]
 for label, K, fmt, comps, pad in ROWS:
-    _C.PAD_PAYLOADS = pad
+    _C.PAD_PAYLOADS = _C.GROUP_PAYLOADS = pad
     feats = synth.shell_features(st.n_features, K)
     tree = svox.N3Tree.from_arrays(st.child, st.data, st.parent_depth, feats, data_format=fmt, device=dev)
     r = svox.VolumeRenderer(tree) if comps is None else svox.VolumeRenderer(tree, min_comp=comps[0], max_comp=comps[1])
