@@ -25,7 +25,8 @@ for pad in (True, False):      # (r05: one or two channels / other row widths ar
              ("SH9, components 1..4 only" + ("" if pad else " [generic kernels]"), 28, "SH9", (1, 4), pad)]
 # (r05: more than three channels with a basis in groups of three: GROUP_PAYLOADS)
 ROWS += [("SH9 x 4 channels (two groups of three)", 37, "SH9", None, True), ("SH9 x 4 channels [generic kernels]", 37, "SH9", None, False),
-         ("SH4 x 6 channels (two groups of three)", 25, "SH4", None, True), ("SH4 x 6 channels [generic kernels]", 25, "SH4", None, False)]
+         ("SH4 x 6 channels (two groups of three)", 25, "SH4", None, True), ("SH4 x 6 channels [generic kernels]", 25, "SH4", None, False),
+         ("RGBA-style row of 64 floats (31 + 31 + 1 channels)", 64, "RGBA", None, True), ("RGBA-style row of 64 floats [generic kernels]", 64, "RGBA", None, False)]
 for label, K, fmt, comps, pad in ROWS:
     _C.PAD_PAYLOADS = _C.GROUP_PAYLOADS = pad
     feats = synth.shell_features(st.n_features, K)
@@ -53,5 +54,5 @@ for label, K, fmt, comps, pad in ROWS:
             fn()
         torch.cuda.synchronize()
         res.append((time.perf_counter() - t0) / 10 * 1e3)
-    print(f"{label:46s} K = {K:2d}: forward {res[0]:7.3f} ms ({W * H / res[0] / 1e3:7.1f} Mrays/s), forward+backward {res[1]:7.3f} ms "
+    print(f"{label:52s} K = {K:2d}: forward {res[0]:7.3f} ms ({W * H / res[0] / 1e3:7.1f} Mrays/s), forward+backward {res[1]:7.3f} ms "
           f"({W * H / res[1] / 1e3:7.1f} Mrays/s)   [{_C.LAST_ROUTE.get('forward')} | {_C.LAST_ROUTE.get('backward')}]", flush=True)

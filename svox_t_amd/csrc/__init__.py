@@ -729,49 +729,50 @@ def _drop_cols(x, real_cols):
     return torch.cat([x[:, :real_cols], x[:, -1:]], dim=1)
 
 
-# More than three channels with a basis (SH9 x 4 ..., which the per-tile kernels do not hold: three coefficients per record
-# live in LDS and registers) are rendered in GROUPS of three channels, each group as the specialised payload -- channels are
-# independent of each other in the forward (rt_kernel.cu:293-307: one sum per channel), and the gradient is linear in the
-# upstream gradient (:365-494), so the groups' gradients add: a channel's coefficients get their group's, sigma gets the sum,
-# the alpha column's upstream gradient goes with the first group alone.  Forward: the same bits per channel.  Gradient:
-# the sigma entries are sums of per-group terms where the reference adds all channels into one total_color first -- the
-# same value to rounding, held to the tight scale by the tests.  (r05; 800 x 800 / depth 8, SH9 x 4 forward+backward: 5.2 ms
-# on the generic kernels.)  GROUP_PAYLOADS False: off.
+# More channels than a specialised kernel holds -- more than three with an SH basis (the per-tile kernels keep three
+# coefficients per record in LDS and registers), more than 31 in an RGBA-style row (rows of 32 floats are the widest with a
+# channel-lane kernel) -- are rendered in GROUPS, each group as the specialised payload (a last group that is short goes
+# through PAD_PAYLOADS like any short payload): channels are independent of each other in the forward (rt_kernel.cu:293-307:
+# one sum per channel), and the gradient is linear in the upstream gradient (:365-494), so the groups' gradients add: a
+# channel's coefficients get their group's, sigma gets the sum, the alpha column's upstream gradient goes with the first
+# group alone.  Forward: the same bits per channel.  Gradient: the sigma entries are sums of per-group terms where the
+# reference adds all channels into one total_color first -- the same value to rounding, held to the tight scale by the
+# tests.  (r05; 800 x 800 / depth 8, SH9 x 4 forward+backward: 5.2 ms on the generic kernels, 1.35 in two groups.)
+# GROUP_PAYLOADS False: off.
 GROUP_PAYLOADS = True
 
 
 def _group_layout(tree: TreeSpec, opt: RenderOptions):
-    """None, or (basis_dim, channels): an SH payload of 4 .. 12 channels, all components."""
+    """None, or (coefficients per channel, channels, channels per group)."""
     f = tree.features
     if not GROUP_PAYLOADS or not isinstance(f, torch.Tensor) or f.dim() != 2 or f.dtype != torch.float32 or not f.is_cuda:
         return None
+    if _numel(tree._weight_accum) or _numel(getattr(tree, "transformation_matrices", None)):
+        return None
     K, fmt, bd = f.shape[1], int(opt.format), int(opt.basis_dim)
+    if fmt == FORMAT_RGBA:
+        return (1, K - 1, 31) if 32 < K <= 8 * 31 + 1 else None
     if fmt != FORMAT_SH or bd not in (1, 4, 9, 16, 25) or (K - 1) % bd or (int(opt.min_comp), int(opt.max_comp)) != (0, bd - 1):
         return None
     C = (K - 1) // bd
-    if C < 4 or C > 12 or _numel(tree._weight_accum) or _numel(getattr(tree, "transformation_matrices", None)):
-        return None
-    return bd, C
+    return (bd, C, 3) if 4 <= C <= 12 else None
 
 
 def _groups(tree: TreeSpec, rays, lay):
-    """[(tree spec of the group, rays spec of the group, first channel, channels)]: feature tables [M, 3 bd + 1] cut out of
-    the caller's (dummy channels of zeros fill the last group), a spec object per group so that each keeps its own plan;
-    kept on the caller's rays / camera spec for the backward of the same call."""
+    """[(tree spec of the group, rays spec of the group, first channel, channels)]: the groups' feature tables cut out of the
+    caller's (their channels' columns + sigma), a spec object per group so that each keeps its own plan; kept on the caller's
+    rays / camera spec for the backward of the same call."""
     f = tree.features
     key = (id(f), f._version, f.data_ptr(), lay)
     ent = getattr(rays, "_svoxt_groups", None)
     if ent is not None and ent[0] == key:
         return ent[1]
-    bd, C = lay
+    bd, C, per = lay
     out = []
-    for c0 in range(0, C, 3):
-        n = min(3, C - c0)
+    for c0 in range(0, C, per):
+        n = min(per, C - c0)
         with torch.no_grad():
-            parts = [f[:, c0 * bd:(c0 + n) * bd]]
-            if n < 3:
-                parts.append(f.new_zeros((f.shape[0], (3 - n) * bd)))
-            fg = torch.cat(parts + [f[:, -1:]], dim=1)
+            fg = torch.cat([f[:, c0 * bd:(c0 + n) * bd], f[:, -1:]], dim=1)
         fg.requires_grad_(f.requires_grad)
         tg = TreeSpec()
         tg.__dict__.update(tree.__dict__)
@@ -799,7 +800,7 @@ def volume_render(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions, record: bo
     glay = _group_layout(tree, opt) if not record else None
     if glay is not None:
         outs = [(volume_render(tg, rg, opt), n) for tg, rg, _, n in _groups(tree, rays, glay)]
-        return torch.cat([o[:, :n] for o, n in outs] + [outs[0][0][:, 3:]], dim=1)
+        return torch.cat([o[:, :n] for o, n in outs] + [outs[0][0][:, -1:]], dim=1)
     if not record and AUTO_PLAN:
         return _planned_forward("volume", lambda t, r, o, rec: _volume_render(t, r, o, rec), tree, rays, opt)
     return _volume_render(tree, rays, opt, record)
@@ -946,16 +947,13 @@ def volume_render_backward(tree: TreeSpec, rays: RaysSpec, opt: RenderOptions,
     glay = _group_layout(tree, opt) if (lists is None and fwd_output is None) else None
     if glay is not None:
         _check_input(grad_output, "grad_output")
-        bd, C = glay
+        bd, C, _ = glay
         if grad_output.dim() != 2 or grad_output.shape[1] != C + 1:
             raise RuntimeError("grad_output must be float32 [Q, C+1]")
         grad = torch.empty_like(tree.features)
         for tg, rg, c0, n in _groups(tree, rays, glay):
-            parts = [grad_output[:, c0:c0 + n]]
-            if n < 3:
-                parts.append(grad_output.new_zeros((grad_output.shape[0], 3 - n)))
-            parts.append(grad_output[:, C:] if c0 == 0 else grad_output.new_zeros((grad_output.shape[0], 1)))
-            gg = volume_render_backward(tg, rg, opt, torch.cat(parts, dim=1))
+            alpha = grad_output[:, C:] if c0 == 0 else grad_output.new_zeros((grad_output.shape[0], 1))
+            gg = volume_render_backward(tg, rg, opt, torch.cat([grad_output[:, c0:c0 + n], alpha], dim=1))
             grad[:, c0 * bd:(c0 + n) * bd] = gg[:, :n * bd]
             if c0 == 0:
                 grad[:, -1] = gg[:, -1]

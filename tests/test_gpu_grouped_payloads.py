@@ -1,5 +1,5 @@
-"""SH payloads of more than three channels are rendered in groups of three, each group as the specialised 3-channel payload
-(r05; svox_t_amd/csrc/__init__.py, GROUP_PAYLOADS).  The reference is generic in the channel count (rt_kernel.cu:293-306,
+"""SH payloads of more than three channels are rendered in groups of three, RGBA-style rows of more than 32 floats in groups of
+31 channels, each group as the specialised payload (r05; svox_t_amd/csrc/__init__.py, GROUP_PAYLOADS).  The reference is generic in the channel count (rt_kernel.cu:293-306,
 410-425, 470-476).  What must hold is what holds for every route: forward bit for bit against the oracle (channels are
 independent), gradient within 1e-5 of the tight scale (its sigma entries are sums of per-group terms where the reference
 forms one total_color over all channels first), the same as the generic kernels give, through every way of calling."""
@@ -15,7 +15,8 @@ from tests.util import Case, assert_grads_close
 
 pytestmark = pytest.mark.gpu
 
-PAYLOADS = [("SH9", 37), ("SH4", 21), ("SH1", 8), ("SH16", 65), ("SH4", 49)]       # 4 x SH9, 5 x SH4, 7 x SH1, 4 x SH16, 12 x SH4
+PAYLOADS = [("SH9", 37), ("SH4", 21), ("SH1", 8), ("SH16", 65), ("SH4", 49),      # 4 x SH9, 5 x SH4, 7 x SH1, 4 x SH16, 12 x SH4
+            ("RGBA", 33), ("RGBA", 40), ("RGBA", 64), ("RGBA", 95)]                 # rows of 33 / 40 / 64 / 95 floats: groups of 31 channels
 
 
 @pytest.mark.parametrize("image", [True, False])
@@ -27,7 +28,7 @@ def test_grouped_payload_matches_oracle_and_generic_kernels(gpu, fmt, K, image, 
         opt = O.make_options(format=c.format, basis_dim=c.basis_dim, sigma_thresh=th[0], stop_thresh=th[1])
         want = O.volume_render(ot, *c.rays_np(), opt)
         cols = want.shape[1]
-        assert cols == (K - 1) // c.basis_dim + 1
+        assert cols == (K - 1) // max(c.basis_dim, 1) + 1
         g = synth.grad_output(c.Q, cols, seed=5)
         gwant, _, tight = O.volume_render_backward(ot, *c.rays_np(), opt, g.numpy(), want_abs="both")
         routes = {}
