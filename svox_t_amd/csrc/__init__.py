@@ -729,7 +729,7 @@ def _drop_cols(x, real_cols):
     return torch.cat([x[:, :real_cols], x[:, -1:]], dim=1)
 
 
-# More channels than a specialised kernel holds -- more than three with an SH basis (the per-tile kernels keep three
+# More channels than a specialised kernel holds -- more than three with an SH / SG / ASG basis (the per-tile kernels keep three
 # coefficients per record in LDS and registers), more than 31 in an RGBA-style row (rows of 32 floats are the widest with a
 # channel-lane kernel) -- are rendered in GROUPS, each group as the specialised payload (a last group that is short goes
 # through PAD_PAYLOADS like any short payload): channels are independent of each other in the forward (rt_kernel.cu:293-307:
@@ -752,7 +752,8 @@ def _group_layout(tree: TreeSpec, opt: RenderOptions):
     K, fmt, bd = f.shape[1], int(opt.format), int(opt.basis_dim)
     if fmt == FORMAT_RGBA:
         return (1, K - 1, 31) if 32 < K <= 8 * 31 + 1 else None
-    if fmt != FORMAT_SH or bd not in (1, 4, 9, 16, 25) or (K - 1) % bd or (int(opt.min_comp), int(opt.max_comp)) != (0, bd - 1):
+    if fmt not in (FORMAT_SH, FORMAT_SG, FORMAT_ASG) or bd not in (1, 4, 9, 16, 25) or (K - 1) % bd \
+            or (int(opt.min_comp), int(opt.max_comp)) != (0, bd - 1):
         return None
     C = (K - 1) // bd
     return (bd, C, 3) if 4 <= C <= 12 else None
